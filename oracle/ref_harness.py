@@ -1,0 +1,103 @@
+"""Drive the shim-imported reference with INJECTED noise (container only; test infrastructure).
+
+The reference draws four random tensors per generated frame from torch's global
+generator (D4:6475 randn, D4:6611 torch.bernoulli, MultiCategorical.sample's
+uniform, D4:6670 randn_like).  `NoiseTape` replaces those four draws with
+pre-drawn tensors so that the reference, `oracle/restate.py` and the HIP path can
+be compared on identical inputs."""
+from contextlib import contextmanager
+
+import torch
+
+from oracle.ref_import import load_reference
+from oracle.restate import Config
+
+
+def make_noise(cfg: Config, frames, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    n, dl, A = cfg.num_latent_tokens, cfg.dim_latent, cfg.total_discrete_actions
+    return dict(
+        latent=torch.randn(frames, batch, n, dl, generator=g),
+        context=torch.randn(frames, batch, n, dl, generator=g),
+        gumbel_u=torch.rand(frames, batch, A, generator=g).clamp(1e-6, 1. - 1e-6),
+        bern_u=torch.rand(frames, batch, generator=g),
+    )
+
+
+class NoiseTape:
+    def __init__(self, noise):
+        self.noise = noise
+        self.f = 0
+        self.a = 0      # action-type offset within a frame
+
+    def randn(self, shape, **kw):
+        t = self.noise['latent'][self.f]
+        return t.reshape(shape).clone()
+
+    def randn_like(self, t):
+        out = self.noise['context'][self.f].reshape(t.shape).clone()
+        self.f += 1
+        self.a = 0
+        return out
+
+    def bernoulli(self, p):
+        u = self.noise['bern_u'][self.f].reshape(p.shape)
+        return (u < p).float()
+
+    def uniform_like(self, t):
+        n = t.shape[-1]
+        u = self.noise['gumbel_u'][self.f][:, self.a:self.a + n].reshape(t.shape).clone()
+        self.a += n
+        return u
+
+
+@contextmanager
+def injected(noise):
+    D4 = load_reference()
+    import discrete_continuous_embed_readout as dcer
+    tape = NoiseTape(noise)
+    saved = (D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like)
+    D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like = tape.randn, tape.randn_like, tape.bernoulli, tape.uniform_like
+    try:
+        yield tape
+    finally:
+        D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like = saved
+
+
+def build_reference_model(cfg: Config, seed=0, head_scale=True):
+    """Reference DynamicsWorldModel for `cfg` with default init under `seed`; heads get
+    non-trivial weights so logits/values are not all ~0."""
+    D4 = load_reference()
+    torch.manual_seed(seed)
+    m = D4.DynamicsWorldModel(
+        dim=cfg.dim, dim_latent=cfg.dim_latent, num_latent_tokens=cfg.num_latent_tokens,
+        depth=cfg.depth, time_block_every=cfg.time_block_every, attn_heads=cfg.attn_heads,
+        attn_dim_head=cfg.attn_dim_head, num_spatial_tokens=cfg.num_spatial_tokens,
+        num_register_tokens=cfg.num_register_tokens, max_steps=cfg.max_steps, num_tasks=cfg.num_tasks,
+        num_discrete_actions=cfg.num_discrete_actions if len(cfg.num_discrete_actions) > 1 else cfg.num_discrete_actions[0],
+        multi_token_pred_len=cfg.multi_token_pred_len,
+        policy_head_mlp_depth=cfg.policy_head_mlp_depth, value_head_mlp_depth=cfg.value_head_mlp_depth,
+        reward_encoder_kwargs=dict(num_bins=cfg.reward_num_bins, reward_range=cfg.reward_range),
+        value_encoder_kwargs=dict(num_bins=cfg.value_num_bins, reward_range=cfg.value_range),
+    ).eval()
+    if head_scale:
+        with torch.no_grad():
+            m.action_embedder.discrete_action_unembed.mul_(100.)
+            for p in m.to_reward_pred.parameters():
+                if p.ndim == 3: p.mul_(20.)
+            g = torch.Generator().manual_seed(seed + 1)
+            for name, p in m.named_parameters():
+                # learned tokens are randn*1e-2 by default: make them O(0.5) so they matter
+                if name in ('register_tokens', 'agent_learned_embed', 'action_learned_embed') or name.endswith('queries'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+                if name.endswith('gamma'):
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+                if name.endswith('norm.weight') or name.endswith('norm_context.weight') or (name.endswith('.0.weight') and p.ndim == 1):
+                    p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
+            last = m.to_state_terminal_pred[0].layers[-1][1]
+            last.bias.fill_(-2.5)
+    return m
+
+
+def weights_of(model):
+    return {k: v.detach().clone().float() for k, v in model.state_dict().items()}

@@ -1,0 +1,668 @@
+"""CPU fp32 restatement of dreamer4's imagination path (ORACLE — TEST INFRASTRUCTURE).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module, and only as the checker / the reported CPU baseline.  The
+product path (`dreamer4_amd`) never routes through it.
+
+What it restates (reference = /root/reference/dreamer4/dreamer4.py, "D4"):
+  * DynamicsWorldModel.generate                 D4:6308-6774
+  * DynamicsWorldModel.forward, inference branch D4:6792-7295
+  * AxialSpaceTimeTransformer.forward           D4:2927-3267
+  * Attention / naive_attend / rotary / K-norm  D4:1604-1756, 1968-2075
+  * FeedForward, AttentionPool, LQAP            D4:2079-2210
+  * ActionEmbedder embed/unembed/sample/logp    D4:1123-1562
+  * HLGaussRewardEncoder                        D4:1041-1105
+  * calc_gae, z_score, learn_from_experience    D4:404-410, 1566-1600, 5893-6305
+
+Everything is a plain function of (config, weights dict keyed by the
+reference's state_dict names, explicit noise tensors).  No hidden RNG.
+
+Parity pin: `oracle/gen_golden.py` imports the reference unmodified through
+`oracle/shim/` in the build container and checks this file against it
+(tests/test_oracle_vs_reference.py), then freezes tests/golden/*.npz.  The
+third-party pieces the reference delegates to (x_mlps_pytorch create_mlp /
+Ensemble, hl_gauss_pytorch, discrete_continuous_embed_readout.MultiCategorical,
+assoc_scan, torch_einops_utils.masked_mean) are absent from the image: they are
+restated from their published algorithms and are PARITY UNPINNED against the
+real packages (see DESIGN.md section "Oracle").
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+EPS_RMS = torch.finfo(torch.float32).eps  # nn.RMSNorm(eps=None) -> finfo(dtype).eps
+
+
+# ----------------------------------------------------------------------------- config
+
+@dataclass
+class Config:
+    """Supported-subset constructor arguments (names follow D4:4662-4778)."""
+    dim: int
+    dim_latent: int
+    num_latent_tokens: int
+    depth: int = 4
+    time_block_every: int = 4
+    attn_heads: int = 8
+    attn_dim_head: int = 64
+    attn_softclamp_value: float = 50.
+    num_spatial_tokens: int = 4
+    num_register_tokens: int = 8
+    max_steps: int = 64
+    num_tasks: int = 0
+    num_discrete_actions: tuple = (4,)
+    multi_token_pred_len: int = 8
+    policy_head_mlp_depth: int = 3
+    value_head_mlp_depth: int = 3
+    terminal_mlp_depth: int = 1
+    predict_terminals: bool = True
+    reward_range: tuple = (-20., 20.)
+    reward_num_bins: int = 255
+    value_range: tuple = (-20., 20.)
+    value_num_bins: int = 255
+    hl_gauss_sigma_to_bin_ratio: float = 2.
+    hl_gauss_eps: float = 1e-10
+    pool_heads: int = 4          # AttentionPool defaults D4:2147-2148
+    pool_dim_head: int = 64
+    gae_discount_factor: float = 0.997
+    gae_lambda: float = 0.95
+    ppo_eps_clip: float = 0.2
+    policy_entropy_weight: float = 0.01
+    use_delight_gating: bool = True
+    delight_temperature: float = 1.
+    pmpo_pos_to_neg_weight: float = 0.5
+    pmpo_reverse_kl: bool = True
+    pmpo_kl_div_loss_weight: float = 0.3
+    rotary_theta: float = 10000.
+
+    def __post_init__(self):
+        if isinstance(self.num_discrete_actions, int):
+            self.num_discrete_actions = (self.num_discrete_actions,)
+        self.num_discrete_actions = tuple(int(n) for n in self.num_discrete_actions if n > 0)
+
+    @property
+    def is_time(self):
+        return [((i + 1) % self.time_block_every) == 0 for i in range(self.depth)]
+
+    @property
+    def num_time_layers(self):
+        return sum(self.is_time)
+
+    @property
+    def tokens_per_frame(self):
+        # [flow | space | registers | action | agent]   D4:7222
+        return 1 + self.num_spatial_tokens + self.num_register_tokens + 1 + 1
+
+    @property
+    def ff_inner(self):
+        return int(self.dim * 4 * 2 / 3)    # D4:2094
+
+    @property
+    def total_discrete_actions(self):
+        return sum(self.num_discrete_actions)
+
+
+# ----------------------------------------------------------------------------- small ops
+
+def rmsnorm(x, w):
+    return x * torch.rsqrt(x.pow(2).mean(dim=-1, keepdim=True) + EPS_RMS) * w
+
+
+def l2norm(t):
+    return F.normalize(t, dim=-1, p=2)      # x / max(||x||, 1e-12)   D4:521
+
+
+def softclamp(t, value):
+    return (t / value).tanh() * value       # D4:527
+
+
+def rotary_freqs(cfg: Config, seq_len, offset, inv_freq=None):
+    """D4:1604-1624."""
+    dh = cfg.attn_dim_head
+    if inv_freq is None:
+        inv_freq = 1.0 / (cfg.rotary_theta ** (torch.arange(0, dh, 2).float() / dh))
+    t = torch.arange(seq_len).float() + offset
+    freqs = t[:, None] * inv_freq[None, :]
+    return torch.cat((freqs, freqs), dim=-1)            # (n, dh)
+
+
+def apply_rotations(rot, t):
+    """D4:1626-1659; rot (n, dh), t (b, h, n, dh)."""
+    n = t.shape[-2]
+    if rot.shape[-2] > n:
+        rot = rot[-n:]
+    x1, x2 = t.chunk(2, dim=-1)
+    half = torch.cat((-x2, x1), dim=-1)
+    return t * rot.cos() + half * rot.sin()
+
+
+def attend(q, k, v, softclamp_value=None, mask=None, causal=False):
+    """naive_attend D4:1683-1756 (the SDPA branch computes the same math)."""
+    scale = q.shape[-1] ** -0.5
+    sim = torch.einsum('bhid,bhjd->bhij', q, k) * scale
+    if softclamp_value is not None:
+        sim = softclamp(sim, softclamp_value)
+    neg = -torch.finfo(sim.dtype).max
+    if mask is not None:
+        sim = sim.masked_fill(~mask, neg)
+    if causal:
+        i, j = sim.shape[-2:]
+        cm = torch.ones((i, j), dtype=torch.bool).triu(j - i + 1)
+        sim = sim.masked_fill(cm, neg)
+    attn = sim.softmax(dim=-1)
+    return torch.einsum('bhij,bhjd->bhid', attn, v)
+
+
+def special_token_mask(seq_len, num_special):
+    """D4:1769-1783 with special_attend_only_itself=False: ordinary queries may not see special keys."""
+    q = torch.arange(seq_len)[:, None]
+    k = torch.arange(seq_len)[None, :]
+    start = seq_len - num_special
+    return ~((q < start) & (k >= start))
+
+
+def attention(W, pre, tokens, *, heads, dim_head, context=None, kv_cache=None, rot=None,
+              causal=False, residual_values=None, softclamp_value=None, mask=None,
+              belief=True, has_ctx_norm=False):
+    """Attention.forward D4:1968-2075.  tokens (b, n, d); returns (out, (k, v))."""
+    x = rmsnorm(tokens, W[pre + 'norm.weight'])
+    q = x @ W[pre + 'to_q.weight'].t()
+    if context is not None:
+        ctx = rmsnorm(context, W[pre + 'norm_context.weight']) if has_ctx_norm else context
+    else:
+        ctx = x
+    k = ctx @ W[pre + 'to_k.weight'].t()
+    v = ctx @ W[pre + 'to_v.weight'].t()
+
+    def split(t):
+        b, n, _ = t.shape
+        return t.reshape(b, n, -1, dim_head).transpose(1, 2)       # b h n d
+
+    q, k, v = split(q), split(k), split(v)
+
+    if residual_values is not None:                                    # (b, n, h, d)
+        rv = residual_values.transpose(1, 2)
+        mix = torch.sigmoid(x @ W[pre + 'to_learned_value_residual_mix.0.weight'].t()
+                            + W[pre + 'to_learned_value_residual_mix.0.bias'])
+        mix = mix.transpose(1, 2)[..., None]                           # b h n 1
+        v = v.lerp(rv, mix)
+
+    gamma = W[pre + 'k_heads_rmsnorm.gamma']                           # (h, d)
+    k = l2norm(k) * ((gamma + 1.) * dim_head ** 0.5)[None, :, None, :]
+
+    if rot is not None:
+        q = apply_rotations(rot, q)
+        k = apply_rotations(rot, k)
+
+    v_for_belief = v if (belief and context is None) else None
+
+    if kv_cache is not None:
+        ck, cv = kv_cache
+        k = torch.cat((ck, k), dim=-2)
+        v = torch.cat((cv, v), dim=-2)
+
+    out = attend(q, k, v, softclamp_value=softclamp_value, mask=mask, causal=causal)
+
+    if v_for_belief is not None:
+        vn = l2norm(v_for_belief)
+        out = out - (out * vn).sum(dim=-1, keepdim=True) * vn
+
+    gates = torch.sigmoid(x @ W[pre + 'to_gates.0.weight'].t())        # b n h
+    out = out * gates.transpose(1, 2)[..., None]
+
+    b, h, n, d = out.shape
+    out = out.transpose(1, 2).reshape(b, n, h * d)
+    out = out @ W[pre + 'to_out.weight'].t()
+    return out, (k, v)
+
+
+def feedforward(W, pre, x):
+    """FeedForward.forward D4:2105-2116 (SiLU-GLU: first chunk value, second gate)."""
+    h = rmsnorm(x, W[pre + 'norm.weight'])
+    h = h @ W[pre + 'proj_in.weight'].t() + W[pre + 'proj_in.bias']
+    a, g = h.chunk(2, dim=-1)
+    h = a * F.silu(g)
+    return h @ W[pre + 'proj_out.weight'].t() + W[pre + 'proj_out.bias']
+
+
+def attention_pool(cfg, W, pre, x, hiddens):
+    """Residual(AttentionPool) D4:2143-2177 + 1869: one query per token over the stack of layer hiddens."""
+    shape = x.shape
+    ctx = torch.stack(hiddens, dim=-2).reshape(-1, len(hiddens), shape[-1])
+    q = x.reshape(-1, 1, shape[-1])
+    out, _ = attention(W, pre + 'fn.attn.', q, heads=cfg.pool_heads, dim_head=cfg.pool_dim_head,
+                       context=ctx, belief=False, has_ctx_norm=True)
+    return x + out.reshape(shape)
+
+
+def lq_attn_pool(cfg, W, pre, x):
+    """LearnedQueriesAttentionPool D4:2179-2210.  x (..., n, d_kv) -> (..., num_queries, dim)."""
+    lead = x.shape[:-2]
+    ctx = x.reshape(-1, *x.shape[-2:])
+    queries = W[pre + 'queries'][None].expand(ctx.shape[0], -1, -1)
+    out, _ = attention(W, pre + 'attn.', queries, heads=cfg.attn_heads, dim_head=cfg.attn_dim_head,
+                       context=ctx, belief=False, has_ctx_norm=True)
+    return out.reshape(*lead, *out.shape[-2:])
+
+
+# ----------------------------------------------------------------------------- trunk
+
+@dataclass
+class TrunkCache:
+    kv: list = field(default_factory=list)     # per time layer: (k, v) each (b*s, h, t, dh)
+    token_count: int = 0
+
+
+def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='transformer.'):
+    """AxialSpaceTimeTransformer.forward D4:2927-3267 (defaults: value residual, attn pools,
+    final special cross-attn, no final norm).  tokens (b, t, s, d).  When a non-empty cache is
+    given and t > 1 only the last frame is processed (D4:2960-2961)."""
+    b, t, s, d = tokens.shape
+    h, dh = cfg.attn_heads, cfg.attn_dim_head
+    has_cache = cache is not None and len(cache.kv) > 0
+    token_count = cache.token_count if cache is not None else 0
+    if has_cache and t > 1:
+        tokens = tokens[:, -1:]
+        t = 1
+
+    space_mask = special_token_mask(s, 1)
+    rot = rotary_freqs(cfg, t, token_count, W.get(pre + 'time_rotary.inv_freq'))
+
+    vres = rmsnorm(tokens, W[pre + 'to_value_residual.0.weight']) @ W[pre + 'to_value_residual.1.weight'].t()
+    vres = vres.reshape(b, t, s, h, dh)
+
+    layer_hiddens = [tokens]
+    new_kv = []
+    time_idx = 0
+    for i, is_time in enumerate(cfg.is_time):
+        ap = f'{pre}layers.{i}.2.fn.'
+        if is_time:
+            x = tokens.transpose(1, 2).reshape(b * s, t, d)
+            rv = vres.transpose(1, 2).reshape(b * s, t, h, dh)
+            kvc = cache.kv[time_idx] if has_cache else None
+            out, kv = attention(W, ap, x, heads=h, dim_head=dh, kv_cache=kvc, rot=rot, causal=True,
+                                residual_values=rv, softclamp_value=cfg.attn_softclamp_value)
+            new_kv.append(kv)
+            time_idx += 1
+            out = out.reshape(b, s, t, d).transpose(1, 2)
+        else:
+            x = tokens.reshape(b * t, s, d)
+            rv = vres.reshape(b * t, s, h, dh)
+            out, _ = attention(W, ap, x, heads=h, dim_head=dh, residual_values=rv,
+                               softclamp_value=cfg.attn_softclamp_value, mask=space_mask)
+            out = out.reshape(b, t, s, d)
+        tokens = tokens + out
+        layer_hiddens.append(tokens)
+
+        tokens = tokens + feedforward(W, f'{pre}layers.{i}.3.fn.', tokens)
+        layer_hiddens.append(tokens)
+
+        if i != cfg.depth - 1:
+            tokens = attention_pool(cfg, W, f'{pre}attn_pools.{i}.', tokens, layer_hiddens)
+
+    # agent token cross-attends the non-special tokens of its frame   D4:3227-3238
+    non_special, special = tokens[:, :, :-1], tokens[:, :, -1:]
+    cp = pre + 'final_special_cross_attn.fn.'
+    q = special.reshape(b * t, 1, d)
+    ctx = non_special.reshape(b * t, s - 1, d)
+    out, _ = attention(W, cp, q, heads=h, dim_head=dh, context=ctx, belief=True, has_ctx_norm=True)
+    special = special + out.reshape(b, t, 1, d)
+    special = special + feedforward(W, pre + 'final_special_ff.fn.', special)
+    tokens = torch.cat((non_special, special), dim=2)
+
+    tokens = attention_pool(cfg, W, pre + 'final_attn_pool.', tokens, layer_hiddens)
+
+    new_cache = TrunkCache(kv=new_kv, token_count=token_count + t)
+    return tokens, new_cache
+
+
+# ----------------------------------------------------------------------------- world-model forward
+
+def action_tokens(cfg: Config, W, actions, time, batch):
+    """D4:7088-7126 + ActionEmbedder.forward D4:1501-1562 (discrete, all action types).
+    actions (b, time-1 | time, na) int64 or None -> (b, time, d); frame 0 gets a zero token."""
+    d = cfg.dim
+    if actions is None or actions.shape[1] == 0:
+        return torch.zeros(batch, time, d)
+    offsets = torch.tensor([0, *torch.tensor(cfg.num_discrete_actions).cumsum(0)[:-1].tolist()])
+    emb = W['action_embedder.discrete_action_embed.weight'][actions + offsets].sum(dim=-2)
+    emb = emb + W['action_learned_embed']                              # (1, d) broadcast
+    if actions.shape[1] == time:
+        emb = emb[:, :-1]
+    assert emb.shape[1] == time - 1
+    return F.pad(emb, (0, 0, 1, 0), value=0.)
+
+
+def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, tasks=None,
+               cache: TrunkCache | None = None):
+    """DynamicsWorldModel.forward(latent_is_noised=True, return_pred_only=True,
+    return_intermediates=True)  D4:6792-7295.
+
+    latents (b, t, n, dl); signal_levels (b, t) int64; step_size python int (power of two).
+    Returns pred (b, t', n, dl), agent_embed (b, t', d), new cache, where t' = 1 when a
+    non-empty cache was supplied (only the last frame is evaluated — per-frame modules are
+    independent across frames, D4:7168/7251, so the dropped frames are never consumed)."""
+    b, t, n, dl = latents.shape
+    d = cfg.dim
+    has_cache = cache is not None and len(cache.kv) > 0
+    act_tok = action_tokens(cfg, W, actions, t, b)
+    if has_cache and t > 1:
+        latents, signal_levels, act_tok = latents[:, -1:], signal_levels[:, -1:], act_tok[:, -1:]
+        t = 1
+
+    space = lq_attn_pool(cfg, W, 'latents_to_spatial_tokens.', latents)             # b t ns d
+    step_log2 = int(math.log2(step_size))
+    sig = W['signal_levels_embed.weight'][signal_levels]                             # b t d/2
+    stp = W['step_size_embed.weight'][step_log2].expand(b, t, -1)
+    flow_tok = torch.cat((sig, stp), dim=-1)[:, :, None]
+    regs = W['register_tokens'].expand(b, t, -1, -1)
+    agent = W['agent_learned_embed'].expand(b, -1, -1)                               # b 1 d
+    if tasks is not None:
+        agent = agent + W['task_embed.weight'][tasks][:, None]
+    agent = agent[:, None].expand(b, t, -1, -1)
+
+    tokens = torch.cat((flow_tok, space, regs, act_tok[:, :, None], agent), dim=2)
+    tokens, new_cache = transformer(cfg, W, tokens, cache)
+
+    ns = cfg.num_spatial_tokens
+    space_out = tokens[:, :, 1:1 + ns]
+    agent_embed = tokens[:, :, -1]
+
+    x = rmsnorm(space_out, W['to_latent_pred.0.weight'])
+    x = lq_attn_pool(cfg, W, 'to_latent_pred.1.', x)
+    pred = x @ W['to_latent_pred.2.weight'].t()
+    return pred, agent_embed, new_cache
+
+
+# ----------------------------------------------------------------------------- heads
+
+def mlp(W, pre, x, n_layers):
+    """Normed MLP (recipe ASSUMED, see oracle/shim/x_mlps_pytorch): RMSNorm -> Linear -> SiLU, no act on last."""
+    for i in range(n_layers):
+        x = rmsnorm(x, W[f'{pre}layers.{i}.0.weight'])
+        x = x @ W[f'{pre}layers.{i}.1.weight'].t() + W[f'{pre}layers.{i}.1.bias']
+        if i != n_layers - 1:
+            x = F.silu(x)
+    return x
+
+
+def mlp_num_layers(depth):
+    return depth + 2       # create_mlp widths (dim_in, dim x (depth+1), dim_out)
+
+
+def hl_gauss_centers(vrange, num_bins):
+    support = torch.linspace(vrange[0], vrange[1], num_bins + 1).float()
+    return support, (support[:-1] + support[1:]) / 2
+
+
+def hl_gauss_to_scalar(logits, vrange, num_bins):
+    _, centers = hl_gauss_centers(vrange, num_bins)
+    return (logits.softmax(dim=-1) * centers).sum(dim=-1)
+
+
+def hl_gauss_to_probs(cfg: Config, values, vrange, num_bins):
+    support, _ = hl_gauss_centers(vrange, num_bins)
+    sigma = cfg.hl_gauss_sigma_to_bin_ratio * (vrange[1] - vrange[0]) / num_bins
+    values = values.clamp(vrange[0], vrange[1])
+    cdf = torch.special.erf((support - values[..., None]) / (math.sqrt(2.) * sigma))
+    z = cdf[..., -1] - cdf[..., 0]
+    return (cdf[..., 1:] - cdf[..., :-1]) / z.clamp(min=cfg.hl_gauss_eps)[..., None]
+
+
+def reward_head(cfg, W, agent_embed):
+    """to_reward_pred.forward_one(x, id=0) -> bins_to_scalar  D4:5067-5075, 6598-6599."""
+    x = rmsnorm(agent_embed, W['to_reward_pred.params.0'][0])
+    logits = x @ W['to_reward_pred.params.1'][0].t()
+    return hl_gauss_to_scalar(logits, cfg.reward_range, cfg.reward_num_bins)
+
+
+def terminal_prob(cfg, W, denoised_latent):
+    """D4:6606-6611: mean over (view, latent token) -> MLP -> sigmoid."""
+    pooled = denoised_latent.mean(dim=-2)
+    logit = mlp(W, 'to_state_terminal_pred.0.', pooled, mlp_num_layers(cfg.terminal_mlp_depth))
+    return logit.squeeze(-1).sigmoid()
+
+
+def policy_logits(cfg, W, policy_embed):
+    """ActionEmbedder.unembed(pred_head_index=0) D4:1313-1326 -> (..., total_discrete_actions)."""
+    un = W['action_embedder.discrete_action_unembed'][:, 0]            # (na_total, 4d)
+    return policy_embed @ un.t()
+
+
+def _log(t, eps=1e-20):
+    return t.clamp(min=eps).log()
+
+
+def sample_discrete(cfg, logits, u, temperature=1.):
+    """Gumbel-max per action type (D4:485-497 / MultiCategorical.sample).  u uniform, same shape as logits."""
+    outs, o = [], 0
+    for n in cfg.num_discrete_actions:
+        l, uu = logits[..., o:o + n], u[..., o:o + n]
+        g = -_log(-_log(uu))
+        outs.append((l / max(temperature, 1e-10) + g).argmax(dim=-1))
+        o += n
+    return torch.stack(outs, dim=-1)
+
+
+def discrete_log_probs(cfg, logits, actions, with_entropy=False):
+    lps, ents, o = [], [], 0
+    for i, n in enumerate(cfg.num_discrete_actions):
+        lp = logits[..., o:o + n].log_softmax(dim=-1)
+        lps.append(lp.gather(-1, actions[..., i:i + 1]).squeeze(-1))
+        ents.append(-(lp.exp() * lp).sum(dim=-1))
+        o += n
+    lps = torch.stack(lps, dim=-1)
+    return (lps, torch.stack(ents, dim=-1)) if with_entropy else lps
+
+
+def policy_head(cfg, W, agent_embed):
+    return mlp(W, 'policy_head.', agent_embed, mlp_num_layers(cfg.policy_head_mlp_depth))
+
+
+def value_head_bins(cfg, W, agent_embed):
+    return mlp(W, 'value_head.', agent_embed, mlp_num_layers(cfg.value_head_mlp_depth))
+
+
+# ----------------------------------------------------------------------------- generate
+
+def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, tasks=None,
+             prompt_latents=None, prompt_discrete_actions=None, prompt_rewards=None,
+             cache: TrunkCache | None = None, use_time_cache=True, return_terminals=True,
+             context_signal_noise=0.1, discrete_temperature=1.):
+    """DynamicsWorldModel.generate(return_rewards_per_frame, return_agent_actions,
+    return_log_probs_and_values[, return_terminals]) D4:6308-6774, with every RNG draw injected:
+
+      noise['latent'][f]   (b, n, dl)  normal   — D4:6475 for the f-th generated frame
+      noise['context'][f]  (b, n, dl)  normal   — D4:6670
+      noise['gumbel_u'][f] (b, A)      uniform  — MultiCategorical.sample
+      noise['bern_u'][f]   (b,)        uniform  — torch.bernoulli (is_terminal = u < p)
+
+    Returns a dict with the Experience fields plus the final cache."""
+    b = batch_size
+    n, dl = cfg.num_latent_tokens, cfg.dim_latent
+    step_size = cfg.max_steps // num_steps
+    latents = prompt_latents.clone() if prompt_latents is not None else torch.zeros(b, 0, n, dl)
+    ctx_noise = latents.clone()
+    actions = prompt_discrete_actions.clone() if prompt_discrete_actions is not None else \
+        torch.zeros(b, 0, len(cfg.num_discrete_actions), dtype=torch.long)
+    rewards = prompt_rewards.clone() if prompt_rewards is not None else torch.zeros(b, 0)
+    log_probs, values, agent_embeds, policy_embeds = [], [], [], []
+    terminals = torch.zeros(b, dtype=torch.bool)
+    lens = torch.full((b,), time_steps)
+    time_cache = cache
+
+    f = 0
+    while latents.shape[1] < time_steps:
+        cur = latents.shape[1]
+        x = noise['latent'][f].clone()[:, None]                          # b 1 n dl
+        for step in range(num_steps + 1):
+            last = step == num_steps
+            sig_val = min(step * step_size, cfg.max_steps - 1)
+            ctx = latents.lerp(ctx_noise, context_signal_noise)
+            lat_in = torch.cat((ctx, x), dim=1)
+            sig = torch.full((b, cur + 1), cfg.max_steps - 1, dtype=torch.long)
+            sig[:, -1] = sig_val
+            act_in = None
+            if actions.shape[1] > 0:                                               # D4:6515-6518
+                act_in = actions[:, :cur]
+                if act_in.shape[1] < cur:
+                    act_in = F.pad(act_in, (0, 0, 0, cur - act_in.shape[1]), value=0)
+            pred, agent_embed, next_cache = wm_forward(cfg, W, lat_in, sig, step_size, act_in, tasks, time_cache)
+            if last:
+                if use_time_cache:
+                    time_cache = next_cache
+                break
+            pred = pred[:, -1:]
+            t_ = sig_val / cfg.max_steps
+            x = x + (pred - x) / (1. - t_) * (step_size / cfg.max_steps)          # D4:6567-6580
+
+        one = agent_embed[:, -1:]                                                  # b 1 d
+        rewards = torch.cat((rewards, reward_head(cfg, W, one)), dim=1)
+
+        if return_terminals and cfg.predict_terminals:
+            p = terminal_prob(cfg, W, x)                                           # b 1
+            is_term = noise['bern_u'][f] < p[:, 0]
+            just = is_term & ~terminals
+            lens = torch.where(just, torch.full_like(lens, cur + 1), lens)
+            terminals = terminals | is_term
+
+        agent_embeds.append(one)
+        pe = policy_head(cfg, W, one)
+        policy_embeds.append(pe)
+        logits = policy_logits(cfg, W, pe)                                         # b 1 A
+        a = sample_discrete(cfg, logits, noise['gumbel_u'][f][:, None], discrete_temperature)
+        actions = torch.cat((actions, a), dim=1)
+        log_probs.append(discrete_log_probs(cfg, logits, a))
+        values.append(hl_gauss_to_scalar(value_head_bins(cfg, W, one), cfg.value_range, cfg.value_num_bins))
+
+        latents = torch.cat((latents, x), dim=1)
+        ctx_noise = torch.cat((ctx_noise, noise['context'][f][:, None]), dim=1)
+        f += 1
+        if return_terminals and cfg.predict_terminals and bool(terminals.all()):
+            break
+
+    latents = latents.clamp(-1., 1.)
+    T = latents.shape[1]
+    step_mask = torch.arange(T) < lens[:, None]
+    policy_embeds = torch.cat(policy_embeds, dim=1)
+    return dict(
+        latents=latents,
+        agent_embed=torch.cat(agent_embeds, dim=1),
+        rewards=rewards,
+        actions=actions,
+        log_probs=torch.cat(log_probs, dim=1),
+        values=torch.cat(values, dim=1),
+        old_action_unembeds=policy_logits(cfg, W, policy_embeds),
+        lens=lens,
+        terminals=terminals,
+        is_truncated=~terminals,
+        episode_return=(rewards * step_mask.float()).sum(dim=-1),
+        step_size=step_size,
+        cache=time_cache,
+        frames_generated=f,
+    )
+
+
+# ----------------------------------------------------------------------------- learning
+
+def calc_gae(rewards, values, masks, learn_masks, gamma, lam):
+    """D4:1566-1600 (AssocScan reverse == plain reverse recurrence)."""
+    masks = masks.float()
+    v = F.pad(values, (0, 1), value=0.)
+    v, v_next = v[..., :-1], v[..., 1:]
+    delta = rewards + gamma * v_next * masks - v
+    delta = delta.masked_fill(~learn_masks, 0.)
+    gates = gamma * lam * masks
+    gae = torch.zeros_like(delta)
+    h = torch.zeros_like(delta[..., 0])
+    for i in range(delta.shape[-1] - 1, -1, -1):
+        h = gates[..., i] * h + delta[..., i]
+        gae[..., i] = h
+    return gae + v
+
+
+def masked_mean(t, mask):
+    return (t * mask).sum() / mask.sum() if mask.any() else (t * mask).sum()
+
+
+def returns_and_advantage(cfg: Config, exp, normalize=True, eps=1e-6):
+    """D4:5943-6024."""
+    rewards, old_values, lens = exp['rewards'], exp['values'], exp['lens']
+    T = rewards.shape[1]
+    ar = torch.arange(T)
+    gae_len_mask = ar < lens[:, None]
+    rewards = rewards.masked_fill(~gae_len_mask, 0.)
+    old_values = old_values.masked_fill(~gae_len_mask, 0.)
+    learn_lens = lens - exp['is_truncated'].long()
+    mask = ar < learn_lens[:, None]
+    gae_masks = ar < (lens - 1).clamp(min=0)[:, None]
+    term_seq = (ar == (lens - 1).clamp(min=0)[:, None]) & exp['terminals'][:, None]
+    gae_masks = gae_masks & ~term_seq
+    returns = calc_gae(rewards, old_values, gae_masks, mask, cfg.gae_discount_factor, cfg.gae_lambda)
+    adv = returns - old_values
+    if normalize:
+        mean = masked_mean(adv, mask)
+        var = masked_mean((adv - mean).pow(2), mask)
+        adv = (adv - mean) / var.clamp(min=eps).sqrt()
+    return returns, old_values, adv, mask
+
+
+def learn_losses(cfg: Config, W, exp, objective='ppo'):
+    """learn_from_experience(only_learn_policy_value_heads=True) with stored agent embeds  D4:5893-6305.
+    Returns (total_policy_loss, value_loss); differentiable w.r.t. the head tensors in W."""
+    returns, old_values, adv, mask = returns_and_advantage(cfg, exp, normalize=(objective != 'pmpo'))
+    agent_embeds = exp['agent_embed'].detach()
+    actions = exp['actions']
+    old_lp = exp['log_probs'].sum(dim=-1)
+
+    pe = policy_head(cfg, W, agent_embeds)
+    logits = policy_logits(cfg, W, pe)
+    lp, ent = discrete_log_probs(cfg, logits, actions, with_entropy=True)
+    lp = lp.sum(dim=-1)
+    fmask = mask.float()
+
+    gate = 1.
+    if cfg.use_delight_gating:
+        gate = ((-lp * adv) / cfg.delight_temperature).sigmoid().detach()
+
+    if objective == 'ppo':
+        ratio = (lp - old_lp).exp()
+        clipped = ratio.clamp(1. - cfg.ppo_eps_clip, 1. + cfg.ppo_eps_clip)
+        pl = -torch.min(ratio * adv, clipped * adv) * gate
+        policy_loss = masked_mean(pl, mask)
+    elif objective == 'spo':
+        ratio = (lp - old_lp).exp()
+        pl = -(ratio * adv - (adv.abs() * (ratio - 1.).square()) / (2 * cfg.ppo_eps_clip)) * gate
+        policy_loss = masked_mean(pl, mask)
+    elif objective == 'pmpo':
+        pos = (adv >= 0.) & mask
+        neg = (adv < 0.) & mask
+        scaled = lp * gate * adv.tanh().abs()
+        pos_loss = scaled[pos].sum() if pos.any() else 0.
+        neg_loss = scaled[neg].sum() if neg.any() else 0.
+        num = max(1., float(mask.sum()))
+        policy_loss = -cfg.pmpo_pos_to_neg_weight * (pos_loss - neg_loss) / num
+        if cfg.pmpo_kl_div_loss_weight > 0.:
+            new_l, old_l = logits, exp['old_action_unembeds']
+            src, tgt = (old_l, new_l) if cfg.pmpo_reverse_kl else (new_l, old_l)
+            kl, o = 0., 0
+            for n in cfg.num_discrete_actions:
+                a, c = src[..., o:o + n].log_softmax(-1), tgt[..., o:o + n].log_softmax(-1)
+                kl = kl + (a.exp() * (a - c)).sum(dim=-1)
+                o += n
+            policy_loss = policy_loss + masked_mean(kl, mask) * cfg.pmpo_kl_div_loss_weight
+    else:
+        raise ValueError(objective)
+
+    entropy_loss = masked_mean(-ent.sum(dim=-1), mask)
+    total_policy_loss = policy_loss + entropy_loss * cfg.policy_entropy_weight
+
+    vbins = value_head_bins(cfg, W, agent_embeds)
+    rbins = hl_gauss_to_probs(cfg, returns, cfg.value_range, cfg.value_num_bins)
+    vl = -(rbins * vbins.log_softmax(dim=-1)).sum(dim=-1)
+    value_loss = vl[mask].mean()
+    return total_policy_loss, value_loss

@@ -1,0 +1,56 @@
+"""Stand-in for `discrete-continuous-embed-readout>=0.2.10` (pyproject.toml:31).
+MultiCategorical = independent categoricals, one per discrete action type:
+Gumbel-max sampling (argmax(logits / T + G), G = -log(-log U)), log-softmax
+gather for log_prob, -sum p log p entropy, sum p (log p - log q) KL.  Call
+sites: dreamer4.py:1375-1376, 1422-1426, 1478-1481.  The uniform draw goes
+through `uniform_like` so the golden generator can inject it.  PARITY UNPINNED
+against the real package (its RNG draw order in particular).  Continuous
+readouts (Readout / BetaDist) are not restated yet."""
+import torch
+from torch import nn
+
+def uniform_like(t):
+    return torch.rand_like(t)
+
+def _log(t, eps = 1e-20):
+    return t.clamp(min = eps).log()
+
+class MultiCategorical:
+    def __init__(self, logits, use_parallel_multi_discrete = None):
+        self.logits = tuple(logits) if isinstance(logits, (tuple, list)) else (logits,)
+
+    def sample(self, temperature = 1., eps = 1e-10):
+        out = []
+        for l in self.logits:
+            g = -_log(-_log(uniform_like(l)))
+            out.append((l / max(temperature, eps) + g).argmax(dim = -1))
+        return torch.stack(out, dim = -1)
+
+    def log_prob(self, targets):
+        out = []
+        for i, l in enumerate(self.logits):
+            lp = l.log_softmax(dim = -1)
+            t = targets[..., i]
+            t = t.expand(lp.shape[:-1]) if t.shape != lp.shape[:-1] else t
+            out.append(lp.gather(-1, t[..., None]).squeeze(-1))
+        return torch.stack(out, dim = -1)
+
+    def entropy(self):
+        out = []
+        for l in self.logits:
+            lp = l.log_softmax(dim = -1)
+            out.append(-(lp.exp() * lp).sum(dim = -1))
+        return torch.stack(out, dim = -1)
+
+    def kl_div(self, other, keep_num_actions_dim = False):
+        out = []
+        for l, m in zip(self.logits, other.logits):
+            lp, lq = l.log_softmax(dim = -1), m.log_softmax(dim = -1)
+            out.append((lp.exp() * (lp - lq)).sum(dim = -1))
+        kl = torch.stack(out, dim = -1)
+        return kl if keep_num_actions_dim else kl.sum(dim = -1)
+
+class Readout(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError('continuous readout not restated')
