@@ -1,0 +1,133 @@
+"""ctypes binding of libd4hip.so (C-ABI declared in include/d4hip.h).
+
+The shared object is built in-tree by `dreamer4_amd.build.build()` (plain hipcc, no torch
+headers).  Loading fails loudly when it is missing: there is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libd4hip.so')
+
+D4_MAX_ACTION_TYPES = 8
+
+GEMM_RMS_ROWSCALE, GEMM_SILU, GEMM_SWIGLU, GEMM_TRANS_A, GEMM_TRANS_B, GEMM_ACCUMULATE = 1, 2, 4, 8, 16, 32
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ('dim', C.c_int32), ('dim_latent', C.c_int32), ('num_latent_tokens', C.c_int32), ('depth', C.c_int32),
+        ('time_block_every', C.c_int32), ('attn_heads', C.c_int32), ('attn_dim_head', C.c_int32),
+        ('attn_softclamp_value', C.c_float),
+        ('num_spatial_tokens', C.c_int32), ('num_register_tokens', C.c_int32), ('max_steps', C.c_int32),
+        ('num_tasks', C.c_int32), ('num_discrete_action_types', C.c_int32),
+        ('num_discrete_actions', C.c_int32 * D4_MAX_ACTION_TYPES),
+        ('multi_token_pred_len', C.c_int32),
+        ('policy_head_mlp_depth', C.c_int32), ('value_head_mlp_depth', C.c_int32),
+        ('terminal_mlp_depth', C.c_int32), ('predict_terminals', C.c_int32),
+        ('reward_num_bins', C.c_int32), ('value_num_bins', C.c_int32),
+        ('pool_heads', C.c_int32), ('pool_dim_head', C.c_int32),
+        ('gae_discount_factor', C.c_float), ('gae_lambda', C.c_float), ('ppo_eps_clip', C.c_float),
+        ('policy_entropy_weight', C.c_float), ('use_delight_gating', C.c_int32),
+        ('delight_temperature', C.c_float), ('pmpo_pos_to_neg_weight', C.c_float),
+        ('pmpo_kl_div_loss_weight', C.c_float), ('pmpo_reverse_kl', C.c_int32),
+        ('hl_gauss_sigma_to_bin_ratio', C.c_float), ('hl_gauss_eps', C.c_float),
+        ('value_min', C.c_float), ('value_max', C.c_float),
+        ('max_batch', C.c_int32), ('max_frames', C.c_int32), ('max_parallel_frames', C.c_int32),
+        ('max_learn_rows', C.c_int32),
+    ]
+
+
+class RolloutIO(C.Structure):
+    _fields_ = [
+        ('batch', C.c_int32), ('time_steps', C.c_int32), ('prompt_frames', C.c_int32), ('num_steps', C.c_int32),
+        ('use_time_cache', C.c_int32), ('sample_terminals', C.c_int32), ('sample_actions', C.c_int32),
+        ('context_signal_noise', C.c_float), ('discrete_temperature', C.c_float),
+        ('noise_latent', C.c_void_p), ('noise_context', C.c_void_p), ('gumbel_u', C.c_void_p), ('bern_u', C.c_void_p),
+        ('tasks', C.c_void_p),
+        ('latents', C.c_void_p), ('actions', C.c_void_p), ('rewards', C.c_void_p), ('ctx_hist', C.c_void_p),
+        ('agent_embed', C.c_void_p), ('log_probs', C.c_void_p), ('values', C.c_void_p), ('action_logits', C.c_void_p),
+        ('lens', C.c_void_p), ('terminals', C.c_void_p),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class LearnIO(C.Structure):
+    _fields_ = [
+        ('batch', C.c_int32), ('time', C.c_int32), ('objective', C.c_int32), ('normalize_advantages', C.c_int32),
+        ('eps', C.c_float),
+        ('agent_embed', C.c_void_p), ('actions', C.c_void_p), ('old_log_probs', C.c_void_p), ('old_values', C.c_void_p),
+        ('rewards', C.c_void_p), ('old_action_logits', C.c_void_p), ('lens', C.c_void_p), ('is_truncated', C.c_void_p),
+        ('terminals', C.c_void_p),
+        ('allreduce_sum', ALLREDUCE_FN), ('allreduce_user', C.c_void_p),
+        ('losses', C.c_void_p), ('returns', C.c_void_p),
+    ]
+
+
+# every symbol include/d4hip.h declares: (restype, argtypes)
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SYMBOLS = {
+    'd4_last_error': (C.c_char_p, []),
+    'd4_version': (_I, []),
+    'd4_engine_create': (_I, [C.POINTER(Config), C.POINTER(_P)]),
+    'd4_engine_destroy': (None, [_P]),
+    'd4_engine_workspace_bytes': (C.c_size_t, [_P]),
+    'd4_engine_set_workspace': (_I, [_P, _P, C.c_size_t]),
+    'd4_engine_bind': (_I, [_P, C.c_char_p, _P, _P, _L]),
+    'd4_engine_prepare': (_I, [_P, _P]),
+    'd4_engine_cache_frames': (_I, [_P]),
+    'd4_engine_cache_reset': (_I, [_P, _I]),
+    'd4_engine_cache_export': (_I, [_P, _P, _I, _P]),
+    'd4_engine_cache_import': (_I, [_P, _P, _I, _I, _P]),
+    'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),
+    'd4_learn': (_I, [_P, C.POINTER(LearnIO), _P]),
+    'd4_group_numel': (_L, [_P, _I]),
+    'd4_optim_step': (_I, [_P, _I, _P, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    'd4_debug_buffer': (_I, [_P, C.c_char_p, C.POINTER(_P)]),
+    'd4_gemm': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    'd4_rmsnorm': (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
+    'd4_hl_gauss_scalar': (_I, [_P, _I, _P, _P, _I, _I, _P]),
+    'd4_gae': (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+class D4Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load libd4hip.so; raises when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise D4Error(f'{LIB_PATH} is missing: run `python -m dreamer4_amd.build` (hipcc, gfx950). '
+                      'There is no CPU fallback for the imagination path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().d4_last_error()
+        raise D4Error(f'd4hip error {rc}: {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'd4hip expects contiguous tensors'
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,197 @@
+// Attention cores of the imagination path: everything between the Q/K/V projection GEMM and the
+// output projection GEMM of reference Attention.forward (D4:2003-2064) in one kernel each.
+//
+//   value-residual lerp (D4:2005-2012) -> K head-RMSNorm (D4:1663-1679, 2017) -> rotary (time
+//   layers, D4:1626-1659) -> [KV cache] -> q.k^T * dh^-1/2 -> softclamp 50*tanh(s/50) (D4:527) ->
+//   special-token / causal mask (D4:1738, 1781) -> softmax -> .v -> belief projection
+//   (D4:2049-2054) -> sigmoid head gates (D4:2058-2060)
+//
+// Head dim is 64 == one wavefront: lane = feature index, one wave per (sequence, head).  Row dot
+// products are DPP row reductions + readlane; scores therefore live in SGPRs.  These kernels are
+// HBM/latency bound (S = 15 tokens per frame): each q/k/v element is read exactly once per wave.
+#include "common.h"
+#include "kernels.h"
+#include <float.h>
+
+namespace d4 {
+
+__device__ __forceinline__ float lerp_torch(float a, float b, float w) {
+    // at::native::lerp: two-branch form
+    float d = b - a;
+    return (fabsf(w) < 0.5f) ? a + w * d : b - d * (1.f - w);
+}
+
+template <int NKM>
+__global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= p.groups * p.heads) return;
+    const int g = wid / p.heads, h = wid % p.heads;
+    const int lane = threadIdx.x & 63;
+    const int nk = p.nk, nq = p.nq;
+    const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;   // (gamma + 1) * sqrt(64)
+
+    float K[NKM], V[NKM];
+#pragma unroll
+    for (int j = 0; j < NKM; ++j) {
+        K[j] = 0.f; V[j] = 0.f;
+        if (j < nk) {
+            float kj = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
+            float vj = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+            if (p.vres) {
+                float vr = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                float w = sigmoidf(p.mix[g * p.m_group_stride + j * p.m_item_stride + h]);
+                vj = lerp_torch(vj, vr, w);
+            }
+            float nrm = sqrtf(wave_sum(kj * kj));
+            K[j] = kj / fmaxf(nrm, 1e-12f) * kscale;
+            V[j] = vj;
+        }
+    }
+
+    for (int i = 0; i < nq; ++i) {
+        const float qi = p.q[g * p.q_group_stride + i * p.q_item_stride + h * 64 + lane];
+        float s[NKM];
+        float m = -FLT_MAX;
+        const bool ordinary_q = p.mask_special > 0 && i < nq - p.mask_special;
+#pragma unroll
+        for (int j = 0; j < NKM; ++j) {
+            s[j] = -FLT_MAX;
+            if (j < nk) {
+                float sc = wave_sum(qi * K[j]) * 0.125f;
+                if (p.softclamp > 0.f) sc = tanhf(sc / p.softclamp) * p.softclamp;
+                if (ordinary_q && j >= nk - p.mask_special) sc = -FLT_MAX;
+                s[j] = sc;
+                m = fmaxf(m, sc);
+            }
+        }
+        float l = 0.f, acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKM; ++j) {
+            if (j < nk) {
+                float e = expf(s[j] - m);
+                l += e;
+                acc += e * V[j];
+            }
+        }
+        float o = acc / l;
+        if (p.belief) {
+            // v_i (self attention): re-read and re-mix rather than index the register array dynamically
+            float vi = p.v[g * p.v_group_stride + i * p.v_item_stride + h * 64 + lane];
+            if (p.vres) {
+                float vr = p.vres[g * p.r_group_stride + i * p.r_item_stride + h * 64 + lane];
+                float w = sigmoidf(p.mix[g * p.m_group_stride + i * p.m_item_stride + h]);
+                vi = lerp_torch(vi, vr, w);
+            }
+            float vn = vi / fmaxf(sqrtf(wave_sum(vi * vi)), 1e-12f);
+            o -= wave_sum(o * vn) * vn;
+        }
+        if (p.gate) o *= sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
+        p.out[g * p.o_group_stride + i * p.o_item_stride + h * 64 + lane] = o;
+    }
+}
+
+int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
+    D4_REQUIRE(p.nk >= 1 && p.nk <= 64, "small_attn: nk=%d out of range [1,64]", p.nk);
+    D4_REQUIRE(!p.belief || p.nq == p.nk, "small_attn: belief needs self attention");
+    const int waves = p.groups * p.heads;
+    if (waves == 0) return 0;
+    dim3 grid(cdiv(waves, 4)), block(256);
+    if (p.nk <= 16) hipLaunchKernelGGL(small_attn_kernel<16>, grid, block, 0, stream, p);
+    else if (p.nk <= 32) hipLaunchKernelGGL(small_attn_kernel<32>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(small_attn_kernel<64>, grid, block, 0, stream, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// time axis
+
+__device__ __forceinline__ float rotate_half_lane(float x, int lane, float pos, const float* inv_freq) {
+    // freqs = cat(f, f); rotated = x * cos + cat(-x2, x1) * sin      (D4:1624, 1653-1658)
+    const float f = pos * inv_freq[lane & 31];
+    const float partner = __shfl_xor(x, 32);
+    const float half = (lane < 32) ? -partner : partner;
+    float sn, cs;
+    sincosf(f, &sn, &cs);
+    return x * cs + half * sn;
+}
+
+__global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = p.B * p.Tq * p.S;
+    if (wid >= rows * p.H) return;
+    const int row = wid / p.H, h = wid % p.H;
+    const int lane = threadIdx.x & 63;
+    const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
+    const int hd = p.H * 64;
+    const float* pr = p.proj + (int64_t)row * p.ldp;
+    float k = pr[hd + h * 64 + lane];
+    float v = pr[2 * hd + h * 64 + lane];
+    const float vr = p.vres[(int64_t)row * p.ldv + h * 64 + lane];
+    const float w = sigmoidf(pr[3 * hd + p.H + h]);
+    v = lerp_torch(v, vr, w);
+    const float nrm = sqrtf(wave_sum(k * k));
+    k = k / fmaxf(nrm, 1e-12f) * ((p.k_gamma[h * 64 + lane] + 1.f) * 8.f);
+    const int pos = p.t0 + tq;
+    k = rotate_half_lane(k, lane, (float)pos, p.inv_freq);
+    const int64_t col = (int64_t)b * p.S + s;
+    const int64_t cols = (int64_t)p.cache_batch * p.S;
+    const int64_t off = ((col * p.H + h) * p.Tcap + pos) * 64 + lane;
+    p.cache[off] = k;
+    p.cache[cols * p.H * p.Tcap * 64 + off] = v;
+}
+
+__global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = p.B * p.Tq * p.S;
+    if (wid >= rows * p.H) return;
+    const int row = wid / p.H, h = wid % p.H;
+    const int lane = threadIdx.x & 63;
+    const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
+    const int hd = p.H * 64;
+    const float* pr = p.proj + (int64_t)row * p.ldp;
+    const int pos = p.t0 + tq;
+    float q = rotate_half_lane(pr[h * 64 + lane], lane, (float)pos, p.inv_freq);
+    const int64_t col = (int64_t)b * p.S + s;
+    const int64_t cols = (int64_t)p.cache_batch * p.S;
+    const float* ck = p.cache + ((col * p.H + h) * p.Tcap) * 64 + lane;
+    const float* cv = ck + cols * p.H * p.Tcap * 64;
+
+    float m = -FLT_MAX, l = 0.f, acc = 0.f;
+    for (int j = 0; j <= pos; ++j) {
+        float sc = wave_sum(q * ck[j * 64]) * 0.125f;
+        if (p.softclamp > 0.f) sc = tanhf(sc / p.softclamp) * p.softclamp;
+        const float mn = fmaxf(m, sc);
+        const float alpha = expf(m - mn);
+        const float e = expf(sc - mn);
+        l = l * alpha + e;
+        acc = acc * alpha + e * cv[j * 64];
+        m = mn;
+    }
+    float o = acc / l;
+    // belief: orthogonalise against this step's (mixed) value            D4:2049-2054
+    const float vi = cv[pos * 64];
+    const float vn = vi / fmaxf(sqrtf(wave_sum(vi * vi)), 1e-12f);
+    o -= wave_sum(o * vn) * vn;
+    o *= sigmoidf(pr[3 * hd + h]);
+    p.out[(int64_t)row * p.ldo + h * 64 + lane] = o;
+}
+
+int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
+    D4_REQUIRE(p.t0 + p.Tq <= p.Tcap, "time attention: cache capacity %d exceeded (t0=%d, Tq=%d)", p.Tcap, p.t0, p.Tq);
+    const int waves = p.B * p.Tq * p.S * p.H;
+    if (waves == 0) return 0;
+    hipLaunchKernelGGL(time_kv_append_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
+    const int waves = p.B * p.Tq * p.S * p.H;
+    if (waves == 0) return 0;
+    hipLaunchKernelGGL(time_attn_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace d4

@@ -1,0 +1,370 @@
+// Glue kernels of the imagination path: weight preparation (RMSNorm gamma folding, SiLU-GLU pair
+// packing), token assembly (D4:7182-7222), latent-pred post-processing, shortcut-flow Euler step
+// (D4:6567-6580), and the small per-frame heads (D4:6595-6662).  All HBM-bound, fully coalesced
+// (float4 where the layout allows), grid-stride.
+#include "common.h"
+#include "kernels.h"
+#include <float.h>
+
+namespace d4 {
+
+static inline dim3 grid1d(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g);
+}
+
+// ---------------------------------------------------------------------------------- weight prep
+__global__ void fold_rows_kernel(const float* W, const float* gamma, float* out, int rows, int K, int ld_out) {
+    const int64_t n = (int64_t)rows * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / K), k = (int)(i % K);
+        out[(int64_t)r * ld_out + k] = W[i] * (gamma ? gamma[k] : 1.f);
+    }
+}
+int fold_rows(const float* W, const float* gamma, float* out, int rows, int K, int ld_out, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(fold_rows_kernel, grid1d((int64_t)rows * K), dim3(256), 0, s, W, gamma, out, rows, K, ld_out);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void copy_rows_kernel(const float* src, int lds, float* dst, int ldd, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c];
+    }
+}
+int copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s) {
+    if (rows == 0 || cols == 0) return 0;
+    hipLaunchKernelGGL(copy_rows_kernel, grid1d((int64_t)rows * cols), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void fill_kernel(float* dst, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+int fill_f32(float* dst, float v, int64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, grid1d(n), dim3(256), 0, s, dst, v, n);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// proj_in [2*inner][K] (value rows first, gate rows second, D4:2111) -> packed [2*inner_pad][K]:
+// per 64 packed rows: 32 value rows then the matching 32 gate rows; gamma folded; zero rows for padding.
+__global__ void swiglu_pack_kernel(const float* W, const float* bias, const float* gamma, float* Wp, float* bp,
+                                   int inner, int inner_pad, int K) {
+    const int64_t n = (int64_t)2 * inner_pad * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int pr = (int)(i / K), k = (int)(i % K);
+        int blk = pr / 64, e = pr % 64;
+        int hidden = blk * 32 + (e % 32);
+        bool is_gate = e >= 32;
+        float w = 0.f, b = 0.f;
+        if (hidden < inner) {
+            int src = hidden + (is_gate ? inner : 0);
+            w = W[(int64_t)src * K + k] * gamma[k];
+            b = bias[src];
+        }
+        Wp[i] = w;
+        if (k == 0) bp[pr] = b;
+    }
+}
+int swiglu_pack_rows(const float* W, const float* bias, const float* gamma, float* Wp, float* bp,
+                     int inner, int inner_pad, int K, hipStream_t s) {
+    hipLaunchKernelGGL(swiglu_pack_kernel, grid1d((int64_t)2 * inner_pad * K), dim3(256), 0, s, W, bias, gamma, Wp, bp, inner, inner_pad, K);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void pad_cols_kernel(const float* W, float* out, int rows, int cols, int cols_pad) {
+    const int64_t n = (int64_t)rows * cols_pad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / cols_pad), c = (int)(i % cols_pad);
+        out[i] = c < cols ? W[(int64_t)r * cols + c] : 0.f;
+    }
+}
+int pad_cols(const float* W, float* out, int rows, int cols, int cols_pad, hipStream_t s) {
+    hipLaunchKernelGGL(pad_cols_kernel, grid1d((int64_t)rows * cols_pad), dim3(256), 0, s, W, out, rows, cols, cols_pad);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- RMSNorm (explicit; head MLPs)
+// one wave per row
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* x, int ldx, const float* gamma, float* y, int ldy,
+                                                           int rows, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)row * ldx;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { float v = xr[c]; ss += v * v; }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    float* yr = y + (int64_t)row * ldy;
+    for (int c = lane; c < D; c += 64) yr[c] = xr[c] * rstd * (gamma ? gamma[c] : 1.f);
+}
+int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int D, float eps, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, y, ldy, rows, D, eps);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- token assembly
+// tokens[(b,t)][s] = [flow | space x ns | registers x nr | action | agent]          D4:7182-7222
+__global__ void assemble_kernel(AssembleArgs p) {
+    const int D = p.D;
+    const int64_t n = (int64_t)p.B * p.Tq * p.S * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int s = (int)((i / D) % p.S);
+        const int64_t f = i / ((int64_t)D * p.S);         // frame index (b * Tq + t)
+        const int b = (int)(f / p.Tq);
+        float v;
+        if (s == 0) {
+            const int half = D / 2;
+            v = d < half ? p.signal_embed[(int64_t)p.signal_levels[f] * half + d]
+                         : p.step_embed[(int64_t)p.step_log2 * half + (d - half)];
+        } else if (s <= p.ns) {
+            v = p.space[(f * p.ns + (s - 1)) * D + d];
+        } else if (s <= p.ns + p.nr) {
+            v = p.registers[(int64_t)(s - 1 - p.ns) * D + d];
+        } else if (s == p.ns + p.nr + 1) {
+            v = 0.f;
+            if (p.prev_actions && p.prev_actions[f * p.na] >= 0) {
+                for (int a = 0; a < p.na; ++a)
+                    v += p.action_embed[(p.prev_actions[f * p.na + a] + p.action_offsets[a]) * D + d];
+                v += p.action_learned[d];
+            }
+        } else {
+            v = p.agent_embed[d];
+            if (p.tasks) v += p.task_embed[p.tasks[b] * D + d];
+        }
+        p.tokens[i] = v;
+    }
+}
+int assemble_tokens(const AssembleArgs& p, hipStream_t s) {
+    const int64_t n = (int64_t)p.B * p.Tq * p.S * p.D;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(assemble_kernel, grid1d(n), dim3(256), 0, s, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// to_latent_pred.0 RMSNorm then the LQAP context RMSNorm (D4:4830-4834, 1993): gathered rows only.
+__global__ __launch_bounds__(256) void gather_space_kernel(const float* tokens, float* out, const float* g0, const float* g1,
+                                                           int frames, int S, int D, int ns, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= frames * ns) return;
+    const int lane = threadIdx.x & 63;
+    const int f = r / ns, j = r % ns;
+    const float* xr = tokens + ((int64_t)f * S + 1 + j) * D;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { float v = xr[c]; ss += v * v; }
+    const float r0 = rsqrtf(wave_sum(ss) / (float)D + eps);
+    float ss1 = 0.f;
+    for (int c = lane; c < D; c += 64) { float v = xr[c] * r0 * g0[c]; ss1 += v * v; }
+    const float r1 = rsqrtf(wave_sum(ss1) / (float)D + eps);
+    float* yr = out + (int64_t)r * D;
+    for (int c = lane; c < D; c += 64) yr[c] = (xr[c] * r0 * g0[c]) * r1 * g1[c];
+}
+int gather_space_double_norm(const float* tokens, float* out, const float* g0, const float* g1,
+                             int frames, int S, int D, int ns, float eps, hipStream_t s) {
+    if (frames == 0) return 0;
+    hipLaunchKernelGGL(gather_space_kernel, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, D, ns, eps);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// x += (pred - x) / (1 - t) * (step_size / max_steps)                                  D4:6567-6580
+__global__ void euler_kernel(float* x, int ldx, const float* pred, int ldp, int B, int n_el, float one_minus_t, float dt) {
+    const int64_t n = (int64_t)B * n_el;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n_el), e = (int)(i % n_el);
+        float* xp = x + (int64_t)b * ldx + e;
+        const float xi = *xp;
+        *xp = xi + (pred[(int64_t)b * ldp + e] - xi) / one_minus_t * dt;
+    }
+}
+int euler_step(float* x, int ldx, const float* pred, int ldp, int B, int n_el, float one_minus_t, float dt, hipStream_t s) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(euler_kernel, grid1d((int64_t)B * n_el), dim3(256), 0, s, x, ldx, pred, ldp, B, n_el, one_minus_t, dt);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void silu_kernel(const float* z, float* y, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = siluf(z[i]);
+}
+int silu_rows(const float* z, float* y, int64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(silu_kernel, grid1d(n), dim3(256), 0, s, z, y, n);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// per-evaluation integer inputs: signal level of every frame and the action token source   D4:6492-6523
+__global__ void prep_inputs_kernel(int32_t* sig, int64_t* pact, const int64_t* hist, int B, int Tq, int na, int frame_base,
+                                   int hist_stride, int sig_val, int ctx_sig) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Tq) return;
+    const int b = i / Tq, t = i % Tq;
+    sig[i] = (t == Tq - 1) ? sig_val : ctx_sig;
+    const int g = frame_base + t;
+    for (int a = 0; a < na; ++a)
+        pact[(int64_t)i * na + a] = (g == 0 || !hist) ? -1 : hist[((int64_t)b * hist_stride + (g - 1)) * na + a];
+}
+int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
+                     int hist_stride, int sig_val, int ctx_sig, hipStream_t s) {
+    hipLaunchKernelGGL(prep_inputs_kernel, dim3(cdiv(B * Tq, 128)), dim3(128), 0, s, sig, pact, actions_hist, B, Tq, na, frame_base,
+                       hist_stride, sig_val, ctx_sig);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// engine cache [Lt][2][cache_batch*S][H][Tcap][64]  <->  reference layout (Lt, 2, B*S, H, frames, 64)   D4:2075, 3256
+__global__ void cache_transfer_kernel(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap,
+                                      int frames, int to_ext) {
+    const int64_t n = (int64_t)Lt * 2 * B * S * H * frames * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int d = (int)(r % 64); r /= 64;
+        const int t = (int)(r % frames); r /= frames;
+        const int h = (int)(r % H); r /= H;
+        const int col = (int)(r % ((int64_t)B * S)); r /= (int64_t)B * S;
+        const int kv = (int)(r % 2); r /= 2;
+        const int l = (int)r;
+        const int64_t ci = ((((int64_t)(l * 2 + kv) * cache_batch * S + col) * H + h) * Tcap + t) * 64 + d;
+        if (to_ext) ext[i] = cache[ci]; else cache[ci] = ext[i];
+    }
+}
+int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, hipStream_t s) {
+    const int64_t n = (int64_t)Lt * 2 * B * S * H * frames * 64;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cache_transfer_kernel, grid1d(n), dim3(256), 0, s, cache, ext, Lt, cache_batch, B, S, H, Tcap, frames, to_ext);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[b][t] = t < Tq-1 ? lerp(hist[b][t], ctx_noise[b][t], w) : x[b]                    D4:6497-6499
+__global__ void build_latent_kernel(float* out, const float* hist, const float* ctx, const float* x,
+                                    int B, int Tq, int n_el, int hist_t_stride, float w) {
+    const int64_t n = (int64_t)B * Tq * n_el;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % n_el);
+        const int t = (int)((i / n_el) % Tq);
+        const int b = (int)(i / ((int64_t)n_el * Tq));
+        float v;
+        if (t == Tq - 1) v = x[(int64_t)b * n_el + e];
+        else {
+            const int64_t o = ((int64_t)b * hist_t_stride + t) * n_el + e;
+            const float a = hist[o], c = ctx ? ctx[o] : a;
+            const float d = c - a;
+            v = (fabsf(w) < 0.5f) ? a + w * d : c - d * (1.f - w);
+        }
+        out[i] = v;
+    }
+}
+int build_latent_input(float* out, const float* hist, const float* ctx_noise, const float* x,
+                       int B, int Tq, int n_el, int hist_t_stride, float w, hipStream_t s) {
+    const int64_t n = (int64_t)B * Tq * n_el;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(build_latent_kernel, grid1d(n), dim3(256), 0, s, out, hist, ctx_noise, x, B, Tq, n_el, hist_t_stride, w);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- heads
+// HL-Gauss bins -> scalar: softmax(logits) . bin centres                               D4:1088-1096
+__global__ __launch_bounds__(256) void hl_gauss_scalar_kernel(const float* logits, int ld, const float* centers, float* out,
+                                                              int out_stride, int rows, int bins) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* lr = logits + (int64_t)row * ld;
+    float m = -FLT_MAX;
+    for (int c = lane; c < bins; c += 64) m = fmaxf(m, lr[c]);
+    m = wave_max(m);
+    float l = 0.f, acc = 0.f;
+    for (int c = lane; c < bins; c += 64) {
+        float e = expf(lr[c] - m);
+        l += e;
+        acc += e * centers[c];
+    }
+    l = wave_sum(l);
+    acc = wave_sum(acc);
+    if (lane == 0) out[(int64_t)row * out_stride] = acc / l;
+}
+int hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int out_stride, int rows, int bins, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(hl_gauss_scalar_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, logits, ld, centers, out, out_stride, rows, bins);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// pooled[b][d] = mean_n x[b][n][d]                                                     D4:6606
+__global__ void mean_tokens_kernel(const float* x, float* out, int B, int n, int d) {
+    const int64_t tot = (int64_t)B * d;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / d), c = (int)(i % d);
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) s += x[((int64_t)b * n + j) * d + c];
+        out[i] = s / (float)n;
+    }
+}
+int mean_tokens(const float* x, float* out, int B, int n, int d, hipStream_t s) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(mean_tokens_kernel, grid1d((int64_t)B * d), dim3(256), 0, s, x, out, B, n, d);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ float log_eps(float t) { return logf(fmaxf(t, 1e-20f)); }
+
+// Gumbel-max sampling per action type + log-prob of the sample (D4:485-497, 1374-1376, 1422-1423);
+// Bernoulli terminal draw and lens bookkeeping (D4:6611-6616).  One thread per trajectory.
+__global__ void sample_kernel(SampleArgs p) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= p.B) return;
+    const float* lg = p.logits + (int64_t)b * p.ld;
+    const float* u = p.gumbel_u + (int64_t)b * p.ld_u;
+    const float temp = fmaxf(p.temperature, 1e-10f);
+    int o = 0;
+    for (int a = 0; a < p.na; ++a) {
+        const int n = p.action_sizes[a];
+        float best = -FLT_MAX, mx = -FLT_MAX;
+        int arg = 0;
+        for (int j = 0; j < n; ++j) {
+            const float l = lg[o + j];
+            const float g = -log_eps(-log_eps(u[o + j]));
+            const float sc = l / temp + g;
+            if (sc > best) { best = sc; arg = j; }
+            mx = fmaxf(mx, l);
+        }
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += expf(lg[o + j] - mx);
+        p.actions[(int64_t)b * p.act_stride + a] = arg;
+        p.log_probs[(int64_t)b * p.lp_stride + a] = (lg[o + arg] - mx) - logf(se);
+        o += n;
+    }
+    if (p.term_logit) {
+        const float pr = sigmoidf(p.term_logit[b]);
+        const bool is_term = p.bern_u[b] < pr;
+        const bool was = p.terminals[b] != 0;
+        if (is_term && !was) p.lens[b] = p.frame_index + 1;
+        p.terminals[b] = (was || is_term) ? 1 : 0;
+    }
+}
+int sample_actions_terminals(const SampleArgs& p, hipStream_t s) {
+    if (p.B == 0) return 0;
+    hipLaunchKernelGGL(sample_kernel, dim3(cdiv(p.B, 128)), dim3(128), 0, s, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace d4

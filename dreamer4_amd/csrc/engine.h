@@ -1,0 +1,93 @@
+// Engine state of the MI355X imagination runtime (one per process / GPU).
+#pragma once
+#include "../../include/d4hip.h"
+#include "kernels.h"
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace d4 {
+
+struct Bound { const float* p; float* g; int64_t n; };
+
+struct AttnW {            // a reference `Attention` module (D4:1887)
+    const float *norm = nullptr, *norm_ctx = nullptr, *to_q = nullptr, *to_k = nullptr, *to_v = nullptr,
+                *to_out = nullptr, *to_gates = nullptr, *k_gamma = nullptr, *mix_w = nullptr, *mix_b = nullptr;
+};
+struct FfW { const float *norm, *in_w, *in_b, *out_w, *out_b; };
+
+struct FfPrep { float *w1, *b1, *w2; };
+
+struct Mlp {              // normed MLP head: [RMSNorm -> Linear(+bias) -> SiLU]*, no activation on the last layer
+    int nl = 0;
+    int dims[10];
+    const float *g[9], *w[9], *b[9];
+    float *dg[9], *dw[9], *db[9];       // gradient buffers (may be null)
+};
+
+}  // namespace d4
+
+struct d4_engine {
+    d4_config c;
+    std::unordered_map<std::string, d4::Bound> bound;
+
+    // derived sizes
+    int S, hd, hp, php, D, Nproj, Nproj0, inner, inner_pad, Lt, A, na, ldpq, ldcq, nslab;
+    std::vector<int> is_time, time_index;
+    int maxB, maxTq, Tcap, Mmax, Fr;
+
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0, ws_need = 0;
+    bool prepared = false;
+    int cache_frames = 0;
+
+    // ---- bound (raw) weights
+    std::vector<d4::AttnW> layer_attn;
+    std::vector<d4::FfW> layer_ff;
+    std::vector<d4::AttnW> pools;          // depth-1 layer pools, then the final pool
+    d4::AttnW cross, lq_in, lq_out;
+    d4::FfW sff;
+    const float *vres_norm, *vres_w, *inv_freq, *lq_in_queries, *lq_out_queries, *latent_norm, *latent_w;
+    const float *registers, *signal_embed, *step_embed, *agent_learned, *action_learned, *task_embed, *action_embed;
+    const float *action_unembed; float* action_unembed_grad;
+    const float *reward_norm, *reward_w, *reward_centers, *value_centers, *value_support;
+    d4::Mlp policy, value, terminal;
+
+    // ---- prepared weight images (workspace)
+    std::vector<float*> proj_w, proj_b;
+    std::vector<d4::FfPrep> ffp;           // depth layers + special ff at index depth
+    std::vector<float*> pq_w, pkv_w;
+    float *cq_w, *ckv_w;
+    float *lin_kv_w, *lin_q, *lin_gate, *lout_kv_w, *lout_q, *lout_gate, *qtmp;
+    int32_t *action_offsets, *action_sizes;
+
+    // ---- activations (workspace)
+    float *slabs, *xpool, *proj0, *proj, *att, *ffh, *pool_q, *pool_kv, *pool_att, *cq, *ckv, *catt;
+    float *lat_in, *lkv, *latt, *space, *gs, *okv, *oatt, *oproj, *pred, *x_lat;
+    int32_t* sig;
+    int64_t* pact;
+    float* cache;
+    float *agent_c, *hbuf[2], *hnorm, *rlogits, *term_pool, *term_logit;
+
+    // ---- learner (workspace; sized by max_learn_rows)
+    int LR = 0;
+    float *l_save;                         // per-layer saved activations for both MLP heads
+    float *l_tmp[3];
+    float *l_logits, *l_dlogits, *l_vbins, *l_dvbins, *l_returns, *l_adv, *l_scal;
+};
+
+namespace d4 {
+int engine_layout(d4_engine* e, bool assign);
+int engine_resolve(d4_engine* e);
+int engine_prepare(d4_engine* e, hipStream_t s);
+int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
+                   const int64_t* tasks, hipStream_t s);
+int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, float* out, int ldo,
+                float* save, hipStream_t s);
+int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s);
+int optim_step(d4_engine* e, int group, float* state, int step, float lr, float b1, float b2, float eps,
+               float wd, float max_norm, float grad_scale, float* norm_out, hipStream_t s);
+int64_t group_numel(const d4_engine* e, int group);
+const char* last_error();
+}  // namespace d4

@@ -1,0 +1,779 @@
+// Native runtime of the imagination path: weight binding by reference state_dict key, weight
+// preparation, the world-model forward (reference DynamicsWorldModel.forward inference branch +
+// AxialSpaceTimeTransformer.forward, D4:6792-7295, 2927-3267) and the rollout driver (reference
+// DynamicsWorldModel.generate, D4:6308-6774).  Everything is enqueued on one HIP stream without
+// host synchronisation; the only host-side state is the KV-cache frame counter.
+#include "common.h"
+#include "engine.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+using namespace d4;
+
+namespace d4 {
+
+static constexpr float RMS_EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps (nn.RMSNorm eps=None)
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------- layout
+int engine_layout(d4_engine* e, bool assign) {
+    const d4_config& c = e->c;
+    size_t off = 0;
+    auto alloc_bytes = [&](size_t bytes) -> char* {
+        off = (off + 255) / 256 * 256;
+        char* p = assign ? e->ws + off : nullptr;
+        off += bytes;
+        return p;
+    };
+    auto fl = [&](size_t n) { return reinterpret_cast<float*>(alloc_bytes(n * sizeof(float))); };
+
+    const int D = e->D, hd = e->hd, hp = e->hp, depth = c.depth, S = e->S;
+    const int n = c.num_latent_tokens, dl = c.dim_latent, ns = c.num_spatial_tokens;
+    const size_t M = e->Mmax, Fr = e->Fr;
+
+    e->proj_w.assign(depth, nullptr); e->proj_b.assign(depth, nullptr);
+    for (int l = 0; l < depth; ++l) {
+        const int N = l == 0 ? e->Nproj0 : e->Nproj;
+        e->proj_w[l] = fl((size_t)N * D);
+        e->proj_b[l] = fl(N);
+    }
+    e->ffp.assign(depth + 1, FfPrep{});
+    for (int l = 0; l <= depth; ++l) {
+        e->ffp[l].w1 = fl((size_t)2 * e->inner_pad * D);
+        e->ffp[l].b1 = fl((size_t)2 * e->inner_pad);
+        e->ffp[l].w2 = fl((size_t)D * e->inner_pad);
+    }
+    e->pq_w.assign(depth, nullptr); e->pkv_w.assign(depth, nullptr);
+    for (int p = 0; p < depth; ++p) {
+        e->pq_w[p] = fl((size_t)(hp + e->php) * D);
+        e->pkv_w[p] = fl((size_t)2 * hp * D);
+    }
+    e->cq_w = fl((size_t)(hd + c.attn_heads) * D);
+    e->ckv_w = fl((size_t)2 * hd * D);
+    e->lin_kv_w = fl((size_t)2 * hd * dl);
+    e->lin_q = fl((size_t)ns * hd);
+    e->lin_gate = fl((size_t)ns * c.attn_heads);
+    e->lout_kv_w = fl((size_t)2 * hd * D);
+    e->lout_q = fl((size_t)n * hd);
+    e->lout_gate = fl((size_t)n * c.attn_heads);
+    e->qtmp = fl((size_t)(n > ns ? n : ns) * D);
+    e->action_offsets = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
+    e->action_sizes = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
+
+    e->slabs = fl((size_t)e->nslab * M * D);
+    e->xpool = fl(M * D);
+    e->proj0 = fl(M * e->Nproj0);
+    e->proj = fl(M * e->Nproj);
+    e->att = fl(M * hd);
+    e->ffh = fl(M * e->inner_pad);
+    e->pool_q = fl(M * e->ldpq);
+    e->pool_kv = fl((size_t)e->nslab * M * 2 * hp);
+    e->pool_att = fl(M * hp);
+    e->cq = fl(Fr * e->ldcq);
+    e->ckv = fl(M * 2 * hd);
+    e->catt = fl(Fr * hd);
+    e->lat_in = fl(Fr * n * dl);
+    e->lkv = fl(Fr * n * 2 * hd);
+    e->latt = fl(Fr * ns * hd);
+    e->space = fl(Fr * ns * D);
+    e->gs = fl(Fr * ns * D);
+    e->okv = fl(Fr * ns * 2 * hd);
+    e->oatt = fl(Fr * n * hd);
+    e->oproj = fl(Fr * n * D);
+    e->pred = fl(Fr * n * dl);
+    e->x_lat = fl((size_t)e->maxB * n * dl);
+    e->sig = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * Fr));
+    e->pact = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * Fr * (e->na > 0 ? e->na : 1)));
+    e->cache = fl((size_t)(e->Lt > 0 ? e->Lt : 1) * 2 * e->maxB * S * c.attn_heads * e->Tcap * 64);
+
+    int maxdim = 4 * D;
+    if (c.reward_num_bins > maxdim) maxdim = c.reward_num_bins;
+    if (c.value_num_bins > maxdim) maxdim = c.value_num_bins;
+    if (4 * dl > maxdim) maxdim = 4 * dl;
+    const size_t hb = (size_t)e->maxB * maxdim;
+    e->agent_c = fl((size_t)e->maxB * D);
+    e->hbuf[0] = fl(hb); e->hbuf[1] = fl(hb); e->hnorm = fl(hb);
+    e->rlogits = fl((size_t)e->maxB * c.reward_num_bins);
+    e->term_pool = fl((size_t)e->maxB * dl);
+    e->term_logit = fl(e->maxB);
+
+    // learner
+    e->LR = c.max_learn_rows;
+    if (e->LR > 0) {
+        const size_t R = e->LR;
+        // saved per layer: x (input), xhat (normalised * gamma input of the linear), z (pre-activation)
+        size_t save = 0;
+        for (const Mlp* m : {&e->policy, &e->value})
+            for (int i = 0; i < m->nl; ++i) save += R * (2 * (size_t)m->dims[i] + (size_t)m->dims[i + 1]) + R;
+        e->l_save = fl(save);
+        for (int i = 0; i < 3; ++i) e->l_tmp[i] = fl(R * maxdim);
+        e->l_logits = fl(R * (e->A > 0 ? e->A : 1));
+        e->l_dlogits = fl(R * (e->A > 0 ? e->A : 1));
+        e->l_vbins = fl(R * c.value_num_bins);
+        e->l_dvbins = fl(R * c.value_num_bins);
+        e->l_returns = fl(R);
+        e->l_adv = fl(R);
+        e->l_scal = fl(64);
+    }
+    e->ws_need = off + 256;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- key lookup
+static thread_local char g_key[256];
+static const char* keyf(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_key, sizeof(g_key), fmt, ap);
+    va_end(ap);
+    return g_key;
+}
+
+struct Resolver {
+    d4_engine* e;
+    int rc = 0;
+    const float* get(const char* key, int64_t numel, float** grad = nullptr) {
+        auto it = e->bound.find(key);
+        if (it == e->bound.end()) {
+            if (!rc) set_error("weight '%s' is not bound (expected %lld elements)", key, (long long)numel);
+            rc = 4;
+            return nullptr;
+        }
+        if (it->second.n != numel) {
+            if (!rc) set_error("weight '%s' has %lld elements, expected %lld", key, (long long)it->second.n, (long long)numel);
+            rc = 4;
+            return nullptr;
+        }
+        if (grad) *grad = it->second.g;
+        return it->second.p;
+    }
+    void attn(AttnW& a, const std::string& pre, int dim_q, int dim_kv, int heads, bool ctx_norm, bool mix) {
+        const int inner = heads * 64;
+        a.norm = get((pre + "norm.weight").c_str(), dim_q);
+        if (ctx_norm) a.norm_ctx = get((pre + "norm_context.weight").c_str(), dim_kv);
+        a.to_q = get((pre + "to_q.weight").c_str(), (int64_t)inner * dim_q);
+        a.to_k = get((pre + "to_k.weight").c_str(), (int64_t)inner * dim_kv);
+        a.to_v = get((pre + "to_v.weight").c_str(), (int64_t)inner * dim_kv);
+        a.to_out = get((pre + "to_out.weight").c_str(), (int64_t)dim_q * inner);
+        a.to_gates = get((pre + "to_gates.0.weight").c_str(), (int64_t)heads * dim_q);
+        a.k_gamma = get((pre + "k_heads_rmsnorm.gamma").c_str(), (int64_t)heads * 64);
+        if (mix) {
+            a.mix_w = get((pre + "to_learned_value_residual_mix.0.weight").c_str(), (int64_t)heads * dim_q);
+            a.mix_b = get((pre + "to_learned_value_residual_mix.0.bias").c_str(), heads);
+        }
+    }
+    void ff(FfW& f, const std::string& pre, int D, int inner) {
+        f.norm = get((pre + "norm.weight").c_str(), D);
+        f.in_w = get((pre + "proj_in.weight").c_str(), (int64_t)2 * inner * D);
+        f.in_b = get((pre + "proj_in.bias").c_str(), 2 * inner);
+        f.out_w = get((pre + "proj_out.weight").c_str(), (int64_t)D * inner);
+        f.out_b = get((pre + "proj_out.bias").c_str(), D);
+    }
+    void mlp(Mlp& m, const std::string& pre) {
+        for (int i = 0; i < m.nl; ++i) {
+            m.g[i] = get(keyf("%slayers.%d.0.weight", pre.c_str(), i), m.dims[i], &m.dg[i]);
+            m.w[i] = get(keyf("%slayers.%d.1.weight", pre.c_str(), i), (int64_t)m.dims[i + 1] * m.dims[i], &m.dw[i]);
+            m.b[i] = get(keyf("%slayers.%d.1.bias", pre.c_str(), i), m.dims[i + 1], &m.db[i]);
+        }
+    }
+};
+
+static void mlp_dims(Mlp& m, int dim_in, int dim, int dim_out, int depth) {
+    // create_mlp(dim, depth, dim_in, dim_out): widths (dim_in, dim x (depth + 1), dim_out)  [recipe: DESIGN.md]
+    int k = 0;
+    m.dims[k++] = dim_in;
+    for (int i = 0; i <= depth; ++i) m.dims[k++] = dim;
+    m.dims[k++] = dim_out;
+    m.nl = k - 1;
+    for (int i = 0; i < 9; ++i) { m.dg[i] = m.dw[i] = m.db[i] = nullptr; m.g[i] = m.w[i] = m.b[i] = nullptr; }
+}
+
+int engine_resolve(d4_engine* e) {
+    const d4_config& c = e->c;
+    Resolver r{e};
+    const int D = e->D, h = c.attn_heads;
+    e->layer_attn.assign(c.depth, AttnW{});
+    e->layer_ff.assign(c.depth, FfW{});
+    for (int l = 0; l < c.depth; ++l) {
+        r.attn(e->layer_attn[l], keyf("transformer.layers.%d.2.fn.", l), D, D, h, false, true);
+        r.ff(e->layer_ff[l], keyf("transformer.layers.%d.3.fn.", l), D, e->inner);
+    }
+    e->pools.assign(c.depth, AttnW{});
+    for (int p = 0; p < c.depth - 1; ++p)
+        r.attn(e->pools[p], keyf("transformer.attn_pools.%d.fn.attn.", p), D, D, c.pool_heads, true, false);
+    r.attn(e->pools[c.depth - 1], "transformer.final_attn_pool.fn.attn.", D, D, c.pool_heads, true, false);
+    r.attn(e->cross, "transformer.final_special_cross_attn.fn.", D, D, h, true, false);
+    r.ff(e->sff, "transformer.final_special_ff.fn.", D, e->inner);
+    e->vres_norm = r.get("transformer.to_value_residual.0.weight", D);
+    e->vres_w = r.get("transformer.to_value_residual.1.weight", (int64_t)e->hd * D);
+    e->inv_freq = r.get("transformer.time_rotary.inv_freq", 32);
+    r.attn(e->lq_in, "latents_to_spatial_tokens.attn.", D, c.dim_latent, h, true, false);
+    e->lq_in_queries = r.get("latents_to_spatial_tokens.queries", (int64_t)c.num_spatial_tokens * D);
+    e->latent_norm = r.get("to_latent_pred.0.weight", D);
+    r.attn(e->lq_out, "to_latent_pred.1.attn.", D, D, h, true, false);
+    e->lq_out_queries = r.get("to_latent_pred.1.queries", (int64_t)c.num_latent_tokens * D);
+    e->latent_w = r.get("to_latent_pred.2.weight", (int64_t)c.dim_latent * D);
+    e->registers = r.get("register_tokens", (int64_t)c.num_register_tokens * D);
+    e->signal_embed = r.get("signal_levels_embed.weight", (int64_t)c.max_steps * (D / 2));
+    e->step_embed = r.get("step_size_embed.weight", (int64_t)(int)round(log2((double)c.max_steps)) * (D / 2));
+    e->agent_learned = r.get("agent_learned_embed", D);
+    e->action_learned = r.get("action_learned_embed", D);
+    e->task_embed = c.num_tasks > 0 ? r.get("task_embed.weight", (int64_t)c.num_tasks * D) : nullptr;
+    e->action_embed = e->A > 0 ? r.get("action_embedder.discrete_action_embed.weight", (int64_t)e->A * D) : nullptr;
+    e->action_unembed = e->A > 0 ? r.get("action_embedder.discrete_action_unembed",
+                                         (int64_t)e->A * c.multi_token_pred_len * 4 * D, &e->action_unembed_grad) : nullptr;
+    e->reward_norm = r.get("to_reward_pred.params.0", (int64_t)c.multi_token_pred_len * D);
+    e->reward_w = r.get("to_reward_pred.params.1", (int64_t)c.multi_token_pred_len * c.reward_num_bins * D);
+    e->reward_centers = r.get("reward_encoder.centers", c.reward_num_bins);
+    e->value_centers = r.get("value_encoder.centers", c.value_num_bins);
+    e->value_support = r.get("value_encoder.support", c.value_num_bins + 1);
+    r.mlp(e->policy, "policy_head.");
+    r.mlp(e->value, "value_head.");
+    if (c.predict_terminals) r.mlp(e->terminal, "to_state_terminal_pred.0.");
+    return r.rc;
+}
+
+// ------------------------------------------------------------------------------------- prepare
+static int fold_attn_rows(float* dst, int D, const float* w, const float* gamma, int rows, hipStream_t s) {
+    return fold_rows(w, gamma, dst, rows, D, D, s);
+}
+
+static int prep_ff(const FfW& f, FfPrep& p, d4_engine* e, hipStream_t s) {
+    int rc;
+    if ((rc = swiglu_pack_rows(f.in_w, f.in_b, f.norm, p.w1, p.b1, e->inner, e->inner_pad, e->D, s))) return rc;
+    return pad_cols(f.out_w, p.w2, e->D, e->inner, e->inner_pad, s);
+}
+
+static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                       int flags, const float* bias, const float* R, int ldr, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS};
+    return gemm(g, s);
+}
+
+int engine_prepare(d4_engine* e, hipStream_t s) {
+    const d4_config& c = e->c;
+    D4_REQUIRE(e->ws != nullptr, "workspace not set");
+    int rc;
+    if ((rc = engine_resolve(e))) return rc;
+    const int D = e->D, hd = e->hd, h = c.attn_heads, hp = e->hp;
+    for (int l = 0; l < c.depth; ++l) {
+        const AttnW& a = e->layer_attn[l];
+        float* w = e->proj_w[l];
+        const int N = l == 0 ? e->Nproj0 : e->Nproj;
+        if ((rc = fill_f32(e->proj_b[l], 0.f, N, s))) return rc;
+        if ((rc = fold_attn_rows(w, D, a.to_q, a.norm, hd, s))) return rc;
+        if ((rc = fold_attn_rows(w + (size_t)hd * D, D, a.to_k, a.norm, hd, s))) return rc;
+        if ((rc = fold_attn_rows(w + (size_t)2 * hd * D, D, a.to_v, a.norm, hd, s))) return rc;
+        if ((rc = fold_attn_rows(w + (size_t)3 * hd * D, D, a.to_gates, a.norm, h, s))) return rc;
+        if ((rc = fold_attn_rows(w + (size_t)(3 * hd + h) * D, D, a.mix_w, a.norm, h, s))) return rc;
+        if ((rc = copy_rows(a.mix_b, h, e->proj_b[l] + 3 * hd + h, h, 1, h, s))) return rc;
+        if (l == 0 && (rc = fold_attn_rows(w + (size_t)(3 * hd + 2 * h) * D, D, e->vres_w, e->vres_norm, hd, s))) return rc;
+        if ((rc = prep_ff(e->layer_ff[l], e->ffp[l], e, s))) return rc;
+    }
+    if ((rc = prep_ff(e->sff, e->ffp[c.depth], e, s))) return rc;
+    for (int p = 0; p < c.depth; ++p) {
+        const AttnW& a = e->pools[p];
+        if ((rc = fold_attn_rows(e->pq_w[p], D, a.to_q, a.norm, hp, s))) return rc;
+        if ((rc = fold_attn_rows(e->pq_w[p] + (size_t)hp * D, D, a.to_gates, a.norm, e->php, s))) return rc;
+        if ((rc = fold_attn_rows(e->pkv_w[p], D, a.to_k, a.norm_ctx, hp, s))) return rc;
+        if ((rc = fold_attn_rows(e->pkv_w[p] + (size_t)hp * D, D, a.to_v, a.norm_ctx, hp, s))) return rc;
+    }
+    if ((rc = fold_attn_rows(e->cq_w, D, e->cross.to_q, e->cross.norm, hd, s))) return rc;
+    if ((rc = fold_attn_rows(e->cq_w + (size_t)hd * D, D, e->cross.to_gates, e->cross.norm, h, s))) return rc;
+    if ((rc = fold_attn_rows(e->ckv_w, D, e->cross.to_k, e->cross.norm_ctx, hd, s))) return rc;
+    if ((rc = fold_attn_rows(e->ckv_w + (size_t)hd * D, D, e->cross.to_v, e->cross.norm_ctx, hd, s))) return rc;
+
+    // learned-query pools: the query side is batch independent -> evaluate once        D4:2189, 2206
+    const int dl = c.dim_latent, ns = c.num_spatial_tokens, n = c.num_latent_tokens;
+    if ((rc = fold_rows(e->lq_in.to_k, e->lq_in.norm_ctx, e->lin_kv_w, hd, dl, dl, s))) return rc;
+    if ((rc = fold_rows(e->lq_in.to_v, e->lq_in.norm_ctx, e->lin_kv_w + (size_t)hd * dl, hd, dl, dl, s))) return rc;
+    if ((rc = rmsnorm_rows(e->lq_in_queries, D, e->lq_in.norm, e->qtmp, D, ns, D, RMS_EPS, s))) return rc;
+    if ((rc = gemm_simple(e->qtmp, D, e->lq_in.to_q, D, e->lin_q, hd, ns, hd, D, 0, nullptr, nullptr, 0, s))) return rc;
+    if ((rc = gemm_simple(e->qtmp, D, e->lq_in.to_gates, D, e->lin_gate, h, ns, h, D, 0, nullptr, nullptr, 0, s))) return rc;
+    // to_latent_pred: both norms are applied explicitly on the gathered rows -> plain K/V weights
+    if ((rc = fold_rows(e->lq_out.to_k, nullptr, e->lout_kv_w, hd, D, D, s))) return rc;
+    if ((rc = fold_rows(e->lq_out.to_v, nullptr, e->lout_kv_w + (size_t)hd * D, hd, D, D, s))) return rc;
+    if ((rc = rmsnorm_rows(e->lq_out_queries, D, e->lq_out.norm, e->qtmp, D, n, D, RMS_EPS, s))) return rc;
+    if ((rc = gemm_simple(e->qtmp, D, e->lq_out.to_q, D, e->lout_q, hd, n, hd, D, 0, nullptr, nullptr, 0, s))) return rc;
+    if ((rc = gemm_simple(e->qtmp, D, e->lq_out.to_gates, D, e->lout_gate, h, n, h, D, 0, nullptr, nullptr, 0, s))) return rc;
+
+    int32_t offs[D4_MAX_ACTION_TYPES] = {0}, sizes[D4_MAX_ACTION_TYPES] = {0};
+    int o = 0;
+    for (int a = 0; a < e->na; ++a) { offs[a] = o; sizes[a] = c.num_discrete_actions[a]; o += sizes[a]; }
+    D4_HIP(hipMemcpyAsync(e->action_offsets, offs, sizeof(offs), hipMemcpyHostToDevice, s));
+    D4_HIP(hipMemcpyAsync(e->action_sizes, sizes, sizeof(sizes), hipMemcpyHostToDevice, s));
+    D4_HIP(hipStreamSynchronize(s));    // the two host arrays above live on this stack frame
+    e->prepared = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------- forward
+static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const float* x, int ldx, float* y, int ldy,
+                    int rows, hipStream_t s) {
+    int rc;
+    if ((rc = gemm_simple(x, ldx, fp.w1, e->D, e->ffh, e->inner_pad, rows, 2 * e->inner_pad, e->D,
+                          GEMM_RMS_ROWSCALE | GEMM_SWIGLU, fp.b1, nullptr, 0, s))) return rc;
+    return gemm_simple(e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, rows, e->D, e->inner_pad, 0, out_b, x, ldx, s);
+}
+
+static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s) {
+    const d4_config& c = e->c;
+    const int D = e->D, hp = e->hp;
+    const AttnW& a = e->pools[p];
+    int rc;
+    if ((rc = gemm_simple(x, D, e->pq_w[p], D, e->pool_q, e->ldpq, M, hp + e->php, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    if ((rc = gemm_simple(e->slabs, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    SmallAttnArgs sa{};
+    sa.q = e->pool_q; sa.q_group_stride = e->ldpq; sa.q_item_stride = 0;
+    sa.k = e->pool_kv; sa.k_group_stride = 2 * hp; sa.k_item_stride = (int64_t)M * 2 * hp;
+    sa.v = e->pool_kv + hp; sa.v_group_stride = 2 * hp; sa.v_item_stride = (int64_t)M * 2 * hp;
+    sa.gate = e->pool_q + hp; sa.g_group_stride = e->ldpq; sa.g_item_stride = 0;
+    sa.k_gamma = a.k_gamma;
+    sa.out = e->pool_att; sa.o_group_stride = hp; sa.o_item_stride = 0;
+    sa.groups = M; sa.heads = c.pool_heads; sa.nq = 1; sa.nk = L;
+    if ((rc = small_attn(sa, s))) return rc;
+    return gemm_simple(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, s);
+}
+
+// Inputs expected in e->sig / e->pact (device).  Results: e->pred [B*Tq][n][dl], e->xpool rows (agent = row S-1).
+int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
+                   const int64_t* tasks, hipStream_t s) {
+    const d4_config& c = e->c;
+    D4_REQUIRE(e->prepared, "engine not prepared");
+    D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
+    D4_REQUIRE(Tq >= 1 && Tq <= e->maxTq, "parallel frames %d exceed max_parallel_frames %d", Tq, e->maxTq);
+    D4_REQUIRE(t0 + Tq <= e->Tcap || e->Lt == 0, "KV cache capacity %d exceeded (%d + %d frames)", e->Tcap, t0, Tq);
+    const int D = e->D, hd = e->hd, h = c.attn_heads, S = e->S;
+    const int n = c.num_latent_tokens, dl = c.dim_latent, ns = c.num_spatial_tokens;
+    const int Fr = B * Tq, M = Fr * S;
+    int rc;
+
+    // ---- latents -> spatial tokens (LearnedQueriesAttentionPool, D4:7168)
+    if ((rc = gemm_simple(latents, dl, e->lin_kv_w, dl, e->lkv, 2 * hd, Fr * n, 2 * hd, dl, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    {
+        SmallAttnArgs sa{};
+        sa.q = e->lin_q; sa.q_group_stride = 0; sa.q_item_stride = hd;
+        sa.k = e->lkv; sa.k_group_stride = (int64_t)n * 2 * hd; sa.k_item_stride = 2 * hd;
+        sa.v = e->lkv + hd; sa.v_group_stride = (int64_t)n * 2 * hd; sa.v_item_stride = 2 * hd;
+        sa.gate = e->lin_gate; sa.g_group_stride = 0; sa.g_item_stride = h;
+        sa.k_gamma = e->lq_in.k_gamma;
+        sa.out = e->latt; sa.o_group_stride = (int64_t)ns * hd; sa.o_item_stride = hd;
+        sa.groups = Fr; sa.heads = h; sa.nq = ns; sa.nk = n;
+        if ((rc = small_attn(sa, s))) return rc;
+    }
+    if ((rc = gemm_simple(e->latt, hd, e->lq_in.to_out, hd, e->space, D, Fr * ns, D, hd, 0, nullptr, nullptr, 0, s))) return rc;
+
+    // ---- pack tokens (D4:7182-7222)
+    float* slab0 = e->slabs;
+    auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
+    {
+        AssembleArgs a{};
+        a.tokens = slab0; a.space = e->space; a.signal_embed = e->signal_embed; a.step_embed = e->step_embed;
+        a.registers = e->registers; a.agent_embed = e->agent_learned; a.task_embed = e->task_embed;
+        a.action_embed = e->action_embed; a.action_learned = e->action_learned;
+        a.signal_levels = e->sig; a.prev_actions = e->na > 0 ? e->pact : nullptr; a.tasks = tasks;
+        a.action_offsets = e->action_offsets;
+        a.B = B; a.Tq = Tq; a.S = S; a.D = D; a.ns = ns; a.nr = c.num_register_tokens; a.na = e->na; a.step_log2 = step_log2;
+        D4_REQUIRE(tasks == nullptr || c.num_tasks > 0, "tasks given but num_tasks == 0");
+        if ((rc = assemble_tokens(a, s))) return rc;
+    }
+
+    // ---- trunk (AxialSpaceTimeTransformer.forward, D4:3040-3223)
+    const float* x_in = slab0;
+    const float* vres = e->proj0 + 3 * hd + 2 * h;
+    for (int l = 0; l < c.depth; ++l) {
+        const AttnW& a = e->layer_attn[l];
+        float* P = l == 0 ? e->proj0 : e->proj;
+        const int ldp = l == 0 ? e->Nproj0 : e->Nproj;
+        if ((rc = gemm_simple(x_in, D, e->proj_w[l], D, P, ldp, M, ldp, D, GEMM_RMS_ROWSCALE, e->proj_b[l], nullptr, 0, s))) return rc;
+        if (e->is_time[l]) {
+            TimeAttnArgs ta{};
+            ta.proj = P; ta.ldp = ldp; ta.vres = vres; ta.ldv = e->Nproj0; ta.k_gamma = a.k_gamma; ta.inv_freq = e->inv_freq;
+            ta.cache = e->cache + (size_t)e->time_index[l] * 2 * e->maxB * S * h * e->Tcap * 64;
+            ta.out = e->att; ta.ldo = hd; ta.B = B; ta.S = S; ta.H = h; ta.Tq = Tq; ta.t0 = t0; ta.Tcap = e->Tcap;
+            ta.softclamp = c.attn_softclamp_value;
+            ta.cache_batch = e->maxB;
+            if ((rc = time_kv_append(ta, s))) return rc;
+            if ((rc = time_attn(ta, s))) return rc;
+        } else {
+            SmallAttnArgs sa{};
+            const int64_t gs = (int64_t)S * ldp;
+            sa.q = P; sa.q_group_stride = gs; sa.q_item_stride = ldp;
+            sa.k = P + hd; sa.k_group_stride = gs; sa.k_item_stride = ldp;
+            sa.v = P + 2 * hd; sa.v_group_stride = gs; sa.v_item_stride = ldp;
+            sa.gate = P + 3 * hd; sa.g_group_stride = gs; sa.g_item_stride = ldp;
+            sa.mix = P + 3 * hd + h; sa.m_group_stride = gs; sa.m_item_stride = ldp;
+            sa.vres = vres; sa.r_group_stride = (int64_t)S * e->Nproj0; sa.r_item_stride = e->Nproj0;
+            sa.k_gamma = a.k_gamma;
+            sa.out = e->att; sa.o_group_stride = (int64_t)S * hd; sa.o_item_stride = hd;
+            sa.groups = Fr; sa.heads = h; sa.nq = S; sa.nk = S;
+            sa.softclamp = c.attn_softclamp_value; sa.mask_special = 1; sa.belief = 1;
+            if ((rc = small_attn(sa, s))) return rc;
+        }
+        float* h1 = slab(2 * l + 1);
+        float* h2 = slab(2 * l + 2);
+        if ((rc = gemm_simple(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, s))) return rc;
+        if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s))) return rc;
+        if (l != c.depth - 1) {
+            if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s))) return rc;
+            x_in = e->xpool;
+        }
+    }
+
+    // ---- agent token cross-attends its frame, then its own feedforward (D4:3227-3238)
+    float* xf = e->xpool;
+    if ((rc = copy_rows(slab(2 * c.depth), D, xf, D, M, D, s))) return rc;
+    {
+        float* agent_rows = xf + (size_t)(S - 1) * D;
+        const int lda = S * D;
+        if ((rc = gemm_simple(agent_rows, lda, e->cq_w, D, e->cq, e->ldcq, Fr, hd + h, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        if ((rc = gemm_simple(xf, D, e->ckv_w, D, e->ckv, 2 * hd, M, 2 * hd, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        SmallAttnArgs sa{};
+        sa.q = e->cq; sa.q_group_stride = e->ldcq; sa.q_item_stride = 0;
+        sa.k = e->ckv; sa.k_group_stride = (int64_t)S * 2 * hd; sa.k_item_stride = 2 * hd;
+        sa.v = e->ckv + hd; sa.v_group_stride = (int64_t)S * 2 * hd; sa.v_item_stride = 2 * hd;
+        sa.gate = e->cq + hd; sa.g_group_stride = e->ldcq; sa.g_item_stride = 0;
+        sa.k_gamma = e->cross.k_gamma;
+        sa.out = e->catt; sa.o_group_stride = hd; sa.o_item_stride = 0;
+        sa.groups = Fr; sa.heads = h; sa.nq = 1; sa.nk = S - 1;
+        if ((rc = small_attn(sa, s))) return rc;
+        if ((rc = gemm_simple(e->catt, hd, e->cross.to_out, hd, agent_rows, lda, Fr, D, hd, 0, nullptr, agent_rows, lda, s))) return rc;
+        if ((rc = ff_block(e, e->ffp[c.depth], e->sff.out_b, agent_rows, lda, agent_rows, lda, Fr, s))) return rc;
+    }
+    // ---- final attention pool over every layer hidden (D4:3242-3243)
+    if ((rc = pool_block(e, c.depth - 1, xf, xf, e->nslab, M, s))) return rc;
+
+    // ---- to_latent_pred: RMSNorm -> LQAP (n queries over the ns spatial tokens) -> Linear  (D4:7251)
+    if ((rc = gather_space_double_norm(xf, e->gs, e->latent_norm, e->lq_out.norm_ctx, Fr, S, D, ns, RMS_EPS, s))) return rc;
+    if ((rc = gemm_simple(e->gs, D, e->lout_kv_w, D, e->okv, 2 * hd, Fr * ns, 2 * hd, D, 0, nullptr, nullptr, 0, s))) return rc;
+    {
+        SmallAttnArgs sa{};
+        sa.q = e->lout_q; sa.q_group_stride = 0; sa.q_item_stride = hd;
+        sa.k = e->okv; sa.k_group_stride = (int64_t)ns * 2 * hd; sa.k_item_stride = 2 * hd;
+        sa.v = e->okv + hd; sa.v_group_stride = (int64_t)ns * 2 * hd; sa.v_item_stride = 2 * hd;
+        sa.gate = e->lout_gate; sa.g_group_stride = 0; sa.g_item_stride = h;
+        sa.k_gamma = e->lq_out.k_gamma;
+        sa.out = e->oatt; sa.o_group_stride = (int64_t)n * hd; sa.o_item_stride = hd;
+        sa.groups = Fr; sa.heads = h; sa.nq = n; sa.nk = ns;
+        if ((rc = small_attn(sa, s))) return rc;
+    }
+    if ((rc = gemm_simple(e->oatt, hd, e->lq_out.to_out, hd, e->oproj, D, Fr * n, D, hd, 0, nullptr, nullptr, 0, s))) return rc;
+    if ((rc = gemm_simple(e->oproj, D, e->latent_w, D, e->pred, dl, Fr * n, dl, D, 0, nullptr, nullptr, 0, s))) return rc;
+    return 0;
+}
+
+// normed MLP head.  `save` (optional): per layer [x | xhat | z | rstd] for the learner's backward.
+int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, float* out, int ldo,
+                float* save, hipStream_t s) {
+    int rc;
+    const float* cur = x;
+    int ld = ldx;
+    for (int i = 0; i < m.nl; ++i) {
+        const int din = m.dims[i], dout = m.dims[i + 1];
+        const bool last = i == m.nl - 1;
+        float* xhat = e->hnorm;
+        float* y = last ? out : e->hbuf[i & 1];
+        int ldy = last ? ldo : dout;
+        if (save) {
+            // learner path: keep x, xhat and the pre-activation
+            float* sx = save; float* sxh = sx + (size_t)rows * din; float* sz = sxh + (size_t)rows * din;
+            save = sz + (size_t)rows * dout + rows;
+            if ((rc = copy_rows(cur, ld, sx, din, rows, din, s))) return rc;
+            xhat = sxh;
+            if ((rc = rmsnorm_rows(cur, ld, m.g[i], xhat, din, rows, din, RMS_EPS, s))) return rc;
+            if ((rc = gemm_simple(xhat, din, m.w[i], din, sz, dout, rows, dout, din, 0, m.b[i], nullptr, 0, s))) return rc;
+            if (last) { if ((rc = copy_rows(sz, dout, y, ldy, rows, dout, s))) return rc; }
+            else if ((rc = silu_rows(sz, y, (int64_t)rows * dout, s))) return rc;
+        } else {
+            if ((rc = rmsnorm_rows(cur, ld, m.g[i], xhat, din, rows, din, RMS_EPS, s))) return rc;
+            if ((rc = gemm_simple(xhat, din, m.w[i], din, y, ldy, rows, dout, din, last ? 0 : GEMM_SILU, m.b[i], nullptr, 0, s))) return rc;
+        }
+        cur = y; ld = ldy;
+    }
+    return 0;
+}
+
+}  // namespace d4
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* d4_last_error(void) { return d4::last_error(); }
+int d4_version(void) { return 1; }
+
+int d4_engine_create(const d4_config* cfg, d4_engine** out) {
+    D4_REQUIRE(cfg && out, "null argument");
+    const d4_config& c = *cfg;
+    D4_REQUIRE(c.attn_dim_head == 64, "attn_dim_head=%d: only 64 (one wavefront per head row) is implemented", c.attn_dim_head);
+    D4_REQUIRE(c.pool_dim_head == 64, "pool_dim_head=%d: only 64 is implemented", c.pool_dim_head);
+    D4_REQUIRE(c.dim % 4 == 0 && c.dim_latent % 4 == 0, "dim and dim_latent must be multiples of 4");
+    D4_REQUIRE(c.depth >= 1 && c.time_block_every >= 1, "bad depth/time_block_every");
+    D4_REQUIRE(c.num_spatial_tokens != c.num_latent_tokens, "num_spatial_tokens == num_latent_tokens (Linear latents_to_spatial path) is not implemented");
+    D4_REQUIRE(c.num_discrete_action_types >= 0 && c.num_discrete_action_types <= D4_MAX_ACTION_TYPES, "too many action types");
+    D4_REQUIRE(c.num_latent_tokens <= 64 && c.num_spatial_tokens <= 64, "at most 64 latent / spatial tokens");
+    D4_REQUIRE((c.max_steps & (c.max_steps - 1)) == 0, "max_steps must be a power of two");
+    D4_REQUIRE(c.policy_head_mlp_depth <= 6 && c.value_head_mlp_depth <= 6 && c.terminal_mlp_depth <= 6, "mlp depth > 6");
+    d4_engine* e = new d4_engine();
+    e->c = c;
+    e->D = c.dim;
+    e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + 1 + 1;
+    D4_REQUIRE(e->S <= 64 && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
+    e->hd = c.attn_heads * 64;
+    e->php = c.pool_heads;
+    e->hp = c.pool_heads * 64;
+    e->Nproj = 3 * e->hd + 2 * c.attn_heads;
+    e->Nproj = (e->Nproj + 3) / 4 * 4;
+    e->Nproj0 = 3 * e->hd + 2 * c.attn_heads + e->hd;
+    e->Nproj0 = (e->Nproj0 + 3) / 4 * 4;
+    e->inner = (int)((double)c.dim * 4 * 2 / 3);               // int(dim * 4 * 2 / 3)  D4:2094
+    e->inner_pad = (e->inner + 31) / 32 * 32;
+    e->ldpq = (e->hp + e->php + 3) / 4 * 4;
+    e->ldcq = (e->hd + c.attn_heads + 3) / 4 * 4;
+    e->nslab = 2 * c.depth + 1;
+    e->na = c.num_discrete_action_types;
+    e->A = 0;
+    for (int a = 0; a < e->na; ++a) e->A += c.num_discrete_actions[a];
+    e->is_time.assign(c.depth, 0);
+    e->time_index.assign(c.depth, -1);
+    e->Lt = 0;
+    for (int l = 0; l < c.depth; ++l)
+        if ((l + 1) % c.time_block_every == 0) { e->is_time[l] = 1; e->time_index[l] = e->Lt++; }
+    e->maxB = c.max_batch > 0 ? c.max_batch : 1;
+    e->maxTq = c.max_parallel_frames > 0 ? c.max_parallel_frames : 1;
+    e->Tcap = c.max_frames > e->maxTq ? c.max_frames : e->maxTq;
+    e->Fr = e->maxB * e->maxTq;
+    e->Mmax = e->Fr * e->S;
+    d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth);
+    d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth);
+    d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth);
+    d4::engine_layout(e, false);
+    *out = e;
+    return 0;
+}
+
+void d4_engine_destroy(d4_engine* e) { delete e; }
+
+size_t d4_engine_workspace_bytes(const d4_engine* e) { return e ? e->ws_need : 0; }
+
+int d4_engine_set_workspace(d4_engine* e, void* p, size_t bytes) {
+    D4_REQUIRE(e && p, "null argument");
+    D4_REQUIRE(bytes >= e->ws_need, "workspace too small: %zu < %zu bytes", bytes, e->ws_need);
+    D4_REQUIRE(((uintptr_t)p % 256) == 0, "workspace must be 256-byte aligned");
+    e->ws = static_cast<char*>(p);
+    e->ws_bytes = bytes;
+    e->prepared = false;
+    e->cache_frames = 0;
+    return d4::engine_layout(e, true);
+}
+
+int d4_engine_bind(d4_engine* e, const char* key, const float* p, float* grad, int64_t numel) {
+    D4_REQUIRE(e && key && p, "null argument");
+    D4_REQUIRE(((uintptr_t)p % 16) == 0, "tensor '%s' is not 16-byte aligned", key);
+    e->bound[key] = d4::Bound{p, grad, numel};
+    e->prepared = false;
+    return 0;
+}
+
+int d4_engine_prepare(d4_engine* e, void* stream) {
+    D4_REQUIRE(e, "null engine");
+    return d4::engine_prepare(e, static_cast<hipStream_t>(stream));
+}
+
+int d4_engine_cache_frames(const d4_engine* e) { return e ? e->cache_frames : -1; }
+
+int d4_engine_cache_reset(d4_engine* e, int frames) {
+    D4_REQUIRE(e && frames >= 0 && frames <= e->cache_frames, "cache_reset: bad frame count %d (have %d)", frames, e ? e->cache_frames : -1);
+    e->cache_frames = frames;
+    return 0;
+}
+
+int d4_engine_cache_export(d4_engine* e, float* dst, int batch, void* stream) {
+    D4_REQUIRE(e && dst, "null argument");
+    return d4::cache_transfer(e->cache, dst, e->Lt, e->maxB, batch, e->S, e->c.attn_heads, e->Tcap, e->cache_frames, 1,
+                              static_cast<hipStream_t>(stream));
+}
+
+int d4_engine_cache_import(d4_engine* e, const float* src, int batch, int frames, void* stream) {
+    D4_REQUIRE(e && src, "null argument");
+    D4_REQUIRE(frames <= e->Tcap && batch <= e->maxB, "cache_import: exceeds capacity");
+    int rc = d4::cache_transfer(e->cache, const_cast<float*>(src), e->Lt, e->maxB, batch, e->S, e->c.attn_heads, e->Tcap, frames, 0,
+                                static_cast<hipStream_t>(stream));
+    if (!rc) e->cache_frames = frames;
+    return rc;
+}
+
+static int step_log2_of(int step_size, int* out) {
+    D4_REQUIRE(step_size >= 1 && (step_size & (step_size - 1)) == 0, "step_sizes must be powers of 2 (got %d)  [D4:6944]", step_size);
+    int l = 0;
+    while ((1 << l) < step_size) ++l;
+    *out = l;
+    return 0;
+}
+
+int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_levels, int step_size,
+                  const int64_t* prev_actions, const int64_t* tasks, int batch, int frames,
+                  int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream) {
+    D4_REQUIRE(e && latents && signal_levels, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int sl, rc;
+    if ((rc = step_log2_of(step_size, &sl))) return rc;
+    D4_REQUIRE(batch <= e->maxB && frames <= e->maxTq, "batch/frames exceed engine capacity");
+    const int Fr = batch * frames;
+    D4_HIP(hipMemcpyAsync(e->sig, signal_levels, sizeof(int32_t) * Fr, hipMemcpyDeviceToDevice, s));
+    if (e->na > 0) {
+        if (prev_actions) D4_HIP(hipMemcpyAsync(e->pact, prev_actions, sizeof(int64_t) * Fr * e->na, hipMemcpyDeviceToDevice, s));
+        else D4_HIP(hipMemsetAsync(e->pact, 0xFF, sizeof(int64_t) * Fr * e->na, s));     // -1 => zero token
+    }
+    const int t0 = use_cache ? e->cache_frames : 0;
+    if ((rc = d4::engine_forward(e, latents, batch, frames, t0, sl, tasks, s))) return rc;
+    if (commit_cache) e->cache_frames = t0 + frames;
+    const int n_el = e->c.num_latent_tokens * e->c.dim_latent;
+    if (pred && (rc = d4::copy_rows(e->pred, n_el, pred, n_el, Fr, n_el, s))) return rc;
+    if (agent_embed && (rc = d4::copy_rows(e->xpool + (size_t)(e->S - 1) * e->D, e->S * e->D, agent_embed, e->D, Fr, e->D, s))) return rc;
+    return 0;
+}
+
+int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
+    D4_REQUIRE(e && io, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const d4_config& c = e->c;
+    const int B = io->batch, T = io->time_steps, P = io->prompt_frames, K = io->num_steps;
+    D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
+    D4_REQUIRE(K >= 1 && (K & (K - 1)) == 0 && K <= c.max_steps, "number of steps %d must be a power of 2 in (0, %d]  [D4:6357-6358]", K, c.max_steps);
+    D4_REQUIRE(P >= 0 && P <= T, "bad prompt_frames");
+    D4_REQUIRE(!io->sample_actions || e->na > 0, "the model has no actions to sample  [D4:6626]");
+    D4_REQUIRE(!io->sample_actions || (io->actions && io->gumbel_u && io->log_probs && io->values && io->action_logits), "sample_actions needs the action outputs and gumbel_u");
+    D4_REQUIRE(!io->sample_terminals || (c.predict_terminals && io->bern_u), "sample_terminals needs predict_terminals and bern_u");
+    D4_REQUIRE(io->use_time_cache || io->noise_context || T - P <= 1, "noise_context is required without the time cache");
+    const int F = T - P;
+    const int step_size = c.max_steps / K;
+    int sl, rc;
+    if ((rc = step_log2_of(step_size, &sl))) return rc;
+    const int n_el = c.num_latent_tokens * c.dim_latent;
+    const int D = e->D, S = e->S, A = e->A, na = e->na;
+    if (!io->use_time_cache) e->cache_frames = 0;
+
+    for (int f = 0; f < F; ++f) {
+        const int cur = P + f;                       // frames of history in this call
+        int Tq, t0;
+        bool commit;
+        if (io->use_time_cache && (e->cache_frames > 0 || cur == 0)) { Tq = 1; t0 = e->cache_frames; commit = true; }
+        else if (io->use_time_cache) { Tq = cur + 1; t0 = 0; commit = true; }
+        else { Tq = cur + 1; t0 = 0; commit = false; }
+        D4_REQUIRE(Tq <= e->maxTq, "a parallel pass over %d frames exceeds max_parallel_frames %d", Tq, e->maxTq);
+        if ((rc = d4::copy_rows(io->noise_latent + (size_t)f * B * n_el, n_el, e->x_lat, n_el, B, n_el, s))) return rc;
+
+        for (int step = 0; step <= K; ++step) {
+            const bool last = step == K;
+            const int sig_val = step * step_size < c.max_steps - 1 ? step * step_size : c.max_steps - 1;   // D4:6492
+            const float* lat = e->x_lat;
+            if (Tq > 1) {
+                // context frames noised with their fixed noise; prompt frames carry noise == themselves (D4:6400, 6497)
+                if ((rc = d4::build_latent_input(e->lat_in, io->latents, io->ctx_hist, e->x_lat, B, Tq, n_el, T, io->context_signal_noise, s))) return rc;
+                lat = e->lat_in;
+            }
+            if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, Tq, na, cur + 1 - Tq, T, sig_val, c.max_steps - 1, s))) return rc;
+            if ((rc = d4::engine_forward(e, lat, B, Tq, t0, sl, io->tasks, s))) return rc;
+            if (last) { if (commit) e->cache_frames = t0 + Tq; break; }
+            const float tt = (float)sig_val / (float)c.max_steps;
+            if ((rc = d4::euler_step(e->x_lat, n_el, e->pred + (size_t)(Tq - 1) * n_el, Tq * n_el, B, n_el,
+                                     1.f - tt, (float)step_size / (float)c.max_steps, s))) return rc;
+        }
+
+        // ---- heads on the agent embedding of the clean step (D4:6595-6662)
+        const float* agent_row = e->xpool + ((size_t)(Tq - 1) * S + (S - 1)) * D;
+        if ((rc = d4::copy_rows(agent_row, Tq * S * D, e->agent_c, D, B, D, s))) return rc;
+        if (io->agent_embed && (rc = d4::copy_rows(e->agent_c, D, io->agent_embed + (size_t)f * D, F * D, B, D, s))) return rc;
+        // reward: Ensemble member 0 of [RMSNorm -> Linear]                     D4:6598-6601
+        if ((rc = d4::rmsnorm_rows(e->agent_c, D, e->reward_norm, e->hnorm, D, B, D, d4::RMS_EPS, s))) return rc;
+        if ((rc = d4::gemm_simple(e->hnorm, D, e->reward_w, D, e->rlogits, c.reward_num_bins, B, c.reward_num_bins, D, 0, nullptr, nullptr, 0, s))) return rc;
+        if ((rc = d4::hl_gauss_scalar(e->rlogits, c.reward_num_bins, e->reward_centers, io->rewards + cur, T, B, c.reward_num_bins, s))) return rc;
+        // terminal logit from the mean-pooled denoised latent                    D4:6605-6607
+        const float* term_logit = nullptr;
+        if (io->sample_terminals) {
+            if ((rc = d4::mean_tokens(e->x_lat, e->term_pool, B, c.num_latent_tokens, c.dim_latent, s))) return rc;
+            if ((rc = d4::mlp_forward(e, e->terminal, e->term_pool, c.dim_latent, B, e->term_logit, 1, nullptr, s))) return rc;
+            term_logit = e->term_logit;
+        }
+        if (io->sample_actions) {
+            // policy embed -> logits of prediction head 0                            D4:6628-6643
+            float* pe = e->hbuf[(e->policy.nl - 1) & 1];   // the buffer mlp_forward's last hidden does not occupy
+            if ((rc = d4::mlp_forward(e, e->policy, e->agent_c, D, B, pe, 4 * D, nullptr, s))) return rc;
+            float* logits = io->action_logits + (size_t)f * A;
+            if ((rc = d4::gemm_simple(pe, 4 * D, e->action_unembed, c.multi_token_pred_len * 4 * D, logits, F * A, B, A, 4 * D, 0, nullptr, nullptr, 0, s))) return rc;
+            // value                                                                    D4:6659-6662
+            float* vb = e->hbuf[(e->value.nl - 1) & 1];
+            if ((rc = d4::mlp_forward(e, e->value, e->agent_c, D, B, vb, c.value_num_bins, nullptr, s))) return rc;
+            if ((rc = d4::hl_gauss_scalar(vb, c.value_num_bins, e->value_centers, io->values + f, F, B, c.value_num_bins, s))) return rc;
+            // sample action, log-prob, terminal                                        D4:6611-6616, 6637-6657
+            d4::SampleArgs sa{};
+            sa.logits = logits; sa.ld = F * A;
+            sa.gumbel_u = io->gumbel_u + (size_t)f * B * A; sa.ld_u = A;
+            sa.term_logit = term_logit; sa.bern_u = io->sample_terminals ? io->bern_u + (size_t)f * B : nullptr;
+            sa.actions = io->actions + (size_t)cur * na; sa.act_stride = T * na;
+            sa.log_probs = io->log_probs + (size_t)f * na; sa.lp_stride = F * na;
+            sa.terminals = io->terminals; sa.lens = io->lens; sa.action_sizes = e->action_sizes;
+            sa.B = B; sa.na = na; sa.frame_index = cur; sa.temperature = io->discrete_temperature;
+            if ((rc = d4::sample_actions_terminals(sa, s))) return rc;
+        } else if (term_logit) {
+            d4::SampleArgs sa{};
+            sa.term_logit = term_logit; sa.bern_u = io->bern_u + (size_t)f * B;
+            sa.terminals = io->terminals; sa.lens = io->lens; sa.B = B; sa.na = 0; sa.frame_index = cur;
+            if ((rc = d4::sample_actions_terminals(sa, s))) return rc;
+        }
+        // history
+        if ((rc = d4::copy_rows(e->x_lat, n_el, io->latents + (size_t)cur * n_el, T * n_el, B, n_el, s))) return rc;
+        if (io->ctx_hist && io->noise_context &&
+            (rc = d4::copy_rows(io->noise_context + (size_t)f * B * n_el, n_el, io->ctx_hist + (size_t)cur * n_el, T * n_el, B, n_el, s))) return rc;
+    }
+    return 0;
+}
+
+int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
+    D4_REQUIRE(e && name && ptr, "null argument");
+    struct { const char* n; float* p; } tbl[] = {
+        {"slabs", e->slabs}, {"xpool", e->xpool}, {"proj0", e->proj0}, {"proj", e->proj}, {"att", e->att},
+        {"ffh", e->ffh}, {"pool_q", e->pool_q}, {"pool_kv", e->pool_kv}, {"pool_att", e->pool_att}, {"cq", e->cq},
+        {"ckv", e->ckv}, {"catt", e->catt}, {"lkv", e->lkv}, {"latt", e->latt}, {"space", e->space}, {"gs", e->gs},
+        {"okv", e->okv}, {"oatt", e->oatt}, {"oproj", e->oproj}, {"pred", e->pred}, {"x_lat", e->x_lat},
+        {"cache", e->cache}, {"lin_q", e->lin_q}, {"lin_gate", e->lin_gate}, {"lout_q", e->lout_q},
+    };
+    for (auto& t : tbl) if (!strcmp(t.n, name)) { *ptr = t.p; return 0; }
+    D4_REQUIRE(false, "unknown debug buffer '%s'", name);
+}
+
+int d4_learn(d4_engine* e, const d4_learn_io* io, void* stream) {
+    D4_REQUIRE(e && io, "null argument");
+    return d4::learn(e, io, static_cast<hipStream_t>(stream));
+}
+
+int64_t d4_group_numel(const d4_engine* e, int group) { return d4::group_numel(e, group); }
+
+int d4_optim_step(d4_engine* e, int group, float* state, int step, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float max_grad_norm, float grad_scale,
+                  float* grad_norm_out, void* stream) {
+    D4_REQUIRE(e && state, "null argument");
+    return d4::optim_step(e, group, state, step, lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale,
+                          grad_norm_out, static_cast<hipStream_t>(stream));
+}
+
+int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+            const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream) {
+    d4::GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    return d4::gemm(g, static_cast<hipStream_t>(stream));
+}
+
+int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim, float eps, void* stream) {
+    return d4::rmsnorm_rows(x, ldx, gamma, y, ldy, rows, dim, eps, static_cast<hipStream_t>(stream));
+}
+
+int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows, int bins, void* stream) {
+    return d4::hl_gauss_scalar(logits, ld, centers, out, 1, rows, bins, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

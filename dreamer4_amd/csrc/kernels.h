@@ -1,0 +1,128 @@
+// Internal launcher interface shared by the engine (engine.hip) and the C-ABI test entry points.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d4 {
+
+// ------------------------------------------------------------------------------------ GEMM
+enum : int {
+    GEMM_RMS_ROWSCALE = 1,   // C = (1/rms(A row)) * (A W^T): RMSNorm folded (gamma pre-multiplied into W)
+    GEMM_SILU = 2,           // C = silu(.)
+    GEMM_SWIGLU = 4,         // packed (value, gate) column pairs -> C[:, N/2] = value * silu(gate)
+    GEMM_TRANS_A = 8,        // A(m, k) read from A[k * lda + m]
+    GEMM_TRANS_B = 16,       // W(n, k) read from W[k * ldw + n]
+    GEMM_ACCUMULATE = 32,    // C += result
+};
+
+struct GemmArgs {
+    const float* A; int lda;
+    const float* W; int ldw;
+    float* C; int ldc;
+    const float* bias;          // [N] or null
+    const float* R; int ldr;    // residual added after activation, or null
+    int M, N, K;
+    int flags;
+    float rms_eps;
+};
+
+int gemm(const GemmArgs& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------ small attention
+// One wave per (group, head); head dim 64 (lane = feature).  Covers the space attention of the
+// trunk, the learned-query pools, the per-token layer pool and the agent-token cross attention.
+struct SmallAttnArgs {
+    const float* q;      int64_t q_group_stride, q_item_stride;      // + h * 64 + lane
+    const float* k;      int64_t k_group_stride, k_item_stride;
+    const float* v;      int64_t v_group_stride, v_item_stride;
+    const float* gate;   int64_t g_group_stride, g_item_stride;      // pre-sigmoid, + h ; may be null
+    const float* k_gamma;                                             // [H][64] K-head-RMSNorm gamma
+    const float* vres;   int64_t r_group_stride, r_item_stride;      // value residual (+ h*64 + lane) or null
+    const float* mix;    int64_t m_group_stride, m_item_stride;      // pre-sigmoid mix logits (+ h) (with vres)
+    float* out;          int64_t o_group_stride, o_item_stride;
+    int groups, heads, nq, nk;
+    float softclamp;      // <= 0 : none
+    int mask_special;     // number of trailing "special" keys ordinary queries may not see
+    int belief;           // subtract the component of out along l2norm(v_i) (requires nq == nk, self attention)
+};
+int small_attn(const SmallAttnArgs& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------ time attention
+// Causal attention along time for every token column (b, s) with a preallocated KV cache.
+//   proj rows are ordered (b, tq, s); columns: q @ 0, k @ hd, v @ 2hd, gate @ 3hd, mix @ 3hd + h.
+//   cache layout: [2][B*S][H][Tcap][64]
+struct TimeAttnArgs {
+    const float* proj; int ldp;
+    const float* vres; int ldv;          // value residual rows (same row order), + h*64 + lane
+    const float* k_gamma;                // [H][64]
+    const float* inv_freq;               // [32]
+    float* cache;                        // this layer's cache
+    float* out; int ldo;                 // rows (b, tq, s), cols h*64 + lane
+    int B, S, H, Tq, t0, Tcap;
+    int cache_batch;                     // batch capacity the cache was laid out for
+    float softclamp;
+};
+int time_kv_append(const TimeAttnArgs& p, hipStream_t stream);   // normalise/rotate/mix new K,V -> cache[t0 .. t0+Tq)
+int time_attn(const TimeAttnArgs& p, hipStream_t stream);        // attend over cache[0 .. t0+i], belief + gates
+
+// ------------------------------------------------------------------------------------ elementwise / glue
+int fold_rows(const float* W, const float* gamma, float* out, int rows, int K, int ld_out, hipStream_t s);
+int copy_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, hipStream_t s);
+int fill_f32(float* dst, float v, int64_t n, hipStream_t s);
+int swiglu_pack_rows(const float* W, const float* bias, const float* gamma, float* Wp, float* bp,
+                     int inner, int inner_pad, int K, hipStream_t s);
+int pad_cols(const float* W, float* out, int rows, int cols, int cols_pad, hipStream_t s);
+int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int D, float eps, hipStream_t s);
+
+struct AssembleArgs {
+    float* tokens;                 // [B*Tq][S][D]
+    const float* space;            // [B*Tq][ns][D]
+    const float* signal_embed;     // [max_steps][D/2]
+    const float* step_embed;       // [log2 max_steps][D/2]
+    const float* registers;        // [nr][D]
+    const float* agent_embed;      // [D]
+    const float* task_embed;       // [num_tasks][D] or null
+    const float* action_embed;     // [total_actions][D]
+    const float* action_learned;   // [D]
+    const int32_t* signal_levels;  // [B*Tq]
+    const int64_t* prev_actions;   // [B*Tq][na] (-1 in slot 0 => zero token) or null (=> zero token)
+    const int64_t* tasks;          // [B] or null
+    const int32_t* action_offsets; // [na] (device)
+    int B, Tq, S, D, ns, nr, na, step_log2;
+};
+int assemble_tokens(const AssembleArgs& p, hipStream_t s);
+
+// gather the spatial-token rows of every frame, RMSNorm(gamma0) then (statistics only) second RMS for the
+// LQAP context norm folded downstream is NOT possible -> both norms applied here.
+int gather_space_double_norm(const float* tokens, float* out, const float* g0, const float* g1,
+                             int frames, int S, int D, int ns, float eps, hipStream_t s);
+
+int euler_step(float* x, int ldx, const float* pred, int ldp, int B, int n_el, float one_minus_t, float dt, hipStream_t s);
+int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
+int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
+                     int hist_stride, int sig_val, int ctx_sig, hipStream_t s);
+int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, hipStream_t s);
+
+// latents input for a parallel (multi-frame) evaluation: context frames lerp(history, ctx_noise, w), last frame = x
+int build_latent_input(float* out, const float* hist, const float* ctx_noise, const float* x,
+                       int B, int Tq, int n_el, int hist_t_stride, float w, hipStream_t s);
+
+// ------------------------------------------------------------------------------------ heads
+int hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int out_stride, int rows, int bins, hipStream_t s);
+int mean_tokens(const float* x, float* out, int B, int n, int d, hipStream_t s);
+struct SampleArgs {
+    const float* logits; int ld;    // [B][A]
+    const float* gumbel_u; int ld_u; // [B][A] uniform
+    const float* term_logit;        // [B] or null
+    const float* bern_u;            // [B] or null
+    int64_t* actions;  int act_stride;      // out [B][na] at stride
+    float* log_probs;  int lp_stride;       // out [B][na]
+    uint8_t* terminals;                     // in/out [B] or null
+    int64_t* lens;                          // in/out [B] or null
+    const int32_t* action_sizes;            // [na] device
+    int B, na, frame_index;
+    float temperature;
+};
+int sample_actions_terminals(const SampleArgs& p, hipStream_t s);
+
+}  // namespace d4

@@ -1,0 +1,692 @@
+"""Host-side mirror of the reference `DynamicsWorldModel` for the imagination path.
+
+Same constructor keyword names, same `generate` / `learn_from_experience` signatures and return
+types as the reference (dreamer4/dreamer4.py:4661-4778, 5893-5904, 6308-6339); parameters carry
+the reference's state_dict key names so checkpoints interchange as flat {key: tensor}.  All compute
+is dispatched to the HIP engine through the C-ABI (include/d4hip.h); PyTorch only owns device
+memory, the stream and (multi-GPU) the process group.  No CPU / eager fallback exists: on a
+machine without the built extension or without a GPU these methods raise.
+
+Configurations outside the supported subset raise NotImplementedError at
+construction instead of being silently ignored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from math import log2
+
+import torch
+from torch import nn
+
+from dreamer4_amd import _lib
+from dreamer4_amd.experience import Actions, Experience
+
+
+class _Node(nn.Module):
+    """Plain container used to reproduce the reference's module tree (names only)."""
+
+
+def _register(root: nn.Module, key: str, tensor: torch.Tensor, buffer=False, persistent=True):
+    parts = key.split('.')
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Node())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(parts[-1], tensor, persistent=persistent)
+    else:
+        m.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _linear_w(out_f, in_f):
+    w = torch.empty(out_f, in_f)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    return w
+
+
+def _linear_b(out_f, in_f):
+    bound = 1 / math.sqrt(in_f) if in_f > 0 else 0
+    return torch.empty(out_f).uniform_(-bound, bound)
+
+
+def mlp_widths(dim_in, dim, dim_out, depth):
+    """create_mlp(dim, depth, dim_in, dim_out) of x-mlps-pytorch: (dim_in, dim x (depth + 1), dim_out).
+    ASSUMED recipe (the package is not in the image) — see DESIGN.md 'Oracle / unpinned third-party pieces'."""
+    return (dim_in, *((dim,) * (depth + 1)), dim_out)
+
+
+class TimeCache:
+    """Opaque handle of the engine's time KV cache (reference: DynamicsIntermediates.main.next_kv_cache,
+    token_count — dreamer4.py:3255-3265).  `kv()` materialises the reference layout
+    (time_layers, 2, B*S, heads, frames, 64)."""
+
+    def __init__(self, model, frames, batch, serial):
+        self._model, self.frames, self.batch, self._serial = model, frames, batch, serial
+        self._kv = None
+
+    @property
+    def token_count(self):
+        return self.frames
+
+    def kv(self):
+        if self._kv is None:
+            self._kv = self._model._export_cache(self)
+        return self._kv
+
+
+_UNSUPPORTED_DEFAULTS = dict(
+    video_tokenizer=None, aux_image_encoder=None, num_agents=1, num_video_views=1, mot_temporal=False,
+    dim_proprio=None, dim_state=None, dim_critic_state=None, critic_state_embedder=None,
+    spatial_pre_encoder_depth=0, action_pre_encoder_depth=0, actor_depth=0, critic_depth=0,
+    pred_orig_latent=True, use_time_rnn=False, add_reward_embed_to_agent_token=False,
+    add_state_pred_head=False, agent_predicts_state=False, num_continuous_actions=0,
+    num_latent_genes=0, keep_reward_ema_stats=False, clip_values=False, time_attention_use_pope=False,
+    latent_ar=False, identity_latents_to_spatial=False, has_aug_conditioning=False, ssl_lapo=False,
+    ssl_tem=False, actor_spr=False, agent_policy_gradient_frac=1., agent_value_gradient_frac=1.,
+    policy_head_mlp_activation='silu', value_head_mlp_activation='silu', state_terminal_pred_mlp_activation='silu',
+)
+
+
+class DynamicsWorldModel(nn.Module):
+    def __init__(
+        self,
+        dim,
+        dim_latent,
+        max_steps=64,
+        num_register_tokens=8,
+        num_spatial_tokens=4,
+        num_latent_tokens=None,
+        num_tasks=0,
+        reward_encoder_type='hl_gauss',
+        reward_encoder_kwargs: dict = dict(),
+        value_encoder_kwargs: dict | None = None,
+        depth=4,
+        time_block_every=4,
+        attn_kwargs: dict = dict(),
+        transformer_kwargs: dict = dict(),
+        attn_heads=8,
+        attn_dim_head=64,
+        attn_softclamp_value=50.,
+        ff_kwargs: dict = dict(),
+        num_discrete_actions: int | tuple = 0,
+        multi_token_pred_len=8,
+        value_head_mlp_depth=3,
+        policy_head_mlp_depth=3,
+        predict_terminals=True,
+        predict_terminal_mlp_kwargs: dict = dict(depth=1),
+        gae_discount_factor=0.997,
+        gae_lambda=0.95,
+        ppo_eps_clip=0.2,
+        pmpo_pos_to_neg_weight=0.5,
+        pmpo_reverse_kl=True,
+        pmpo_kl_div_loss_weight=.3,
+        use_delight_gating=True,
+        delight_temperature=1.,
+        normalize_advantages=None,
+        policy_entropy_weight=.01,
+        **kwargs,
+    ):
+        super().__init__()
+        for k, v in kwargs.items():
+            if k not in _UNSUPPORTED_DEFAULTS:
+                raise TypeError(f'unknown argument {k!r}')
+            if v != _UNSUPPORTED_DEFAULTS[k]:
+                raise NotImplementedError(f'{k}={v!r} is outside the supported imagination-path subset (SURVEY.md section 8)')
+        if reward_encoder_type != 'hl_gauss':
+            raise NotImplementedError('only the default hl_gauss reward/value encoder is implemented')
+        if attn_kwargs or transformer_kwargs or ff_kwargs:
+            raise NotImplementedError('attn_kwargs / transformer_kwargs / ff_kwargs must be empty (reference defaults)')
+        if num_latent_tokens is None:
+            raise AssertionError('`num_latent_tokens` must be set')
+        if attn_dim_head != 64:
+            raise NotImplementedError('attn_dim_head must be 64 (one CDNA wavefront per head row)')
+        if num_spatial_tokens == num_latent_tokens:
+            raise NotImplementedError('num_spatial_tokens == num_latent_tokens (Linear latents_to_spatial) is not implemented')
+        assert dim % 2 == 0
+        assert log2(max_steps).is_integer(), '`max_steps` must be a power of 2'
+
+        nda = num_discrete_actions if isinstance(num_discrete_actions, (tuple, list)) else (num_discrete_actions,)
+        nda = tuple(int(n) for n in nda if n > 0)
+        value_encoder_kwargs = reward_encoder_kwargs if value_encoder_kwargs is None else value_encoder_kwargs
+
+        def enc(kw):
+            kw = dict(kw)
+            rng = tuple(kw.pop('reward_range', (-20., 20.)))
+            bins = kw.pop('num_bins', 255)
+            ratio = kw.pop('sigma_to_bin_ratio', 2.)
+            eps = kw.pop('eps', 1e-10)
+            if kw:
+                raise NotImplementedError(f'reward/value encoder options {sorted(kw)} are not implemented')
+            return rng, bins, ratio, eps
+
+        (self.reward_range, self.reward_num_bins, _, _) = enc(reward_encoder_kwargs)
+        (self.value_range, self.value_num_bins, self.hl_sigma_ratio, self.hl_eps) = enc(value_encoder_kwargs)
+
+        self.dim, self.dim_latent, self.depth = dim, dim_latent, depth
+        self.num_latent_tokens, self.latent_shape = num_latent_tokens, (num_latent_tokens, dim_latent)
+        self.max_steps, self.num_register_tokens, self.num_spatial_tokens = max_steps, num_register_tokens, num_spatial_tokens
+        self.num_tasks, self.time_block_every = num_tasks, time_block_every
+        self.attn_heads, self.attn_dim_head, self.attn_softclamp_value = attn_heads, attn_dim_head, attn_softclamp_value
+        self.num_discrete_actions = nda
+        self.multi_token_pred_len = multi_token_pred_len
+        self.policy_head_mlp_depth, self.value_head_mlp_depth = policy_head_mlp_depth, value_head_mlp_depth
+        self.terminal_mlp_depth = dict(predict_terminal_mlp_kwargs).get('depth', 1)
+        self.predict_terminals = predict_terminals
+        self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip = gae_discount_factor, gae_lambda, ppo_eps_clip
+        self.pmpo_pos_to_neg_weight, self.pmpo_reverse_kl = pmpo_pos_to_neg_weight, pmpo_reverse_kl
+        self.pmpo_kl_div_loss_weight = pmpo_kl_div_loss_weight
+        self.use_delight_gating, self.delight_temperature = use_delight_gating, delight_temperature
+        self.normalize_advantages, self.policy_entropy_weight = normalize_advantages, policy_entropy_weight
+        self.pool_heads, self.pool_dim_head = 4, 64              # AttentionPool defaults, dreamer4.py:2147-2148
+        self.tokens_per_frame = 1 + num_spatial_tokens + num_register_tokens + 1 + 1
+        self.ff_inner = int(dim * 4 * 2 / 3)
+
+        self._build_parameters()
+
+        # engine state (created lazily on the parameters' device)
+        self._engine = None
+        self._engine_caps = None
+        self._ws = None
+        self._bound_sig = None
+        self._trunk_version = None
+        self._cache_serial = 0
+        self._live_cache = None
+        self._groups = {}
+
+    # ------------------------------------------------------------------------------ parameters
+    def _build_parameters(self):
+        D, dl, h = self.dim, self.dim_latent, self.attn_heads
+        hd = h * 64
+        reg = lambda k, t: _register(self, k, t)
+
+        def attn(pre, dim_q, dim_kv, heads, ctx_norm, mix):
+            inner = heads * 64
+            reg(pre + 'norm.weight', torch.ones(dim_q))
+            if ctx_norm:
+                reg(pre + 'norm_context.weight', torch.ones(dim_kv))
+            reg(pre + 'to_q.weight', _linear_w(inner, dim_q))
+            reg(pre + 'to_k.weight', _linear_w(inner, dim_kv))
+            reg(pre + 'to_v.weight', _linear_w(inner, dim_kv))
+            reg(pre + 'to_out.weight', _linear_w(dim_q, inner))
+            reg(pre + 'to_gates.0.weight', _linear_w(heads, dim_q))
+            reg(pre + 'k_heads_rmsnorm.gamma', torch.zeros(heads, 64))
+            if mix:
+                reg(pre + 'to_learned_value_residual_mix.0.weight', _linear_w(heads, dim_q))
+                reg(pre + 'to_learned_value_residual_mix.0.bias', _linear_b(heads, dim_q))
+
+        def ff(pre):
+            reg(pre + 'norm.weight', torch.ones(D))
+            reg(pre + 'proj_in.weight', _linear_w(2 * self.ff_inner, D))
+            reg(pre + 'proj_in.bias', _linear_b(2 * self.ff_inner, D))
+            reg(pre + 'proj_out.weight', _linear_w(D, self.ff_inner))
+            reg(pre + 'proj_out.bias', _linear_b(D, self.ff_inner))
+
+        def mlp(pre, widths):
+            for i, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
+                reg(f'{pre}layers.{i}.0.weight', torch.ones(a))
+                reg(f'{pre}layers.{i}.1.weight', _linear_w(b, a))
+                reg(f'{pre}layers.{i}.1.bias', _linear_b(b, a))
+
+        reg('latents_to_spatial_tokens.queries', torch.randn(self.num_spatial_tokens, D) * 1e-2)
+        attn('latents_to_spatial_tokens.attn.', D, dl, h, True, False)
+        reg('to_latent_pred.0.weight', torch.ones(D))
+        reg('to_latent_pred.1.queries', torch.randn(self.num_latent_tokens, D) * 1e-2)
+        attn('to_latent_pred.1.attn.', D, D, h, True, False)
+        reg('to_latent_pred.2.weight', _linear_w(dl, D))
+        reg('register_tokens', torch.randn(self.num_register_tokens, D) * 1e-2)
+        reg('signal_levels_embed.weight', torch.randn(self.max_steps, D // 2))
+        reg('step_size_embed.weight', torch.randn(int(log2(self.max_steps)), D // 2))
+        reg('agent_learned_embed', torch.randn(1, D) * 1e-2)
+        reg('action_learned_embed', torch.randn(1, D) * 1e-2)
+        reg('reward_learned_embed', torch.randn(1, D) * 1e-2)          # unused on the supported path; kept for key parity
+        reg('task_embed.weight', torch.randn(self.num_tasks, D))
+        mlp('policy_head.', mlp_widths(D, 4 * D, 4 * D, self.policy_head_mlp_depth))
+        A = sum(self.num_discrete_actions)
+        reg('action_embedder.discrete_action_unembed', torch.randn(A, self.multi_token_pred_len, 4 * D) * 1e-2)
+        reg('action_embedder.continuous_action_unembed', torch.randn(0, self.multi_token_pred_len, 4 * D, 2) * 1e-2)
+        reg('action_embedder.discrete_action_embed.weight', torch.randn(A, D))
+        reg('action_embedder.continuous_action_embed.weight', torch.randn(0, D))
+        mtp = self.multi_token_pred_len
+        reg('to_reward_pred.params.0', torch.ones(mtp, D))
+        reg('to_reward_pred.params.1', torch.stack([_linear_w(self.reward_num_bins, D) for _ in range(mtp)]))
+        if self.predict_terminals:
+            mlp('to_state_terminal_pred.0.', mlp_widths(dl, 4 * dl, 1, self.terminal_mlp_depth))
+        mlp('value_head.', mlp_widths(D, 4 * D, self.value_num_bins, self.value_head_mlp_depth))
+        inv_freq = 1.0 / (10000. ** (torch.arange(0, 64, 2).float() / 64))
+        _register(self, 'transformer.time_rotary.inv_freq', inv_freq, buffer=True)
+        reg('transformer.to_value_residual.0.weight', torch.ones(D))
+        reg('transformer.to_value_residual.1.weight', _linear_w(hd, D))
+        for i in range(self.depth):
+            attn(f'transformer.layers.{i}.2.fn.', D, D, h, False, True)
+            ff(f'transformer.layers.{i}.3.fn.')
+        for i in range(self.depth - 1):
+            attn(f'transformer.attn_pools.{i}.fn.attn.', D, D, self.pool_heads, True, False)
+        attn('transformer.final_attn_pool.fn.attn.', D, D, self.pool_heads, True, False)
+        attn('transformer.final_special_cross_attn.fn.', D, D, h, True, True)
+        ff('transformer.final_special_ff.fn.')
+        # constructor-built buffers of the HL-Gauss encoders (hl_gauss_pytorch.HLGaussLoss.support / centers)
+        for name, rng, bins in (('reward_encoder', self.reward_range, self.reward_num_bins),
+                                ('value_encoder', self.value_range, self.value_num_bins)):
+            support = torch.linspace(rng[0], rng[1], bins + 1).float()
+            _register(self, f'{name}.support', support, buffer=True, persistent=False)
+            _register(self, f'{name}.centers', (support[:-1] + support[1:]) / 2, buffer=True, persistent=False)
+        _register(self, 'zero', torch.tensor(0.), buffer=True, persistent=False)
+
+    @property
+    def device(self):
+        return self.zero.device
+
+    def policy_head_parameters(self):
+        """dreamer4.py:5343-5355"""
+        return [*self.policy_head.parameters(), self.action_embedder.discrete_action_unembed,
+                self.action_embedder.continuous_action_unembed]
+
+    def value_head_parameters(self):
+        """dreamer4.py:5357-5363"""
+        return list(self.value_head.parameters())
+
+    # ------------------------------------------------------------------------------ engine plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _make_config(self, caps):
+        c = _lib.Config()
+        c.dim, c.dim_latent, c.num_latent_tokens, c.depth = self.dim, self.dim_latent, self.num_latent_tokens, self.depth
+        c.time_block_every, c.attn_heads, c.attn_dim_head = self.time_block_every, self.attn_heads, self.attn_dim_head
+        c.attn_softclamp_value = self.attn_softclamp_value
+        c.num_spatial_tokens, c.num_register_tokens = self.num_spatial_tokens, self.num_register_tokens
+        c.max_steps, c.num_tasks = self.max_steps, self.num_tasks
+        c.num_discrete_action_types = len(self.num_discrete_actions)
+        for i, n in enumerate(self.num_discrete_actions):
+            c.num_discrete_actions[i] = n
+        c.multi_token_pred_len = self.multi_token_pred_len
+        c.policy_head_mlp_depth, c.value_head_mlp_depth = self.policy_head_mlp_depth, self.value_head_mlp_depth
+        c.terminal_mlp_depth, c.predict_terminals = self.terminal_mlp_depth, int(self.predict_terminals)
+        c.reward_num_bins, c.value_num_bins = self.reward_num_bins, self.value_num_bins
+        c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
+        c.gae_discount_factor, c.gae_lambda, c.ppo_eps_clip = self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip
+        c.policy_entropy_weight = self.policy_entropy_weight
+        c.use_delight_gating, c.delight_temperature = int(self.use_delight_gating), self.delight_temperature
+        c.pmpo_pos_to_neg_weight, c.pmpo_kl_div_loss_weight = self.pmpo_pos_to_neg_weight, self.pmpo_kl_div_loss_weight
+        c.pmpo_reverse_kl = int(self.pmpo_reverse_kl)
+        c.hl_gauss_sigma_to_bin_ratio, c.hl_gauss_eps = self.hl_sigma_ratio, self.hl_eps
+        c.value_min, c.value_max = self.value_range
+        c.max_batch, c.max_frames, c.max_parallel_frames, c.max_learn_rows = caps
+        return c
+
+    def _ensure_engine(self, batch=1, frames=1, parallel=1, learn_rows=0):
+        if self.device.type != 'cuda':
+            raise _lib.D4Error('the imagination path runs only on an MI355X (HIP) device: move the model with .cuda(); '
+                               'there is no CPU fallback')
+        lib = _lib.load()
+        caps = self._engine_caps
+        if caps is None or batch > caps[0] or frames > caps[1] or parallel > caps[2] or learn_rows > caps[3]:
+            keep = None
+            if self._engine is not None and lib.d4_engine_cache_frames(self._engine) > 0 and self._live_cache is not None:
+                keep = (self._live_cache, self._live_cache.kv())
+            old = caps or (0, 0, 0, 0)
+            caps = (max(batch, old[0]), max(frames, old[1]), max(parallel, old[2]), max(learn_rows, old[3]))
+            if self._engine is not None:
+                lib.d4_engine_destroy(self._engine)
+            eng = C.c_void_p()
+            cfg = self._make_config(caps)
+            _lib.check(lib.d4_engine_create(C.byref(cfg), C.byref(eng)))
+            self._engine, self._engine_caps = eng, caps
+            nbytes = lib.d4_engine_workspace_bytes(eng)
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            base = self._ws.data_ptr()
+            self._ws_off = (-base) % 256
+            _lib.check(lib.d4_engine_set_workspace(eng, C.c_void_p(base + self._ws_off), nbytes))
+            self._bound_sig = None
+            self._trunk_version = None
+            if keep is not None:
+                tc, kv = keep
+                _lib.check(lib.d4_engine_cache_import(eng, _lib.ptr(kv), tc.batch, tc.frames, self._stream()))
+        self._bind()
+        return self._engine
+
+    def _flatten_group(self, name, params):
+        """Make a head's parameters views of one flat buffer (and allocate its flat gradient), so the
+        optimiser step and the RCCL all-reduce each touch a single contiguous tensor."""
+        params = [p for p in params if p.numel() > 0]
+        total = sum(p.numel() for p in params)
+        g = self._groups.get(name)
+        ok = g is not None and g['flat'].device == self.device and g['flat'].numel() == total
+        if ok:
+            off = 0
+            for p in params:
+                if p.data_ptr() != g['flat'].data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if ok:
+            return g
+        flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        g = dict(flat=flat, grad=grad, params=params)
+        self._groups[name] = g
+        return g
+
+    def _bind(self):
+        lib = _lib.load()
+        groups = dict(policy=self._flatten_group('policy', self.policy_head_parameters()),
+                      value=self._flatten_group('value', self.value_head_parameters()))
+        grads = {}
+        for g in groups.values():
+            off = 0
+            for p in g['params']:
+                grads[id(p)] = g['grad'][off:off + p.numel()]
+                off += p.numel()
+        tensors = dict(self.named_parameters())
+        tensors.update({k: v for k, v in self.named_buffers() if k != 'zero'})
+        sig = tuple((k, t.data_ptr(), t.numel()) for k, t in tensors.items())
+        if sig != self._bound_sig:
+            for k, t in tensors.items():
+                if t.numel() == 0:
+                    continue
+                assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device, k
+                gr = grads.get(id(t))
+                _lib.check(lib.d4_engine_bind(self._engine, k.encode(), _lib.ptr(t), _lib.ptr(gr), t.numel()))
+            self._bound_sig = sig
+            self._trunk_version = None
+        head_ids = {id(p) for g in groups.values() for p in g['params']}
+        ver = tuple(t._version for t in tensors.values() if id(t) not in head_ids)
+        if ver != self._trunk_version:
+            _lib.check(lib.d4_engine_prepare(self._engine, self._stream()))
+            self._trunk_version = ver
+
+    def _export_cache(self, tc: TimeCache):
+        lib = _lib.load()
+        if self._live_cache is not tc:
+            raise _lib.D4Error('this TimeCache is stale (the engine cache has advanced past it); '
+                               'call .kv() before issuing further generate() calls to keep a copy')
+        lt = sum(1 for i in range(self.depth) if (i + 1) % self.time_block_every == 0)
+        out = torch.empty(lt, 2, tc.batch * self.tokens_per_frame, self.attn_heads, tc.frames, 64, device=self.device)
+        _lib.check(lib.d4_engine_cache_export(self._engine, _lib.ptr(out), tc.batch, self._stream()))
+        return out
+
+    def _adopt_cache(self, time_cache, batch):
+        lib = _lib.load()
+        if time_cache is None:
+            _lib.check(lib.d4_engine_cache_reset(self._engine, 0))
+            self._live_cache = None
+            return 0
+        assert isinstance(time_cache, TimeCache), 'time_cache must come from generate(..., return_time_cache=True)'
+        assert time_cache.batch == batch, 'time_cache batch size mismatch'
+        if self._live_cache is not time_cache:
+            if time_cache._kv is None:
+                raise _lib.D4Error('stale TimeCache without a materialised copy (.kv())')
+            _lib.check(lib.d4_engine_cache_import(self._engine, _lib.ptr(time_cache._kv), batch, time_cache.frames, self._stream()))
+            self._live_cache = time_cache
+        return time_cache.frames
+
+    # ------------------------------------------------------------------------------ forward (inference branch)
+    @torch.no_grad()
+    def forward(self, *, latents, signal_levels, step_sizes, discrete_actions=None, tasks=None, time_cache=None,
+                latent_is_noised=True, return_pred_only=True, return_intermediates=True, commit_cache=True, **kwargs):
+        """Inference branch of DynamicsWorldModel.forward (dreamer4.py:6792-7295): latents are already noised,
+        returns (pred_flow, (agent_embed, next_time_cache)).  The training branch is out of scope."""
+        if kwargs:
+            raise NotImplementedError(f'forward(): arguments {sorted(kwargs)} are outside the inference branch')
+        if not (latent_is_noised and return_pred_only):
+            raise NotImplementedError('only forward(latent_is_noised=True, return_pred_only=True) is implemented')
+        B, T = latents.shape[:2]
+        step = int(step_sizes if not torch.is_tensor(step_sizes) else step_sizes.flatten()[0].item())
+        cached = time_cache.frames if time_cache is not None else 0
+        self._ensure_engine(batch=B, frames=cached + T, parallel=T)
+        lib = _lib.load()
+        self._adopt_cache(time_cache, B)
+        dev = self.device
+        if isinstance(signal_levels, int):
+            signal_levels = torch.full((B, T), signal_levels)
+        sig = signal_levels.to(dev).expand(B, T).to(torch.int32).contiguous() if signal_levels.ndim == 2 else \
+            signal_levels.to(dev).reshape(-1, 1).expand(B, T).to(torch.int32).contiguous()
+        prev = None
+        na = len(self.num_discrete_actions)
+        if discrete_actions is not None and discrete_actions.shape[1] > 0:
+            a = discrete_actions.to(dev)
+            a = a[..., None] if a.ndim == 2 else a
+            if time_cache is not None and T == 1 and a.shape[1] == 1:
+                prev = a.contiguous()                                   # sequential step: already paired (dreamer4.py:7103)
+            else:
+                if a.shape[1] == T:
+                    a = a[:, :-1]
+                assert a.shape[1] == T - 1
+                prev = torch.cat((torch.full((B, 1, na), -1, dtype=torch.long, device=dev), a), dim=1).contiguous()
+        tk = tasks.to(dev).long().contiguous() if tasks is not None else None
+        pred = torch.empty(B, T, *self.latent_shape, device=dev)
+        agent = torch.empty(B, T, self.dim, device=dev)
+        lat = latents.to(dev).float().reshape(B, T, *self.latent_shape).contiguous()
+        _lib.check(lib.d4_wm_forward(self._engine, _lib.ptr(lat), _lib.ptr(sig), step, _lib.ptr(prev), _lib.ptr(tk), B, T,
+                                     int(time_cache is not None), int(commit_cache), _lib.ptr(pred), _lib.ptr(agent), self._stream()))
+        self._cache_serial += 1
+        tc = TimeCache(self, lib.d4_engine_cache_frames(self._engine), B, self._cache_serial)
+        self._live_cache = tc if commit_cache else None
+        return pred, (agent, tc)
+
+    # ------------------------------------------------------------------------------ generate
+    @torch.no_grad()
+    def generate(
+        self,
+        time_steps,
+        num_steps=4,
+        batch_size=1,
+        agent_index=0,
+        tasks=None,
+        latent_gene_ids=None,
+        image_height=None,
+        image_width=None,
+        return_decoded_video=None,
+        context_signal_noise=0.1,
+        time_cache: TimeCache | None = None,
+        use_time_cache=True,
+        return_rewards_per_frame=False,
+        return_terminals=False,
+        return_agent_actions=False,
+        return_log_probs_and_values=False,
+        return_for_policy_optimization=False,
+        return_time_cache=False,
+        store_agent_embed=True,
+        store_old_action_unembeds=True,
+        prompt=None,
+        prompt_latents=None,
+        prompt_proprio=None,
+        prompt_discrete_actions=None,
+        prompt_continuous_actions=None,
+        prompt_rewards=None,
+        aug_id=False,
+        discrete_temperature=1.,
+        continuous_temperature=1.,
+        *,
+        noise: dict | None = None,
+        generator: torch.Generator | None = None,
+    ):
+        """DynamicsWorldModel.generate (dreamer4.py:6308-6774) on the HIP engine.
+
+        Extra keyword-only arguments: `noise` injects the four per-frame random draws
+        (`latent`, `context` (F,B,n,dl) normal; `gumbel_u` (F,B,A), `bern_u` (F,B) uniform) for
+        parity runs; otherwise they are drawn on the device from `generator`."""
+        if prompt is not None or return_decoded_video:
+            raise NotImplementedError('video prompts / decoding need the VideoTokenizer, which is out of scope (SURVEY.md 8f)')
+        if latent_gene_ids is not None or prompt_proprio is not None or prompt_continuous_actions is not None or aug_id not in (False, None, 0):
+            raise NotImplementedError('latent genes / proprio / continuous actions / aug conditioning are not implemented')
+        assert agent_index == 0
+        if return_for_policy_optimization:
+            return_agent_actions = return_log_probs_and_values = return_rewards_per_frame = True
+            return_terminals = return_terminals or self.predict_terminals
+        return_agent_actions = return_agent_actions or return_log_probs_and_values
+        assert log2(num_steps).is_integer(), f'number of steps {num_steps} must be a power of 2'
+        assert 0 < num_steps <= self.max_steps, f'number of steps {num_steps} must be between 0 and {self.max_steps}'
+        if return_agent_actions and not self.num_discrete_actions:
+            raise AssertionError('the model has no actions (dreamer4.py:6626)')
+        if not self.num_discrete_actions:
+            raise NotImplementedError('action-free world models are not implemented on the engine yet')
+
+        dev, B, T = self.device, batch_size, time_steps
+        n, dl = self.latent_shape
+        na, A = len(self.num_discrete_actions), sum(self.num_discrete_actions)
+        if isinstance(tasks, int):
+            tasks = torch.full((B,), tasks)
+        assert tasks is None or tasks.shape[0] == B
+
+        P = 0
+        if prompt_latents is not None:
+            pl = prompt_latents
+            if pl.ndim == 5:
+                assert pl.shape[2] == 1
+                pl = pl[:, :, 0]
+            assert pl.shape[0] == B
+            P = pl.shape[1]
+        F_ = max(T - P, 0)
+        sample_terminals = bool(return_terminals and self.predict_terminals)
+
+        cached = time_cache.frames if time_cache is not None else 0
+        if use_time_cache:
+            parallel = (P + 1) if (P > 0 and cached == 0) else 1
+        else:
+            parallel = T
+        self._ensure_engine(batch=B, frames=cached + max(T, 1), parallel=parallel)
+        lib = _lib.load()
+        self._adopt_cache(time_cache if use_time_cache else None, B)
+
+        # ---- noise
+        if noise is None:
+            g = generator
+            noise = dict(
+                latent=torch.randn(F_, B, n, dl, device=dev, generator=g),
+                context=torch.randn(F_, B, n, dl, device=dev, generator=g) if not use_time_cache else None,
+                gumbel_u=torch.rand(F_, B, A, device=dev, generator=g) if return_agent_actions else None,
+                bern_u=torch.rand(F_, B, device=dev, generator=g) if sample_terminals else None,
+            )
+        nz = {k: (v.to(dev).float().contiguous() if v is not None else None) for k, v in noise.items()}
+        assert nz['latent'].shape[0] >= F_
+
+        # ---- histories
+        latents = torch.zeros(B, T, n, dl, device=dev)
+        ctx_hist = None
+        if P > 0:
+            latents[:, :P] = pl.to(dev)
+        if not use_time_cache:
+            ctx_hist = latents.clone()
+        actions = None
+        if return_agent_actions or prompt_discrete_actions is not None:
+            actions = torch.zeros(B, T, na, dtype=torch.long, device=dev)
+            if prompt_discrete_actions is not None:
+                pa = prompt_discrete_actions.to(dev)
+                pa = pa[..., None] if pa.ndim == 2 else pa
+                actions[:, :pa.shape[1]] = pa[:, :T]
+        rewards = torch.zeros(B, T, device=dev)
+        if prompt_rewards is not None:
+            rewards[:, :prompt_rewards.shape[1]] = prompt_rewards.to(dev)[:, :T]
+        agent_embed = torch.empty(B, F_, self.dim, device=dev)
+        log_probs = torch.empty(B, F_, na, device=dev)
+        values = torch.empty(B, F_, device=dev)
+        logits = torch.empty(B, F_, A, device=dev)
+        lens = torch.full((B,), T, dtype=torch.long, device=dev)
+        terminals = torch.zeros(B, dtype=torch.uint8, device=dev)
+        tk = tasks.to(dev).long().contiguous() if tasks is not None else None
+
+        io = _lib.RolloutIO()
+        io.batch, io.time_steps, io.prompt_frames, io.num_steps = B, T, P, num_steps
+        io.use_time_cache, io.sample_terminals = int(use_time_cache), int(sample_terminals)
+        io.sample_actions = int(return_agent_actions)
+        io.context_signal_noise, io.discrete_temperature = context_signal_noise, discrete_temperature
+        P_ = _lib.ptr
+        io.noise_latent, io.noise_context = P_(nz['latent']), P_(nz.get('context'))
+        io.gumbel_u, io.bern_u, io.tasks = P_(nz.get('gumbel_u')), P_(nz.get('bern_u')), P_(tk)
+        io.latents, io.actions, io.rewards, io.ctx_hist = P_(latents), P_(actions), P_(rewards), P_(ctx_hist)
+        io.agent_embed, io.log_probs, io.values, io.action_logits = P_(agent_embed), P_(log_probs), P_(values), P_(logits)
+        io.lens, io.terminals = P_(lens), P_(terminals)
+        if F_ > 0:
+            _lib.check(lib.d4_rollout(self._engine, C.byref(io), self._stream()))
+
+        self._cache_serial += 1
+        new_cache = None
+        if use_time_cache:
+            new_cache = TimeCache(self, lib.d4_engine_cache_frames(self._engine), B, self._cache_serial)
+            self._live_cache = new_cache
+        else:
+            self._live_cache = None
+
+        # ---- early exit once every trajectory has terminated (dreamer4.py:6681): the engine always runs all
+        # frames (no host sync inside the rollout); frames past the reference's break are dropped here.
+        Tp = T
+        terminals_b = terminals.bool()
+        if sample_terminals and bool(terminals_b.all()):
+            Tp = int(lens.max().item())
+        Fp = Tp - P
+        latents = latents[:, :Tp].clamp(-1., 1.)
+
+        if not (return_rewards_per_frame or return_agent_actions):
+            return (latents, new_cache) if return_time_cache else latents
+
+        step_mask = torch.arange(Tp, device=dev) < lens[:, None]
+        rewards = rewards[:, :Tp]
+        gen = Experience(
+            latents=latents,
+            video=None,
+            proprio=None,
+            agent_embed=agent_embed[:, :Fp] if store_agent_embed else None,
+            old_action_unembeds=Actions(logits[:, :Fp], None) if (return_agent_actions and store_old_action_unembeds) else None,
+            step_size=self.max_steps // num_steps,
+            agent_index=agent_index,
+            lens=lens,
+            is_truncated=~terminals_b,
+            terminals=terminals_b,
+            is_from_world_model=True,
+            episode_return=(rewards * step_mask.float()).sum(dim=-1),
+            rewards=rewards if return_rewards_per_frame else None,
+            actions=Actions(actions[:, :Tp], None) if return_agent_actions else None,
+            log_probs=Actions(log_probs[:, :Fp], None) if return_log_probs_and_values else None,
+            values=values[:, :Fp] if return_log_probs_and_values else None,
+        )
+        return (gen, new_cache) if return_time_cache else gen
+
+    # ------------------------------------------------------------------------------ learn
+    def learn_from_experience(
+        self,
+        experience: Experience,
+        policy_optim=None,
+        value_optim=None,
+        only_learn_policy_value_heads=True,
+        objective='ppo',
+        use_delight_gating=None,
+        delight_temperature=None,
+        normalize_advantages=None,
+        eps=1e-6,
+        *,
+        process_group=None,
+        stats='global',
+    ):
+        """DynamicsWorldModel.learn_from_experience (dreamer4.py:5893-6305) for the default
+        `only_learn_policy_value_heads=True` path with stored agent embeddings.  Losses and the
+        gradients of both heads come from the HIP learner; the returned tensors are autograd-connected
+        to the head parameters, so `loss.backward()` / optimiser usage is unchanged.
+
+        Data parallel: with an initialised process group and `stats='global'` the advantage
+        statistics and every masked-mean denominator are all-reduced, so N ranks x B_local equal one
+        process at B_global; gradients are all-reduced by the caller (DreamTrainer)."""
+        from dreamer4_amd.learner import learn
+        return learn(self, experience, policy_optim, value_optim, only_learn_policy_value_heads, objective,
+                     use_delight_gating, delight_temperature, normalize_advantages, eps, process_group, stats)
+
+
+def _debug_buffer(model, name, shape):
+    """Test hook: copy an engine-internal activation buffer out (see d4_debug_buffer)."""
+    lib = _lib.load()
+    p = C.c_void_p()
+    _lib.check(lib.d4_debug_buffer(model._engine, name.encode(), C.byref(p)))
+    base = model._ws.data_ptr()
+    off = p.value - base
+    numel = 1
+    for s in shape:
+        numel *= s
+    return model._ws[off:off + 4 * numel].view(torch.float32).view(*shape).clone()

@@ -1,0 +1,194 @@
+/*
+ * d4hip — C-ABI of the MI355X-native (gfx950) implementation of dreamer4's imagination hot path.
+ *
+ * The reference (lucidrains/dreamer4, /root/reference/dreamer4/dreamer4.py = "D4") has no FFI or
+ * operator boundary: its API is the Python nn.Module surface.  This header is the boundary a
+ * maintainer would bind instead of the ATen op sequences of
+ *
+ *   DynamicsWorldModel.generate               D4:6308-6774   -> d4_rollout
+ *   DynamicsWorldModel.forward (inference)    D4:6792-7295   -> d4_wm_forward
+ *   DynamicsWorldModel.learn_from_experience  D4:5893-6305   -> d4_learn (+ d4_optim_step)
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers + sizes; `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success; otherwise a non-zero code and d4_last_error() holds the
+ *     message (shape / config / HIP errors).  Nothing is retried or silently replaced by a fallback.
+ *   - all tensors are dense fp32 row-major unless stated; integer tensors are int64 (actions, lens,
+ *     tasks) to match torch.long on the Python side; booleans are uint8.
+ *   - the engine never allocates device memory: the caller owns one workspace buffer
+ *     (d4_engine_workspace_bytes) and all weight / IO tensors.  Kernels are enqueued on `stream`
+ *     with no host synchronisation, so calls are hipGraph-capturable.
+ *   - weights are bound by the reference's state_dict key names (weight interchange = flat
+ *     {key: tensor}), see d4_engine_bind.
+ */
+#ifndef D4HIP_H
+#define D4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D4_MAX_ACTION_TYPES 8
+
+/* Constructor arguments of DynamicsWorldModel (supported subset; names as D4:4662-4778). */
+typedef struct d4_config {
+    int32_t dim, dim_latent, num_latent_tokens, depth, time_block_every;
+    int32_t attn_heads, attn_dim_head;          /* attn_dim_head must be 64 (one wavefront) */
+    float attn_softclamp_value;
+    int32_t num_spatial_tokens, num_register_tokens, max_steps, num_tasks;
+    int32_t num_discrete_action_types;
+    int32_t num_discrete_actions[D4_MAX_ACTION_TYPES];
+    int32_t multi_token_pred_len;
+    int32_t policy_head_mlp_depth, value_head_mlp_depth, terminal_mlp_depth, predict_terminals;
+    int32_t reward_num_bins, value_num_bins;
+    int32_t pool_heads, pool_dim_head;          /* AttentionPool defaults 4 x 64 (D4:2147-2148) */
+    /* learn_from_experience hyper-parameters (D4:4731-4744) */
+    float gae_discount_factor, gae_lambda, ppo_eps_clip, policy_entropy_weight;
+    int32_t use_delight_gating;
+    float delight_temperature, pmpo_pos_to_neg_weight, pmpo_kl_div_loss_weight;
+    int32_t pmpo_reverse_kl;
+    float hl_gauss_sigma_to_bin_ratio, hl_gauss_eps, value_min, value_max;
+    /* capacities the workspace is sized for */
+    int32_t max_batch;            /* trajectories per call */
+    int32_t max_frames;           /* KV-cache capacity in frames (prompt + generated) */
+    int32_t max_parallel_frames;  /* frames evaluated in one parallel pass (1 = cached decode only) */
+    int32_t max_learn_rows;       /* batch * time rows of one learn_from_experience call (0 = no learner) */
+} d4_config;
+
+typedef struct d4_engine d4_engine;
+
+const char* d4_last_error(void);
+int d4_version(void);
+
+int d4_engine_create(const d4_config* cfg, d4_engine** out);
+void d4_engine_destroy(d4_engine* e);
+
+/* Bytes of device workspace the engine needs (prepared weights + activations + KV cache). */
+size_t d4_engine_workspace_bytes(const d4_engine* e);
+int d4_engine_set_workspace(d4_engine* e, void* device_ptr, size_t bytes);
+
+/* Bind one parameter/buffer by its reference state_dict key, e.g.
+ * "transformer.layers.3.2.fn.to_q.weight" (layout list: DESIGN.md "Weight interchange").
+ * `grad` may be NULL; when given, d4_learn writes d(loss)/d(param) there (policy / value heads).
+ * Pseudo-keys for buffers the reference builds in its constructor:
+ *   "reward_encoder.centers" [reward_num_bins], "value_encoder.centers" [value_num_bins],
+ *   "value_encoder.support" [value_num_bins + 1]. */
+int d4_engine_bind(d4_engine* e, const char* key, const float* device_ptr, float* grad, int64_t numel);
+
+/* Build the fused / gamma-folded weight images in the workspace.  Call after binding, and again
+ * whenever a trunk weight changes (head MLP weights are read in place and need no re-prepare). */
+int d4_engine_prepare(d4_engine* e, void* stream);
+
+/* Number of frames currently held by the time KV cache (token_count of D4:3261). */
+int d4_engine_cache_frames(const d4_engine* e);
+int d4_engine_cache_reset(d4_engine* e, int frames);   /* truncate / reset (0 = empty) */
+/* Export / import the cache in the reference layout (time_layers, 2, B*S, heads, t, 64)  D4:2075, 3256. */
+int d4_engine_cache_export(d4_engine* e, float* dst, int batch, void* stream);
+int d4_engine_cache_import(d4_engine* e, const float* src, int batch, int frames, void* stream);
+
+/* DynamicsWorldModel.forward(latents=..., signal_levels=..., step_sizes=..., discrete_actions=...,
+ * time_cache=..., latent_is_noised=True, return_pred_only=True, return_intermediates=True)
+ * D4:6792-7295.  Evaluates `frames` new frames per trajectory (row order b, t):
+ *   latents        [batch][frames][n][dl]
+ *   signal_levels  [batch][frames] int32 in [0, max_steps)
+ *   prev_actions   [batch][frames][action_types] int64: the action token of each frame, i.e. the
+ *                  action taken at the previous frame; a negative first entry means "no action"
+ *                  (zero token, D4:7110-7126).  NULL = zero tokens everywhere.
+ *   tasks          [batch] int64 or NULL
+ *   use_cache      attend over the frames already in the KV cache (their count is the rotary offset)
+ *   commit_cache   keep the new frames' K/V in the cache (the "extra clean step" of D4:6545)
+ * Outputs: pred [batch][frames][n][dl], agent_embed [batch][frames][dim]. */
+int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_levels, int step_size,
+                  const int64_t* prev_actions, const int64_t* tasks, int batch, int frames,
+                  int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream);
+
+/* DynamicsWorldModel.generate(...) D4:6308-6774 with every random draw injected. */
+typedef struct d4_rollout_io {
+    int32_t batch;
+    int32_t time_steps;            /* total frames incl. prompt (while latents.shape[1] < time_steps) */
+    int32_t prompt_frames;         /* frames already present in `latents` (teacher forcing, D4:6392) */
+    int32_t num_steps;             /* denoising steps K (power of two) */
+    int32_t use_time_cache;        /* D4:6321 */
+    int32_t sample_terminals;      /* return_terminals && predict_terminals (D4:6454) */
+    int32_t sample_actions;        /* return_agent_actions (D4:6625): policy head + Gumbel sample + value head */
+    float context_signal_noise;    /* D4:6319 */
+    float discrete_temperature;
+    /* injected noise, one slice per generated frame f = 0 .. time_steps - prompt_frames - 1 */
+    const float* noise_latent;     /* [F][batch][n][dl] normal   (D4:6475) */
+    const float* noise_context;    /* [F][batch][n][dl] normal   (D4:6670); may be NULL when use_time_cache */
+    const float* gumbel_u;         /* [F][batch][A] uniform (0,1) (MultiCategorical.sample) */
+    const float* bern_u;           /* [F][batch] uniform         (D4:6611); NULL unless sample_terminals */
+    const int64_t* tasks;          /* [batch] or NULL */
+    /* in/out histories, time-major stride = time_steps; prompt entries pre-filled by the caller */
+    float* latents;                /* [batch][time_steps][n][dl]  (unclamped; caller clamps, D4:6686) */
+    int64_t* actions;              /* [batch][time_steps][action_types] */
+    float* rewards;                /* [batch][time_steps] */
+    float* ctx_hist;               /* [batch][time_steps][n][dl] fixed context noise per frame (prompt entries =
+                                      the prompt latents, D4:6400); NULL allowed when use_time_cache */
+    /* outputs for generated frames only, index = frame - prompt_frames, stride = F */
+    float* agent_embed;            /* [batch][F][dim] */
+    float* log_probs;              /* [batch][F][action_types] */
+    float* values;                 /* [batch][F] */
+    float* action_logits;          /* [batch][F][A]   (old_action_unembeds, D4:6749-6750) */
+    int64_t* lens;                 /* [batch]  pre-filled with time_steps */
+    uint8_t* terminals;            /* [batch]  pre-filled with 0 */
+} d4_rollout_io;
+
+int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream);
+
+/* DynamicsWorldModel.learn_from_experience(experience, only_learn_policy_value_heads=True,
+ * objective=...) D4:5893-6305 with stored agent embeds: losses AND gradients of the policy head
+ * (policy MLP + discrete_action_unembed) and the value head into the `grad` buffers given at bind. */
+typedef struct d4_learn_io {
+    int32_t batch, time;
+    int32_t objective;             /* 0 = ppo, 1 = spo, 2 = pmpo */
+    int32_t normalize_advantages;  /* -1 = default (objective != pmpo) */
+    float eps;                     /* z-score epsilon (1e-6, D4:5903) */
+    const float* agent_embed;      /* [batch][time][dim] */
+    const int64_t* actions;        /* [batch][time][action_types] */
+    const float* old_log_probs;    /* [batch][time][action_types] */
+    const float* old_values;       /* [batch][time] */
+    const float* rewards;          /* [batch][time] */
+    const float* old_action_logits;/* [batch][time][A] (pmpo KL) or NULL */
+    const int64_t* lens;           /* [batch] */
+    const uint8_t* is_truncated;   /* [batch] */
+    const uint8_t* terminals;      /* [batch] */
+    /* global-batch statistics for data parallel runs: host callback that sum-reduces `n` floats in
+     * place across ranks (NULL = single process).  Called on the host between kernel phases. */
+    int (*allreduce_sum)(float* device_buf, int n, void* user);
+    void* allreduce_user;
+    float* losses;                 /* device [2]: total_policy_loss, value_loss */
+    float* returns;                /* optional device [batch][time] */
+} d4_learn_io;
+
+int d4_learn(d4_engine* e, const d4_learn_io* io, void* stream);
+
+/* clip_grad_norm_(params, max_norm) + AdamW step over one parameter group (0 = policy head,
+ * 1 = value head), as DreamTrainer does (trainers.py:1436-1452).  `state` is caller-owned device
+ * memory of 2 * group_numel floats (exp_avg, exp_avg_sq), zero-initialised. */
+int64_t d4_group_numel(const d4_engine* e, int group);
+int d4_optim_step(d4_engine* e, int group, float* state, int step, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float max_grad_norm, float grad_scale,
+                  float* grad_norm_out, void* stream);
+
+/* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */
+int d4_debug_buffer(d4_engine* e, const char* name, float** ptr);
+
+/* ---- single-kernel entry points (parity tests call the same launchers the engine uses) ---- */
+int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+            const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
+int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
+               float eps, void* stream);
+int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,
+                       int bins, void* stream);
+int d4_gae(const float* rewards, const float* values, const int64_t* lens, const uint8_t* is_truncated,
+           const uint8_t* terminals, float gamma, float lam, int batch, int time, float* returns,
+           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D4HIP_H */

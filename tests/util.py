@@ -1,0 +1,73 @@
+"""Shared helpers for the parity tests: build a product model + the matching oracle inputs."""
+import torch
+
+from oracle.restate import Config
+
+
+def oracle_config(m) -> Config:
+    return Config(
+        dim=m.dim, dim_latent=m.dim_latent, num_latent_tokens=m.num_latent_tokens, depth=m.depth,
+        time_block_every=m.time_block_every, attn_heads=m.attn_heads, attn_dim_head=m.attn_dim_head,
+        attn_softclamp_value=m.attn_softclamp_value, num_spatial_tokens=m.num_spatial_tokens,
+        num_register_tokens=m.num_register_tokens, max_steps=m.max_steps, num_tasks=m.num_tasks,
+        num_discrete_actions=m.num_discrete_actions, multi_token_pred_len=m.multi_token_pred_len,
+        policy_head_mlp_depth=m.policy_head_mlp_depth, value_head_mlp_depth=m.value_head_mlp_depth,
+        terminal_mlp_depth=m.terminal_mlp_depth, predict_terminals=m.predict_terminals,
+        reward_range=m.reward_range, reward_num_bins=m.reward_num_bins, value_range=m.value_range,
+        value_num_bins=m.value_num_bins, gae_discount_factor=m.gae_discount_factor, gae_lambda=m.gae_lambda,
+        ppo_eps_clip=m.ppo_eps_clip, policy_entropy_weight=m.policy_entropy_weight,
+        use_delight_gating=m.use_delight_gating, delight_temperature=m.delight_temperature,
+        pmpo_pos_to_neg_weight=m.pmpo_pos_to_neg_weight, pmpo_reverse_kl=m.pmpo_reverse_kl,
+        pmpo_kl_div_loss_weight=m.pmpo_kl_div_loss_weight,
+    )
+
+
+@torch.no_grad()
+def randomize_weights(m, seed=0, unembed_scale=30., terminal_bias=-2.5):
+    """Default init leaves logits/values ~0 (unembed is randn*1e-2, dreamer4.py:1226): give every
+    norm / gamma / learned token / head a non-trivial value so each code path is numerically visible."""
+    g = torch.Generator().manual_seed(seed)
+    for name, p in m.named_parameters():
+        if p.numel() == 0:
+            continue
+        if name.endswith('gamma'):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        elif p.ndim == 1 and ('norm' in name or name.endswith('.0.weight')):
+            p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
+        elif name in ('register_tokens', 'agent_learned_embed', 'action_learned_embed') or name.endswith('queries'):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+        elif name == 'to_reward_pred.params.0':
+            p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
+        elif name == 'to_reward_pred.params.1':
+            p.mul_(5.)
+        elif name == 'action_embedder.discrete_action_unembed':
+            p.mul_(unembed_scale)
+    if m.predict_terminals:
+        last = m.terminal_mlp_depth + 1
+        getattr(m.to_state_terminal_pred, '0').layers._modules[str(last)]._modules['1'].bias.fill_(terminal_bias)
+    return m
+
+
+def oracle_weights(m):
+    W = {k: v.detach().cpu().float().clone() for k, v in m.state_dict().items()}
+    return W
+
+
+def make_noise(cfg: Config, frames, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    n, dl, A = cfg.num_latent_tokens, cfg.dim_latent, cfg.total_discrete_actions
+    return dict(
+        latent=torch.randn(frames, batch, n, dl, generator=g),
+        context=torch.randn(frames, batch, n, dl, generator=g),
+        gumbel_u=torch.rand(frames, batch, A, generator=g).clamp(1e-6, 1. - 1e-6),
+        bern_u=torch.rand(frames, batch, generator=g),
+    )
+
+
+def small_model(**over):
+    from dreamer4_amd import DynamicsWorldModel
+    kw = dict(dim=64, dim_latent=8, num_latent_tokens=6, depth=4, time_block_every=2, attn_heads=2,
+              num_discrete_actions=4, num_tasks=3)
+    kw.update(over)
+    torch.manual_seed(0)
+    return randomize_weights(DynamicsWorldModel(**kw))
