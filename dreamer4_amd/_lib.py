@@ -59,7 +59,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
 class LearnIO(C.Structure):
     _fields_ = [
         ('batch', C.c_int32), ('time', C.c_int32), ('objective', C.c_int32), ('normalize_advantages', C.c_int32),
-        ('eps', C.c_float),
+        ('eps', C.c_float), ('use_delight_gating', C.c_int32), ('delight_temperature', C.c_float),
         ('agent_embed', C.c_void_p), ('actions', C.c_void_p), ('old_log_probs', C.c_void_p), ('old_values', C.c_void_p),
         ('rewards', C.c_void_p), ('old_action_logits', C.c_void_p), ('lens', C.c_void_p), ('is_truncated', C.c_void_p),
         ('terminals', C.c_void_p),
@@ -86,8 +86,7 @@ SYMBOLS = {
     'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),
     'd4_learn': (_I, [_P, C.POINTER(LearnIO), _P]),
-    'd4_group_numel': (_L, [_P, _I]),
-    'd4_optim_step': (_I, [_P, _I, _P, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    'd4_adamw_clip': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
     'd4_debug_buffer': (_I, [_P, C.c_char_p, C.POINTER(_P)]),
     'd4_gemm': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'd4_rmsnorm': (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),

@@ -23,6 +23,19 @@ struct Mlp {              // normed MLP head: [RMSNorm -> Linear(+bias) -> SiLU]
     int dims[10];
     const float *g[9], *w[9], *b[9];
     float *dg[9], *dw[9], *db[9];       // gradient buffers (may be null)
+    // learner save area, per layer: x [R][din] | xhat [R][din] | z [R][ldz]; every block 256-byte aligned
+    static size_t al(size_t n) { return (n + 63) / 64 * 64; }
+    int ldz(int i) const { return (dims[i + 1] + 3) / 4 * 4; }
+    size_t save_floats(size_t R) const {
+        size_t t = 0;
+        for (int i = 0; i < nl; ++i) t += 2 * al(R * dims[i]) + al(R * (size_t)ldz(i));
+        return t;
+    }
+    void save_ptrs(float* base, size_t R, int i, float** x, float** xhat, float** z) const {
+        float* p = base;
+        for (int j = 0; j < i; ++j) p += 2 * al(R * dims[j]) + al(R * (size_t)ldz(j));
+        *x = p; *xhat = p + al(R * dims[i]); *z = *xhat + al(R * dims[i]);
+    }
 };
 
 }  // namespace d4
@@ -74,7 +87,7 @@ struct d4_engine {
     int LR = 0;
     float *l_save;                         // per-layer saved activations for both MLP heads
     float *l_tmp[3];
-    float *l_logits, *l_dlogits, *l_vbins, *l_dvbins, *l_returns, *l_adv, *l_scal;
+    float *l_logits, *l_dlogits, *l_vbins, *l_dvbins, *l_returns, *l_adv, *l_scal, *l_mask, *l_rows, *l_dpe;
 };
 
 namespace d4 {
@@ -86,8 +99,5 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
 int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, float* out, int ldo,
                 float* save, hipStream_t s);
 int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s);
-int optim_step(d4_engine* e, int group, float* state, int step, float lr, float b1, float b2, float eps,
-               float wd, float max_norm, float grad_scale, float* norm_out, hipStream_t s);
-int64_t group_numel(const d4_engine* e, int group);
 const char* last_error();
 }  // namespace d4

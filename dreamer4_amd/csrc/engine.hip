@@ -105,17 +105,17 @@ int engine_layout(d4_engine* e, bool assign) {
     if (e->LR > 0) {
         const size_t R = e->LR;
         // saved per layer: x (input), xhat (normalised * gamma input of the linear), z (pre-activation)
-        size_t save = 0;
-        for (const Mlp* m : {&e->policy, &e->value})
-            for (int i = 0; i < m->nl; ++i) save += R * (2 * (size_t)m->dims[i] + (size_t)m->dims[i + 1]) + R;
-        e->l_save = fl(save);
+        e->l_save = fl(e->policy.save_floats(R) + e->value.save_floats(R));
         for (int i = 0; i < 3; ++i) e->l_tmp[i] = fl(R * maxdim);
-        e->l_logits = fl(R * (e->A > 0 ? e->A : 1));
-        e->l_dlogits = fl(R * (e->A > 0 ? e->A : 1));
-        e->l_vbins = fl(R * c.value_num_bins);
-        e->l_dvbins = fl(R * c.value_num_bins);
+        e->l_logits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
+        e->l_dlogits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
+        e->l_vbins = fl(R * (size_t)((c.value_num_bins + 3) / 4 * 4));
+        e->l_dvbins = fl(R * (size_t)((c.value_num_bins + 3) / 4 * 4));
         e->l_returns = fl(R);
         e->l_adv = fl(R);
+        e->l_mask = fl(R);
+        e->l_rows = fl(4 * R);
+        e->l_dpe = fl(R * 4 * (size_t)D);
         e->l_scal = fl(64);
     }
     e->ws_need = off + 256;
@@ -478,15 +478,22 @@ int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, f
         float* y = last ? out : e->hbuf[i & 1];
         int ldy = last ? ldo : dout;
         if (save) {
-            // learner path: keep x, xhat and the pre-activation
-            float* sx = save; float* sxh = sx + (size_t)rows * din; float* sz = sxh + (size_t)rows * din;
-            save = sz + (size_t)rows * dout + rows;
-            if ((rc = copy_rows(cur, ld, sx, din, rows, din, s))) return rc;
-            xhat = sxh;
-            if ((rc = rmsnorm_rows(cur, ld, m.g[i], xhat, din, rows, din, RMS_EPS, s))) return rc;
-            if ((rc = gemm_simple(xhat, din, m.w[i], din, sz, dout, rows, dout, din, 0, m.b[i], nullptr, 0, s))) return rc;
-            if (last) { if ((rc = copy_rows(sz, dout, y, ldy, rows, dout, s))) return rc; }
-            else if ((rc = silu_rows(sz, y, (int64_t)rows * dout, s))) return rc;
+            // learner path (rows may exceed max_batch: only the save area is used, never hbuf / hnorm):
+            // x_i -> sx[i], xhat_i -> sxh[i], pre-activation -> sz[i]; silu(z_i) is written straight into sx[i+1].
+            float *sx, *sxh, *sz;
+            m.save_ptrs(save, rows, i, &sx, &sxh, &sz);
+            const int ldz = m.ldz(i);
+            if (i == 0 && (rc = copy_rows(x, ldx, sx, din, rows, din, s))) return rc;
+            if ((rc = rmsnorm_rows(sx, din, m.g[i], sxh, din, rows, din, RMS_EPS, s))) return rc;
+            if (ldz != dout && (rc = fill_f32(sz, 0.f, (int64_t)rows * ldz, s))) return rc;
+            if ((rc = gemm_simple(sxh, din, m.w[i], din, sz, ldz, rows, dout, din, 0, m.b[i], nullptr, 0, s))) return rc;
+            if (last) { if ((rc = copy_rows(sz, ldz, out, ldo, rows, dout, s))) return rc; }
+            else {
+                float *nx, *nxh, *nz;
+                m.save_ptrs(save, rows, i + 1, &nx, &nxh, &nz);
+                if ((rc = silu_rows(sz, nx, (int64_t)rows * dout, s))) return rc;
+            }
+            continue;
         } else {
             if ((rc = rmsnorm_rows(cur, ld, m.g[i], xhat, din, rows, din, RMS_EPS, s))) return rc;
             if ((rc = gemm_simple(xhat, din, m.w[i], din, y, ldy, rows, dout, din, last ? 0 : GEMM_SILU, m.b[i], nullptr, 0, s))) return rc;
@@ -750,16 +757,6 @@ int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
 int d4_learn(d4_engine* e, const d4_learn_io* io, void* stream) {
     D4_REQUIRE(e && io, "null argument");
     return d4::learn(e, io, static_cast<hipStream_t>(stream));
-}
-
-int64_t d4_group_numel(const d4_engine* e, int group) { return d4::group_numel(e, group); }
-
-int d4_optim_step(d4_engine* e, int group, float* state, int step, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float max_grad_norm, float grad_scale,
-                  float* grad_norm_out, void* stream) {
-    D4_REQUIRE(e && state, "null argument");
-    return d4::optim_step(e, group, state, step, lr, beta1, beta2, eps, weight_decay, max_grad_norm, grad_scale,
-                          grad_norm_out, static_cast<hipStream_t>(stream));
 }
 
 int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,

@@ -1,8 +1,507 @@
+// Actor / critic learner: reference DynamicsWorldModel.learn_from_experience with
+// only_learn_policy_value_heads=True and stored agent embeddings (D4:5893-6305), forward AND
+// backward, plus the clipped AdamW step DreamTrainer applies (trainers.py:1436-1452).
+//
+//   calc_gae (D4:1566-1600) -> masked z-score (D4:404-410, 6024) -> policy MLP + unembed head 0 ->
+//   log-prob / entropy (D4:1422-1426) -> PPO / SPO / PMPO surrogate with delight gating
+//   (D4:6119-6242) ;  value MLP -> HL-Gauss cross entropy against transform_to_probs(returns)
+//   (D4:6268-6295).
+//
+// The reference builds these losses from ~40 elementwise ATen ops and lets autograd derive the
+// gradients; here each loss has one fused forward+backward kernel and the MLP backward is explicit
+// (GEMMs on the MFMA kernel in its transposed-operand modes, deterministic column reductions).
+// Every reduction has a fixed order: results are bitwise reproducible run to run.
 #include "common.h"
 #include "engine.h"
+#include <float.h>
+#include <math.h>
+
 namespace d4 {
-int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) { D4_REQUIRE(false, "learn: not built yet"); }
-int optim_step(d4_engine*, int, float*, int, float, float, float, float, float, float, float, float*, hipStream_t) { D4_REQUIRE(false, "optim: not built yet"); }
-int64_t group_numel(const d4_engine*, int) { return 0; }
+
+static constexpr float RMS_EPS_L = 1.1920928955078125e-07f;
+
+// ------------------------------------------------------------------------------------ GAE
+// one thread per trajectory: masks (D4:5943-5967) + reverse recurrence
+__global__ void gae_kernel(const float* rewards, const float* values, const int64_t* lens, const uint8_t* is_truncated,
+                           const uint8_t* terminals, float gamma, float lam, int B, int T,
+                           float* returns, float* adv, float* mask) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int len = lens ? (int)lens[b] : T;
+    const int trunc = is_truncated ? (is_truncated[b] != 0) : 1;
+    const int term = terminals ? (terminals[b] != 0) : 0;
+    const int learn_len = len - trunc;
+    const int last = len - 1 > 0 ? len - 1 : 0;
+    float g = 0.f, v_next = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const bool in_len = t < len;
+        const float r = in_len ? rewards[(int64_t)b * T + t] : 0.f;
+        const float v = in_len ? values[(int64_t)b * T + t] : 0.f;
+        bool cont = t < last;
+        if (term && t == last) cont = false;
+        const float m = cont ? 1.f : 0.f;
+        const bool learn = t < learn_len;
+        float delta = r + gamma * v_next * m - v;
+        if (!learn) delta = 0.f;
+        g = (gamma * lam * m) * g + delta;
+        const float ret = g + v;
+        returns[(int64_t)b * T + t] = ret;
+        if (adv) adv[(int64_t)b * T + t] = ret - v;
+        if (mask) mask[(int64_t)b * T + t] = learn ? 1.f : 0.f;
+        v_next = v;
+    }
 }
-extern "C" int d4_gae(const float*, const float*, const int64_t*, const uint8_t*, const uint8_t*, float, float, int, int, float*, void*) { return 9; }
+
+// ------------------------------------------------------------------------------------ deterministic reductions
+// out[slot] = sum_i f(a[i], b[i]) with one 1024-thread block (fixed tree order).
+enum { RED_PROD = 0, RED_SQDIFF_MASKED = 1, RED_SUM = 2 };
+template <int MODE>
+__global__ __launch_bounds__(1024) void reduce1_kernel(const float* a, const float* b, const float* scal, int64_t n, float* out) {
+    __shared__ float sh[1024];
+    float s = 0.f;
+    float mean = 0.f;
+    if (MODE == RED_SQDIFF_MASKED) mean = scal[0] / fmaxf(scal[1], 1.f);
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        if (MODE == RED_PROD) s += a[i] * b[i];
+        else if (MODE == RED_SUM) s += a[i];
+        else { float d = a[i] - mean; s += d * d * b[i]; }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+// column sums: out[c] = sum_r x[r][c]; block = 64 columns x 16 row lanes, fixed order
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int ld, int rows, int cols, float* out) {
+    __shared__ float sh[16][65];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 16) s += x[(int64_t)r * ld + c];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += sh[i][threadIdx.x & 63];
+        out[c] = t;
+    }
+}
+static int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, s, x, ld, rows, cols, out);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ policy loss fwd + bwd
+struct PolicyLossArgs {
+    const float* logits; int ld;        // [R][Apad]
+    const int64_t* actions;             // [R][na]
+    const float* old_lp;                // [R][na]
+    const float* old_logits; int ldo;   // [R][A] (pmpo) or null
+    const float* adv_raw;               // [R]
+    const float* mask;                  // [R]
+    const float* scal;                  // stats: [0] sum adv*mask, [1] count, [2] sum sq diff
+    const int32_t* action_sizes;
+    float* dlogits;                     // [R][Apad]
+    float* row_pl; float* row_ent; float* row_aux;   // per-row masked terms
+    int R, na, A, objective, normalize, use_gate, reverse_kl;
+    float eps, clip, ent_w, gate_temp, pmpo_alpha, kl_w;
+};
+
+__global__ void policy_loss_kernel(PolicyLossArgs p) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.R) return;
+    const float count = fmaxf(p.scal[1], 1.f);
+    const float mk = p.mask[r];
+    float adv = p.adv_raw[r];
+    if (p.normalize) {
+        const float mean = p.scal[0] / count;
+        const float var = p.scal[2] / count;
+        adv = (adv - mean) / sqrtf(fmaxf(var, p.eps));
+    }
+    const float* lg = p.logits + (int64_t)r * p.ld;
+    float* dl = p.dlogits + (int64_t)r * p.ld;
+    // pass 1: joint log-prob, entropy
+    float lp = 0.f, old = 0.f, ent = 0.f;
+    int o = 0;
+    for (int a = 0; a < p.na; ++a) {
+        const int n = p.action_sizes[a];
+        float mx = -FLT_MAX;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, lg[o + j]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += expf(lg[o + j] - mx);
+        const float lse = mx + logf(se);
+        const int act = (int)p.actions[(int64_t)r * p.na + a];
+        lp += lg[o + act] - lse;
+        old += p.old_lp[(int64_t)r * p.na + a];
+        float h = 0.f;
+        for (int j = 0; j < n; ++j) { const float l = lg[o + j] - lse; h -= expf(l) * l; }
+        ent += h;
+        o += n;
+    }
+    const float gate = p.use_gate ? sigmoidf(-lp * adv / p.gate_temp) : 1.f;
+    float pl = 0.f, dpl_dlp = 0.f, aux = 0.f;
+    if (p.objective == 0) {             // ppo  D4:6204-6212
+        const float ratio = expf(lp - old);
+        const float cr = fminf(fmaxf(ratio, 1.f - p.clip), 1.f + p.clip);
+        const float s1 = ratio * adv, s2 = cr * adv;
+        pl = -fminf(s1, s2) * gate;
+        const bool inside = ratio >= 1.f - p.clip && ratio <= 1.f + p.clip;
+        const float dmin = (s1 < s2 || (s1 == s2 && inside)) ? s1 : ((s1 == s2) ? 0.5f * s1 : 0.f);
+        dpl_dlp = -dmin * gate;
+    } else if (p.objective == 1) {      // spo  D4:6188-6198
+        const float ratio = expf(lp - old);
+        const float q = fabsf(adv) * (ratio - 1.f) / p.clip;
+        pl = -(ratio * adv - fabsf(adv) * (ratio - 1.f) * (ratio - 1.f) / (2.f * p.clip)) * gate;
+        dpl_dlp = -(ratio * adv - q * ratio) * gate;
+    } else {                            // pmpo D4:6127-6154
+        const float w = fabsf(tanhf(adv)) * gate;
+        const float sgn = adv >= 0.f ? 1.f : -1.f;
+        pl = -p.pmpo_alpha * sgn * lp * w;              // summed / num below (mask applied there)
+        dpl_dlp = -p.pmpo_alpha * sgn * w;
+    }
+    // pass 2: gradients wrt logits
+    const float scale = mk / count;
+    o = 0;
+    for (int a = 0; a < p.na; ++a) {
+        const int n = p.action_sizes[a];
+        float mx = -FLT_MAX;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, lg[o + j]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += expf(lg[o + j] - mx);
+        const float lse = mx + logf(se);
+        const int act = (int)p.actions[(int64_t)r * p.na + a];
+        float h = 0.f;
+        for (int j = 0; j < n; ++j) { const float l = lg[o + j] - lse; h -= expf(l) * l; }
+        float kl = 0.f, lse_o = 0.f;
+        if (p.objective == 2 && p.kl_w > 0.f && p.old_logits) {
+            const float* og = p.old_logits + (int64_t)r * p.ldo;
+            float mo = -FLT_MAX;
+            for (int j = 0; j < n; ++j) mo = fmaxf(mo, og[o + j]);
+            float so = 0.f;
+            for (int j = 0; j < n; ++j) so += expf(og[o + j] - mo);
+            lse_o = mo + logf(so);
+            for (int j = 0; j < n; ++j) {
+                const float ln = lg[o + j] - lse, lo = og[o + j] - lse_o;
+                kl += p.reverse_kl ? expf(lo) * (lo - ln) : expf(ln) * (ln - lo);
+            }
+            aux += kl;
+        }
+        for (int j = 0; j < n; ++j) {
+            const float l = lg[o + j] - lse;
+            const float pj = expf(l);
+            float g = dpl_dlp * ((j == act ? 1.f : 0.f) - pj);          // d lp / d logit
+            g += p.ent_w * pj * (l + h);                                  // d(-H)/d logit
+            if (p.objective == 2 && p.kl_w > 0.f && p.old_logits) {
+                const float lo = p.old_logits[(int64_t)r * p.ldo + o + j] - lse_o;
+                g += p.kl_w * (p.reverse_kl ? (pj - expf(lo)) : pj * ((l - lo) - kl));
+            }
+            dl[o + j] = g * scale;
+        }
+        o += n;
+    }
+    for (int j = p.A; j < p.ld; ++j) dl[j] = 0.f;
+    p.row_pl[r] = pl * mk;
+    p.row_ent[r] = -ent * mk;
+    p.row_aux[r] = aux * mk;
+}
+
+// ------------------------------------------------------------------------------------ value loss fwd + bwd
+// one wave per row: HL-Gauss target probs (erf), CE against log_softmax(value bins)
+__global__ __launch_bounds__(256) void value_loss_kernel(const float* vbins, int ld, const float* returns, const float* mask,
+                                                         const float* scal, const float* support, int R, int bins,
+                                                         float sigma_sqrt2, float hl_eps, float vmin, float vmax,
+                                                         float* dv, float* row_loss) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float count = fmaxf(scal[1], 1.f);
+    const float mk = mask[r];
+    const float* v = vbins + (int64_t)r * ld;
+    float ret = fminf(fmaxf(returns[r], vmin), vmax);
+    const float z = erff((support[bins] - ret) / sigma_sqrt2) - erff((support[0] - ret) / sigma_sqrt2);
+    const float zc = fmaxf(z, hl_eps);
+    float mx = -FLT_MAX;
+    for (int c = lane; c < bins; c += 64) mx = fmaxf(mx, v[c]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int c = lane; c < bins; c += 64) se += expf(v[c] - mx);
+    const float lse = mx + logf(wave_sum(se));
+    float loss = 0.f, psum = 0.f;
+    for (int c = lane; c < bins; c += 64) {
+        const float pr = (erff((support[c + 1] - ret) / sigma_sqrt2) - erff((support[c] - ret) / sigma_sqrt2)) / zc;
+        loss -= pr * (v[c] - lse);
+        psum += pr;
+    }
+    loss = wave_sum(loss);
+    psum = wave_sum(psum);
+    const float scale = mk / count;
+    for (int c = lane; c < bins; c += 64) {
+        const float pr = (erff((support[c + 1] - ret) / sigma_sqrt2) - erff((support[c] - ret) / sigma_sqrt2)) / zc;
+        dv[(int64_t)r * ld + c] = (expf(v[c] - lse) * psum - pr) * scale;
+    }
+    for (int c = bins + lane; c < ld; c += 64) dv[(int64_t)r * ld + c] = 0.f;
+    if (lane == 0) row_loss[r] = loss * mk;
+}
+
+__global__ void finalize_losses_kernel(const float* scal, float* losses, int objective, float ent_w, float kl_w) {
+    // scal: [1] count, [4] sum pl, [5] sum ent, [6] sum aux(kl), [7] sum value loss
+    const float count = fmaxf(scal[1], 1.f);
+    float pl = scal[4] / count;
+    if (objective == 2) pl += kl_w * scal[6] / count;
+    losses[0] = pl + ent_w * scal[5] / count;
+    losses[1] = scal[7] / count;
+}
+
+// ------------------------------------------------------------------------------------ MLP backward pieces
+__global__ void silu_bwd_kernel(const float* dy, const float* z, float* dz, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = sigmoidf(z[i]);
+        dz[i] = dy[i] * s * (1.f + z[i] * (1.f - s));
+    }
+}
+
+// RMSNorm backward, one wave per row:  xhat = x * rstd * gamma
+//   tg[r][k] = dxhat * x * rstd   (column-summed afterwards -> dgamma)
+//   dx[r][k] = rstd * (gamma * dxhat - x * rstd^2 * mean_k(gamma * dxhat * x))
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* x, const float* dxhat, const float* gamma, float* tg, float* dx,
+                                                          int rows, int d, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)r * d;
+    const float* gr = dxhat + (int64_t)r * d;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < d; c += 64) { const float v = xr[c]; ss += v * v; dot += gamma[c] * gr[c] * v; }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    dot = wave_sum(dot) / (float)d;
+    for (int c = lane; c < d; c += 64) {
+        const float v = xr[c], g = gr[c];
+        tg[(int64_t)r * d + c] = g * v * rstd;
+        if (dx) dx[(int64_t)r * d + c] = rstd * (gamma[c] * g - v * rstd * rstd * dot);
+    }
+}
+
+static inline dim3 grid1d(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return dim3((unsigned)g);
+}
+
+static int gemm_l(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, C, ldc, nullptr, nullptr, 0, M, N, K, flags, 0.f};
+    return gemm(g, s);
+}
+
+// Backward of mlp_forward(save=...).  dout: [R][dims[nl]] gradient of the (un-activated) output.
+static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, const float* dout, int ld_dout, hipStream_t s) {
+    int rc;
+    float* sx[9]; float* sxh[9]; float* sz[9];
+    for (int i = 0; i < m.nl; ++i) m.save_ptrs(const_cast<float*>(save), R, i, &sx[i], &sxh[i], &sz[i]);
+    float* dy = e->l_tmp[0]; float* dz = e->l_tmp[1]; float* dxh = e->l_tmp[2];
+    const float* cur = dout;
+    for (int i = m.nl - 1; i >= 0; --i) {
+        const int din = m.dims[i], dout_i = m.dims[i + 1];
+        const float* dzp;
+        int ldd = dout_i;
+        if (i == m.nl - 1) { dzp = cur; ldd = ld_dout; }
+        else {
+            hipLaunchKernelGGL(silu_bwd_kernel, grid1d((int64_t)R * dout_i), dim3(256), 0, s, cur, sz[i], dz, (int64_t)R * dout_i);
+            D4_LAUNCH_CHECK();
+            dzp = dz;
+        }
+        D4_REQUIRE(m.db[i] && m.dw[i] && m.dg[i], "learner: head parameters were bound without gradient buffers");
+        if ((rc = colsum(dzp, ldd, R, dout_i, m.db[i], s))) return rc;
+        // dW[n][k] = sum_r dz[r][n] * xhat[r][k]
+        if ((rc = gemm_l(dzp, ldd, sxh[i], din, m.dw[i], din, dout_i, din, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        // dxhat[r][k] = sum_n dz[r][n] * W[n][k]
+        if ((rc = gemm_l(dzp, ldd, m.w[i], din, dxh, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
+        // through the RMSNorm; dy of the previous layer overwrites e->l_tmp[0]; tg reuses dz (dz is dead after the GEMMs)
+        float* tg = dz;
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, sx[i], dxh, m.g[i], tg, i > 0 ? dy : nullptr, R, din, RMS_EPS_L);
+        D4_LAUNCH_CHECK();
+        if ((rc = colsum(tg, din, R, din, m.dg[i], s))) return rc;
+        cur = dy;
+    }
+    return 0;
+}
+
+int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
+    const d4_config& c = e->c;
+    D4_REQUIRE(e->prepared, "engine not prepared");
+    const int B = io->batch, T = io->time, R = B * T;
+    D4_REQUIRE(R > 0 && R <= e->LR, "learn: %d rows exceed max_learn_rows %d", R, e->LR);
+    D4_REQUIRE(io->agent_embed && io->actions && io->old_log_probs && io->old_values && io->rewards && io->losses,
+               "the generations need to contain the log probs, values, and rewards for policy optimization  [D4:5935]");
+    D4_REQUIRE(io->objective >= 0 && io->objective <= 2, "unknown objective %d  [D4:6215]", io->objective);
+    const int D = e->D, A = e->A, Apad = (A + 3) / 4 * 4, na = e->na;
+    int rc;
+    float* scal = e->l_scal;
+    D4_HIP(hipMemsetAsync(scal, 0, 64 * sizeof(float), s));
+
+    // ---- returns, advantages, masks
+    float* row_a = e->l_adv;                        // raw advantage [R]
+    float* mask_keep = e->l_mask;                   // learnable-step mask [R]
+    hipLaunchKernelGGL(gae_kernel, dim3(cdiv(B, 128)), dim3(128), 0, s, io->rewards, io->old_values, io->lens, io->is_truncated,
+                       io->terminals, c.gae_discount_factor, c.gae_lambda, B, T, e->l_returns, row_a, mask_keep);
+    D4_LAUNCH_CHECK();
+    if (io->returns) D4_HIP(hipMemcpyAsync(io->returns, e->l_returns, sizeof(float) * R, hipMemcpyDeviceToDevice, s));
+
+    hipLaunchKernelGGL(reduce1_kernel<RED_PROD>, dim3(1), dim3(1024), 0, s, row_a, mask_keep, scal, (int64_t)R, scal + 0);
+    hipLaunchKernelGGL(reduce1_kernel<RED_SUM>, dim3(1), dim3(1024), 0, s, mask_keep, nullptr, scal, (int64_t)R, scal + 1);
+    D4_LAUNCH_CHECK();
+    if (io->allreduce_sum && (rc = io->allreduce_sum(scal, 2, io->allreduce_user))) { set_error("allreduce callback failed (%d)", rc); return 5; }
+    hipLaunchKernelGGL(reduce1_kernel<RED_SQDIFF_MASKED>, dim3(1), dim3(1024), 0, s, row_a, mask_keep, scal, (int64_t)R, scal + 2);
+    D4_LAUNCH_CHECK();
+    if (io->allreduce_sum && (rc = io->allreduce_sum(scal + 2, 1, io->allreduce_user))) { set_error("allreduce callback failed (%d)", rc); return 5; }
+
+    const int normalize = io->normalize_advantages < 0 ? (io->objective != 2) : io->normalize_advantages;
+
+    // ---- policy head forward (saved), logits of prediction head 0
+    float* save_p = e->l_save;
+    float* save_v = e->l_save + e->policy.save_floats(R);
+    float* pe = e->l_tmp[0];
+    if ((rc = mlp_forward(e, e->policy, io->agent_embed, D, R, pe, 4 * D, save_p, s))) return rc;
+    if ((rc = fill_f32(e->l_logits, 0.f, (int64_t)R * Apad, s))) return rc;
+    {
+        GemmArgs g{pe, 4 * D, e->action_unembed, c.multi_token_pred_len * 4 * D, e->l_logits, Apad, nullptr, nullptr, 0, R, A, 4 * D, 0, 0.f};
+        if ((rc = gemm(g, s))) return rc;
+    }
+    float* row_pl = e->l_rows, *row_ent = e->l_rows + R, *row_aux = e->l_rows + 2 * R, *row_vl = e->l_rows + 3 * R;
+    {
+        PolicyLossArgs p{};
+        p.logits = e->l_logits; p.ld = Apad; p.actions = io->actions; p.old_lp = io->old_log_probs;
+        p.old_logits = io->old_action_logits; p.ldo = A; p.adv_raw = row_a; p.mask = mask_keep; p.scal = scal;
+        p.action_sizes = e->action_sizes; p.dlogits = e->l_dlogits; p.row_pl = row_pl; p.row_ent = row_ent; p.row_aux = row_aux;
+        p.R = R; p.na = na; p.A = A; p.objective = io->objective; p.normalize = normalize;
+        p.use_gate = io->use_delight_gating < 0 ? c.use_delight_gating : io->use_delight_gating;
+        p.reverse_kl = c.pmpo_reverse_kl;
+        p.eps = io->eps; p.clip = c.ppo_eps_clip; p.ent_w = c.policy_entropy_weight;
+        p.gate_temp = io->delight_temperature > 0.f ? io->delight_temperature : c.delight_temperature;
+        p.pmpo_alpha = c.pmpo_pos_to_neg_weight;
+        p.kl_w = io->objective == 2 ? c.pmpo_kl_div_loss_weight : 0.f;
+        D4_REQUIRE(!(p.kl_w > 0.f) || io->old_action_logits, "pmpo with a KL weight needs old_action_unembeds  [D4:6160-6170]");
+        hipLaunchKernelGGL(policy_loss_kernel, dim3(cdiv(R, 128)), dim3(128), 0, s, p);
+        D4_LAUNCH_CHECK();
+    }
+    // ---- value head forward (saved) + HL-Gauss cross entropy
+    const int vld = (c.value_num_bins + 3) / 4 * 4;
+    if ((rc = mlp_forward(e, e->value, io->agent_embed, D, R, e->l_vbins, vld, save_v, s))) return rc;
+    {
+        const float sigma = c.hl_gauss_sigma_to_bin_ratio * (c.value_max - c.value_min) / (float)c.value_num_bins;
+        hipLaunchKernelGGL(value_loss_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, e->l_vbins, vld, e->l_returns, mask_keep, scal,
+                           e->value_support, R, c.value_num_bins, sqrtf(2.f) * sigma, c.hl_gauss_eps, c.value_min, c.value_max,
+                           e->l_dvbins, row_vl);
+        D4_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(reduce1_kernel<RED_SUM>, dim3(1), dim3(1024), 0, s, row_pl, nullptr, scal, (int64_t)R, scal + 4);
+    hipLaunchKernelGGL(reduce1_kernel<RED_SUM>, dim3(1), dim3(1024), 0, s, row_ent, nullptr, scal, (int64_t)R, scal + 5);
+    hipLaunchKernelGGL(reduce1_kernel<RED_SUM>, dim3(1), dim3(1024), 0, s, row_aux, nullptr, scal, (int64_t)R, scal + 6);
+    hipLaunchKernelGGL(reduce1_kernel<RED_SUM>, dim3(1), dim3(1024), 0, s, row_vl, nullptr, scal, (int64_t)R, scal + 7);
+    D4_LAUNCH_CHECK();
+    if (io->allreduce_sum && (rc = io->allreduce_sum(scal + 4, 4, io->allreduce_user))) { set_error("allreduce callback failed (%d)", rc); return 5; }
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1), 0, s, scal, io->losses, io->objective, c.policy_entropy_weight,
+                       io->objective == 2 ? c.pmpo_kl_div_loss_weight : 0.f);
+    D4_LAUNCH_CHECK();
+
+    // ---- backward: unembed head 0, policy MLP, value MLP
+    D4_REQUIRE(e->action_unembed_grad, "learner: discrete_action_unembed was bound without a gradient buffer");
+    const int mtp4d = c.multi_token_pred_len * 4 * D;
+    if ((rc = fill_f32(e->action_unembed_grad, 0.f, (int64_t)A * mtp4d, s))) return rc;
+    // pe (policy MLP output) was saved as the last layer's z
+    float *pe_x, *pe_xh, *pe_saved;
+    e->policy.save_ptrs(save_p, R, e->policy.nl - 1, &pe_x, &pe_xh, &pe_saved);
+    // dU0[a][k] = sum_r dlogits[r][a] * pe[r][k]
+    if ((rc = gemm_l(e->l_dlogits, Apad, pe_saved, 4 * D, e->action_unembed_grad, mtp4d, A, 4 * D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    // dpe[r][k] = sum_a dlogits[r][a] * U0[a][k]      (K = Apad; pad rows of U0 are never read: mask K to A)
+    float* dpe = e->l_dpe;
+    if ((rc = gemm_l(e->l_dlogits, Apad, e->action_unembed, mtp4d, dpe, 4 * D, R, 4 * D, A, GEMM_TRANS_B, s))) return rc;
+    if ((rc = mlp_backward(e, e->policy, save_p, R, dpe, 4 * D, s))) return rc;
+    if ((rc = mlp_backward(e, e->value, save_v, R, e->l_dvbins, vld, s))) return rc;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ clip_grad_norm_ + AdamW
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, int64_t n, float* partial) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void norm_final_kernel(const float* partial, int np, float grad_scale, float* norm_out) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *norm_out = sqrtf(sh[0]) * grad_scale;
+}
+
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n, const float* norm, float max_norm,
+                             float grad_scale, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+    float coef = grad_scale;
+    if (max_norm > 0.f) {
+        const float c = max_norm / (*norm + 1e-6f);           // torch.nn.utils.clip_grad_norm_
+        coef *= c < 1.f ? c : 1.f;
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+}  // namespace d4
+
+extern "C" {
+
+int d4_gae(const float* rewards, const float* values, const int64_t* lens, const uint8_t* is_truncated,
+           const uint8_t* terminals, float gamma, float lam, int batch, int time, float* returns, void* stream) {
+    D4_REQUIRE(rewards && values && returns, "null argument");
+    hipLaunchKernelGGL(d4::gae_kernel, dim3(d4::cdiv(batch, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), rewards, values, lens,
+                       is_truncated, terminals, gamma, lam, batch, time, returns, (float*)nullptr, (float*)nullptr);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// clip_grad_norm_(params, max_norm) followed by one AdamW step on a flat parameter group
+// (trainers.py:1436-1452; torch.optim.AdamW semantics).  scratch: >= 1025 floats.
+int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                  float grad_scale, float* scratch, void* stream) {
+    D4_REQUIRE(params && grads && exp_avg && exp_avg_sq && scratch && n > 0 && step >= 1, "adamw: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int np = 1024;
+    hipLaunchKernelGGL(d4::sumsq_partial_kernel, dim3(np), dim3(256), 0, s, grads, n, scratch + 1);
+    hipLaunchKernelGGL(d4::norm_final_kernel, dim3(1), dim3(256), 0, s, scratch + 1, np, grad_scale, scratch);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(d4::adamw_kernel, dim3((unsigned)g), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, scratch, max_grad_norm,
+                       grad_scale, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

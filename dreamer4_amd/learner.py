@@ -1,2 +1,128 @@
-def learn(*a, **k):
-    raise NotImplementedError
+"""Host side of learn_from_experience (reference dreamer4.py:5893-6305): marshal the Experience into
+the d4_learn C call, bridge the natively computed gradients into autograd, optional optimiser step."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from dreamer4_amd import _lib
+from dreamer4_amd.experience import Experience
+from dreamer4_amd import parallel
+
+_OBJECTIVES = dict(ppo=0, spo=1, pmpo=2)
+
+
+class _NativeLoss(torch.autograd.Function):
+    """Scalar loss whose gradient w.r.t. a head's parameters was already computed by the HIP learner."""
+
+    @staticmethod
+    def forward(ctx, loss, grad_flat, *params):
+        ctx.grad_flat = grad_flat
+        ctx.shapes = [p.shape for p in params]
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            out.append(ctx.grad_flat[off:off + n].view(shp) * g)
+            off += n
+        return (None, None, *out)
+
+
+def run_learner(model, experience: Experience, objective='ppo', use_delight_gating=None, delight_temperature=None,
+                normalize_advantages=None, eps=1e-6, process_group=None, stats='global', want_returns=False):
+    """Runs d4_learn: returns (losses[2] device tensor, returns or None).  Head gradients land in the
+    per-group flat gradient buffers (model._groups[...]['grad'])."""
+    assert isinstance(experience, Experience)
+    if objective not in _OBJECTIVES:
+        raise ValueError(f'unknown objective {objective}')
+    dev = model.device
+    exp = experience.to(dev)
+    if exp.agent_embed is None:
+        raise NotImplementedError('learn_from_experience needs the agent embeddings stored by generate(store_agent_embed=True); '
+                                  're-running the trunk (dreamer4.py:6045-6070) is not implemented')
+    assert all(v is not None for v in (exp.log_probs, exp.actions, exp.values, exp.rewards, exp.step_size)), \
+        'the generations need to contain the log probs, values, and rewards for policy optimization'
+    agent = exp.agent_embed.float().contiguous()
+    B, T = agent.shape[:2]
+    na = len(model.num_discrete_actions)
+
+    def bt(t, trailing=()):          # align histories that include a prompt part to the generated part
+        t = t[:, -T:] if t.shape[1] > T else t
+        assert t.shape[:2] == (B, T), f'experience field of shape {tuple(t.shape)} does not match agent_embed {(B, T)}'
+        return t.contiguous()
+
+    actions = exp.actions.discrete
+    actions = actions[..., None] if actions.ndim == 2 else actions
+    actions = bt(actions).long()
+    old_lp = bt(exp.log_probs.discrete.float().reshape(B, -1, na))
+    old_values = bt(exp.values.float())
+    rewards = bt(exp.rewards.float())
+    old_logits = None
+    if exp.old_action_unembeds is not None and exp.old_action_unembeds.discrete is not None:
+        old_logits = bt(exp.old_action_unembeds.discrete.float())
+    prompt_off = exp.latents.shape[1] - T if exp.latents is not None else 0
+    lens = exp.lens.long() - prompt_off if exp.lens is not None else torch.full((B,), T, device=dev)
+    lens = lens.contiguous()
+    trunc = (exp.is_truncated if exp.is_truncated is not None else torch.ones(B, dtype=torch.bool, device=dev))
+    trunc = trunc.to(torch.uint8).contiguous()
+    terms = exp.terminals.to(torch.uint8).contiguous() if exp.terminals is not None else None
+
+    model._ensure_engine(learn_rows=B * T)
+    lib = _lib.load()
+    losses = torch.zeros(2, device=dev)
+    returns = torch.empty(B, T, device=dev) if want_returns else None
+
+    io = _lib.LearnIO()
+    io.batch, io.time, io.objective = B, T, _OBJECTIVES[objective]
+    na_flag = normalize_advantages if normalize_advantages is not None else model.normalize_advantages
+    io.normalize_advantages = -1 if na_flag is None else int(bool(na_flag))
+    io.eps = eps
+    io.use_delight_gating = -1 if use_delight_gating is None else int(bool(use_delight_gating))
+    io.delight_temperature = -1. if delight_temperature is None else float(delight_temperature)
+    P = _lib.ptr
+    io.agent_embed, io.actions, io.old_log_probs, io.old_values = P(agent), P(actions), P(old_lp), P(old_values)
+    io.rewards, io.old_action_logits, io.lens, io.is_truncated, io.terminals = P(rewards), P(old_logits), P(lens), P(trunc), P(terms)
+    io.losses, io.returns = P(losses), P(returns)
+
+    cb = None
+    if stats == 'global' and parallel.world_size(process_group) > 1:
+        ws, base = model._ws, model._ws.data_ptr()
+
+        def _allreduce(ptr, n, _user):
+            off = ptr - base
+            view = ws[off:off + 4 * n].view(torch.float32)
+            parallel.all_reduce_sum_(view, process_group)
+            return 0
+
+        cb = _lib.ALLREDUCE_FN(_allreduce)
+        io.allreduce_sum = cb
+    _lib.check(lib.d4_learn(model._engine, C.byref(io), model._stream()))
+    del cb
+    return losses, returns
+
+
+def learn(model, experience, policy_optim, value_optim, only_learn_policy_value_heads, objective,
+          use_delight_gating, delight_temperature, normalize_advantages, eps, process_group, stats):
+    if not only_learn_policy_value_heads:
+        raise NotImplementedError('fine-tuning the whole world model through learn_from_experience is out of scope '
+                                  '(needs the trunk backward, SURVEY.md 8f-3)')
+    losses, _ = run_learner(model, experience, objective, use_delight_gating, delight_temperature,
+                            normalize_advantages, eps, process_group, stats)
+    gp, gv = model._groups['policy'], model._groups['value']
+    policy_loss = _NativeLoss.apply(losses[0], gp['grad'].clone(), *gp['params'])
+    value_loss = _NativeLoss.apply(losses[1], gv['grad'].clone(), *gv['params'])
+    if policy_optim is not None:
+        policy_loss.backward()
+        policy_optim.step()
+        policy_optim.zero_grad()
+    if value_optim is not None:
+        value_loss.backward()
+        value_optim.step()
+        value_optim.zero_grad()
+    return policy_loss, value_loss

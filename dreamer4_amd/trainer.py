@@ -1,2 +1,85 @@
+"""DreamTrainer: generate -> learn_from_experience -> clip + AdamW on each head, the loop of the
+reference's DreamTrainer.forward (dreamer4/trainers.py:1416-1468) without HF Accelerate.
+
+The optimiser step runs natively (d4_adamw_clip) on the flat parameter group of each head:
+`clip_grad_norm_(head, 0.5)` then AdamW(lr 3e-4, weight_decay 0) as trainers.py:1375-1376, 1436-1452.
+Multi-GPU: one process per GPU, trajectories sharded by rank, one RCCL sum all-reduce per head over
+its flat gradient bucket; with global statistics the local gradients are already scaled by the
+global masked-mean denominators, so the sum IS the single-process gradient at B_global.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from dreamer4_amd import _lib, parallel
+from dreamer4_amd.learner import run_learner
+
+
 class DreamTrainer:
-    pass
+    def __init__(self, model, batch_size=16, generate_timesteps=16, learning_rate=3e-4, max_grad_norm=0.5,
+                 num_train_steps=10_000, weight_decay=0., objective='ppo', betas=(0.9, 0.999), adam_eps=1e-8,
+                 process_group=None, stats='global', seed=None, generate_kwargs: dict | None = None):
+        self.model, self.objective = model, objective
+        self.batch_size, self.generate_timesteps = batch_size, generate_timesteps
+        self.lr, self.max_grad_norm, self.weight_decay = learning_rate, max_grad_norm, weight_decay
+        self.betas, self.adam_eps = betas, adam_eps
+        self.num_train_steps = num_train_steps
+        self.process_group, self.stats = process_group, stats
+        self.generate_kwargs = dict(return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True)
+        if generate_kwargs:
+            self.generate_kwargs.update(generate_kwargs)
+        self.step = 0
+        self._state = {}
+        self.generator = None
+        if seed is not None:
+            self.generator = torch.Generator(device=model.device).manual_seed(parallel.rank_seed(seed, process_group))
+
+    def _optim_step(self, name):
+        m = self.model
+        g = m._groups[name]
+        n = g['flat'].numel()
+        st = self._state.get(name)
+        if st is None or st['m'].numel() != n or st['m'].device != g['flat'].device:
+            st = dict(m=torch.zeros(n, device=m.device), v=torch.zeros(n, device=m.device),
+                      scratch=torch.zeros(1025, device=m.device), t=0)
+            self._state[name] = st
+        grad_scale = 1.
+        if parallel.world_size(self.process_group) > 1:
+            parallel.all_reduce_sum_(g['grad'], self.process_group)           # ONE collective per head
+            if self.stats != 'global':
+                grad_scale = 1. / parallel.world_size(self.process_group)     # average of per-rank means (what DDP would do)
+        st['t'] += 1
+        lib = _lib.load()
+        P = _lib.ptr
+        _lib.check(lib.d4_adamw_clip(P(g['flat']), P(g['grad']), P(st['m']), P(st['v']), n, st['t'], self.lr, self.betas[0],
+                                     self.betas[1], self.adam_eps, self.weight_decay,
+                                     self.max_grad_norm if self.max_grad_norm is not None else 0., grad_scale,
+                                     P(st['scratch']), m._stream()))
+        return st['scratch'][0]
+
+    def generate(self):
+        return self.model.generate(self.generate_timesteps + 1, batch_size=self.batch_size, generator=self.generator,
+                                   **self.generate_kwargs)
+
+    def learn(self, dreams):
+        """learn_from_experience + backward + clip + AdamW for the policy head, then the value head.
+        Returns the device tensor [total_policy_loss, value_loss] (no host sync)."""
+        losses, _ = run_learner(self.model, dreams, self.objective, process_group=self.process_group, stats=self.stats)
+        self._optim_step('policy')
+        self._optim_step('value')
+        self.step += 1
+        return losses
+
+    def train_step(self):
+        return self.learn(self.generate())
+
+    def forward(self):
+        for _ in range(self.num_train_steps):
+            losses = self.train_step()
+            pl, vl = losses.tolist()
+            if parallel.rank(self.process_group) == 0:
+                print(f'policy head loss: {pl:.3f} | value head loss: {vl:.3f}')
+
+    __call__ = forward

@@ -147,6 +147,8 @@ typedef struct d4_learn_io {
     int32_t objective;             /* 0 = ppo, 1 = spo, 2 = pmpo */
     int32_t normalize_advantages;  /* -1 = default (objective != pmpo) */
     float eps;                     /* z-score epsilon (1e-6, D4:5903) */
+    int32_t use_delight_gating;    /* -1 = engine config default */
+    float delight_temperature;     /* <= 0 = engine config default */
     const float* agent_embed;      /* [batch][time][dim] */
     const int64_t* actions;        /* [batch][time][action_types] */
     const float* old_log_probs;    /* [batch][time][action_types] */
@@ -166,13 +168,14 @@ typedef struct d4_learn_io {
 
 int d4_learn(d4_engine* e, const d4_learn_io* io, void* stream);
 
-/* clip_grad_norm_(params, max_norm) + AdamW step over one parameter group (0 = policy head,
- * 1 = value head), as DreamTrainer does (trainers.py:1436-1452).  `state` is caller-owned device
- * memory of 2 * group_numel floats (exp_avg, exp_avg_sq), zero-initialised. */
-int64_t d4_group_numel(const d4_engine* e, int group);
-int d4_optim_step(d4_engine* e, int group, float* state, int step, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float max_grad_norm, float grad_scale,
-                  float* grad_norm_out, void* stream);
+/* clip_grad_norm_(params, max_norm) followed by one torch.optim.AdamW step on a flat parameter group,
+ * as DreamTrainer does per head (trainers.py:1436-1452).  `grad_scale` multiplies the gradient first
+ * (1/world_size after a SUM all-reduce of per-rank-mean gradients; 1 with global statistics).
+ * exp_avg / exp_avg_sq: caller-owned optimiser state (zero-initialised); scratch: >= 1025 floats;
+ * scratch[0] receives the (scaled) total gradient norm. */
+int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                  float grad_scale, float* scratch, void* stream);
 
 /* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr);
