@@ -1,0 +1,226 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (build container only).
+
+    python -m oracle.gen_golden          # needs /root/reference; writes tests/golden/
+
+The reference's dreamer4/dreamer4.py is imported unmodified through oracle/shim (stand-ins for the
+third-party packages this image lacks, see oracle/ref_import.py).  Each fixture records
+`oracle = "shim"` and which third-party behaviours were restated rather than imported.  Every random
+draw of DynamicsWorldModel.generate is injected (oracle/ref_harness.py) so the fixtures are pure
+functions of the stored inputs.
+
+Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block every 2):
+  weights.npz      reference state_dict of the fixture model
+  generate.npz     generate() in four modes: cached, no time cache, 2-frame prompt, 3 chained calls
+  forward.npz      one parallel forward over 4 frames (+ the same frames fed one at a time with the cache)
+  learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
+  trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.ref_harness import build_reference_model, injected, make_noise, weights_of   # noqa: E402
+from oracle.ref_import import load_reference                                            # noqa: E402
+from oracle.restate import Config                                                       # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+META = dict(
+    oracle='shim',
+    reference='lucidrains/dreamer4 v0.16.3 dreamer4/dreamer4.py imported unmodified',
+    restated_third_party='x_mlps_pytorch(create_mlp, Ensemble) hl_gauss_pytorch discrete_continuous_embed_readout(MultiCategorical) '
+                         'assoc_scan einx torch_einops_utils  -- PARITY UNPINNED against the real packages',
+)
+
+CFG = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=4, time_block_every=2, attn_heads=2, attn_dim_head=64,
+           num_discrete_actions=(4,), num_tasks=3, reward_num_bins=63, value_num_bins=63, multi_token_pred_len=4)
+
+
+def fixture_config():
+    return Config(**CFG)
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def exp_dict(prefix, e, out):
+    out[prefix + 'latents'] = npy(e.latents)
+    out[prefix + 'agent_embed'] = npy(e.agent_embed)
+    out[prefix + 'rewards'] = npy(e.rewards)
+    out[prefix + 'values'] = npy(e.values)
+    out[prefix + 'log_probs'] = npy(e.log_probs.discrete)
+    out[prefix + 'actions'] = npy(e.actions.discrete)
+    out[prefix + 'lens'] = npy(e.lens)
+    out[prefix + 'terminals'] = npy(e.terminals)
+    out[prefix + 'unembeds'] = npy(e.old_action_unembeds.discrete)
+    out[prefix + 'episode_return'] = npy(e.episode_return)
+
+
+def noise_dict(prefix, nz, out):
+    for k, v in nz.items():
+        out[prefix + 'noise_' + k] = npy(v)
+
+
+def min_margin(e, noise, cfg):
+    """Smallest top-2 gap of (logit + gumbel) over all sampled actions: exact-index parity is only
+    well posed when this is comfortably above the fp32 tolerance."""
+    lg = e.old_action_unembeds.discrete                    # (B, F, A)
+    F = lg.shape[1]
+    u = noise['gumbel_u'][:F].transpose(0, 1)
+    g = -torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+    top = (lg + g).topk(2, dim=-1).values
+    return float((top[..., 0] - top[..., 1]).min())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    D4 = load_reference()
+    cfg = fixture_config()
+    m = build_reference_model(cfg, seed=0)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)      # 100x -> 30x: keep the policy stochastic
+    W = weights_of(m)
+    np.savez(os.path.join(OUT, 'weights.npz'), **{k: npy(v) for k, v in W.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()},
+             **{'cfg_' + k: np.array(v) for k, v in CFG.items()})
+
+    # ------------------------------------------------------------------ generate
+    B, T = 3, 5
+    out = {}
+    tasks = torch.tensor([0, 2, 1])
+    nz = make_noise(cfg, T, B, 101)
+    with injected(nz):
+        e = m.generate(T, batch_size=B, return_for_policy_optimization=True, tasks=tasks)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_tasks'] = npy(tasks)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg))
+    cached_exp = e
+
+    nz = make_noise(cfg, T, B, 102)
+    with injected(nz):
+        e = m.generate(T, batch_size=B, return_for_policy_optimization=True, use_time_cache=False, num_steps=2)
+    exp_dict('nocache_', e, out); noise_dict('nocache_', nz, out)
+    out['nocache_margin'] = np.array(min_margin(e, nz, cfg))
+
+    g = torch.Generator().manual_seed(5)
+    pl = torch.randn(B, 2, 6, 8, generator=g).clamp(-1, 1)
+    pa = torch.randint(0, 4, (B, 2, 1), generator=g)
+    pr = torch.randn(B, 2, generator=g)
+    nz = make_noise(cfg, T, B, 103)
+    with injected(nz):
+        e = m.generate(T, batch_size=B, return_for_policy_optimization=True, prompt_latents=pl,
+                       prompt_discrete_actions=pa, prompt_rewards=pr)
+    exp_dict('prompt_', e, out); noise_dict('prompt_', nz, out)
+    out['prompt_latents_in'], out['prompt_actions_in'], out['prompt_rewards_in'] = npy(pl), npy(pa), npy(pr)
+    out['prompt_margin'] = np.array(min_margin(e, nz, cfg))
+
+    nz = make_noise(cfg, 3, B, 104)
+    with injected(nz):
+        tc = None
+        for i in range(3):
+            e, tc = m.generate(1, batch_size=B, return_for_policy_optimization=True, time_cache=tc,
+                               return_time_cache=True, return_terminals=False)
+            exp_dict(f'chain{i}_', e, out)
+    noise_dict('chain_', nz, out)
+    out['chain_final_kv'] = npy(tc.main.next_kv_cache)
+    np.savez(os.path.join(OUT, 'generate.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('generate margins', out['cached_margin'], out['nocache_margin'], out['prompt_margin'],
+          'lens', out['cached_lens'], out['nocache_lens'], out['prompt_lens'])
+
+    # ------------------------------------------------------------------ forward: parallel vs cached sequential
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    Tf = 4
+    lat = torch.randn(B, Tf, 6, 8, generator=g)
+    sig = torch.randint(0, 64, (B, Tf), generator=g)
+    acts = torch.randint(0, 4, (B, Tf, 1), generator=g)
+    with torch.no_grad():
+        pred, (emb, inter) = m(latents=lat, signal_levels=sig, step_sizes=4, discrete_actions=acts, latent_is_noised=True,
+                               return_pred_only=True, return_intermediates=True)
+        out.update(latents=npy(lat), signal_levels=npy(sig), actions=npy(acts), pred=npy(pred.flow[:, :, 0]),
+                   agent_embed=npy(emb.agent[:, :, 0]), kv=npy(inter.main.next_kv_cache))
+        tc, seq_agent, seq_pred = None, [], []
+        for t in range(Tf):
+            a = None if t == 0 else acts[:, t - 1:t]
+            pred, (emb, tc) = m(latents=lat[:, t:t + 1], signal_levels=sig[:, t:t + 1], step_sizes=4, discrete_actions=a,
+                                time_cache=tc, latent_is_noised=True, return_pred_only=True, return_intermediates=True)
+            seq_agent.append(emb.agent[:, :, 0]); seq_pred.append(pred.flow[:, :, 0])
+        out['seq_agent_embed'] = npy(torch.cat(seq_agent, 1)); out['seq_pred'] = npy(torch.cat(seq_pred, 1))
+    print('parallel vs sequential (reference self-consistency):', np.abs(out['agent_embed'] - out['seq_agent_embed']).max())
+    np.savez(os.path.join(OUT, 'forward.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+
+    # ------------------------------------------------------------------ learn
+    out = {}
+    e = cached_exp
+    heads = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
+    for obj in ('ppo', 'spo', 'pmpo'):
+        m.zero_grad()
+        pl_, vl_ = m.learn_from_experience(e, objective=obj)
+        pl_.backward(); vl_.backward()
+        out[f'{obj}_policy_loss'], out[f'{obj}_value_loss'] = npy(pl_), npy(vl_)
+        for k, p in m.named_parameters():
+            if k.startswith(heads) and p.numel() > 0 and p.grad is not None:
+                if obj == 'ppo' or p.ndim == 1 or 'unembed' in k:
+                    out[f'{obj}_grad/{k}'] = npy(p.grad)
+                else:       # large matrices of the other objectives: Frobenius norm + a strided sample
+                    out[f'{obj}_gnorm/{k}'] = npy(p.grad.norm())
+                    out[f'{obj}_gsample/{k}'] = npy(p.grad.flatten()[::97])
+    # GAE with terminations / truncations
+    g = torch.Generator().manual_seed(9)
+    r = torch.randn(4, 7, generator=g); v = torch.randn(4, 7, generator=g)
+    lens = torch.tensor([7, 3, 5, 1]); trunc = torch.tensor([True, False, False, True]); term = ~trunc
+    ar = torch.arange(7)
+    gae_masks = ar < (lens - 1).clamp(min=0)[:, None]
+    term_seq = D4.flags_to_sequence(term, (lens - 1).clamp(min=0), 7)
+    gae_masks = gae_masks.masked_fill(term_seq, False)
+    len_mask = ar < lens[:, None]
+    learn_mask = ar < (lens - trunc.long())[:, None]
+    ret = D4.calc_gae(r.masked_fill(~len_mask, 0.), v.masked_fill(~len_mask, 0.), masks=gae_masks, learn_masks=learn_mask,
+                      gamma=0.997, lam=0.95, use_accelerated=False)
+    out.update(gae_rewards=npy(r), gae_values=npy(v), gae_lens=npy(lens), gae_trunc=npy(trunc), gae_term=npy(term), gae_returns=npy(ret))
+    np.savez(os.path.join(OUT, 'learn.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+
+    # ------------------------------------------------------------------ three DreamTrainer steps (trainers.py:1422-1452)
+    out = {}
+    m2 = build_reference_model(cfg, seed=0)
+    with torch.no_grad():
+        m2.action_embedder.discrete_action_unembed.mul_(0.3)
+    popt = torch.optim.AdamW(m2.policy_head_parameters(), lr=3e-4, weight_decay=0.)
+    vopt = torch.optim.AdamW(m2.value_head_parameters(), lr=3e-4, weight_decay=0.)
+    Bt, Ht = 4, 4
+    for step in range(3):
+        nz = make_noise(cfg, Ht + 1, Bt, 200 + step)
+        noise_dict(f'step{step}_', nz, out)
+        with injected(nz):
+            dreams = m2.generate(Ht + 1, batch_size=Bt, return_rewards_per_frame=True, return_agent_actions=True,
+                                 return_log_probs_and_values=True)
+        pl_, vl_ = m2.learn_from_experience(dreams, objective='ppo')
+        pl_.backward()
+        out[f'step{step}_policy_gnorm'] = npy(torch.nn.utils.clip_grad_norm_(m2.policy_head_parameters(), 0.5))
+        popt.step(); popt.zero_grad()
+        vl_.backward()
+        out[f'step{step}_value_gnorm'] = npy(torch.nn.utils.clip_grad_norm_(m2.value_head_parameters(), 0.5))
+        vopt.step(); vopt.zero_grad()
+        out[f'step{step}_policy_loss'], out[f'step{step}_value_loss'] = npy(pl_), npy(vl_)
+        out[f'step{step}_actions'] = npy(dreams.actions.discrete)
+    for k, p in m2.named_parameters():
+        if k.startswith(heads) and p.numel() > 0:
+            if p.ndim == 1 or 'unembed' in k:
+                out['final/' + k] = npy(p)
+            else:
+                out['final_sample/' + k] = npy(p.flatten()[::97])
+                out['final_delta_norm/' + k] = npy((p - W[k]).norm())
+    np.savez(os.path.join(OUT, 'trainer.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()

@@ -14,6 +14,7 @@ from oracle.restate import Config
 
 
 def make_noise(cfg: Config, frames, batch, seed):
+    """Same recipe as tests/util.make_noise (kept identical so fixtures can be regenerated from seeds)."""
     g = torch.Generator().manual_seed(seed)
     n, dl, A = cfg.num_latent_tokens, cfg.dim_latent, cfg.total_discrete_actions
     return dict(

@@ -1,0 +1,165 @@
+"""GPU: DynamicsWorldModel.generate / forward on the HIP engine against (a) the fixtures frozen from the
+reference and (b) the oracle restatement on fresh seeded inputs.  Tolerance: atol 2e-4,
+rtol 1e-4 on floating point outputs after a multi-frame rollout; sampled action indices, terminals and
+lens bit-exact (the fixtures assert a top-2 margin >= 1e-3 so exactness is well posed)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restate
+from util import (golden_model, golden_noise, golden_oracle, load_golden, make_noise, oracle_config, oracle_weights,
+                  randomize_weights, small_model, t)
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 2e-4, 1e-4
+
+
+def close(a, b, atol=ATOL, rtol=RTOL):
+    a = a.detach().float().cpu() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).float()
+    b = b.detach().float().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), f'max abs diff {(a - b).abs().max().item():.3e}'
+
+
+def check_exp(e, g, prefix):
+    close(e.latents, g[prefix + 'latents']); close(e.agent_embed, g[prefix + 'agent_embed'])
+    close(e.rewards, g[prefix + 'rewards']); close(e.values, g[prefix + 'values'])
+    close(e.log_probs.discrete, g[prefix + 'log_probs']); close(e.old_action_unembeds.discrete, g[prefix + 'unembeds'])
+    close(e.episode_return, g[prefix + 'episode_return'])
+    assert np.array_equal(e.actions.discrete.cpu().numpy(), g[prefix + 'actions'])
+    assert np.array_equal(e.lens.cpu().numpy(), g[prefix + 'lens'])
+    assert np.array_equal(e.terminals.cpu().numpy(), g[prefix + 'terminals'])
+    assert np.array_equal(e.is_truncated.cpu().numpy(), ~g[prefix + 'terminals'])
+
+
+@pytest.fixture(scope='module')
+def GM():
+    assert torch.cuda.is_available()
+    return golden_model().cuda(), load_golden('generate.npz')
+
+
+def test_generate_cached_vs_reference_fixture(GM):
+    m, G = GM
+    e = m.generate(5, batch_size=3, return_for_policy_optimization=True, tasks=t(G['cached_tasks']), noise=golden_noise(G, 'cached_'))
+    check_exp(e, G, 'cached_')
+    assert e.step_size == 16 and e.is_from_world_model is True
+
+
+def test_generate_without_time_cache_vs_reference_fixture(GM):
+    m, G = GM
+    e = m.generate(5, batch_size=3, num_steps=2, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(G, 'nocache_'))
+    check_exp(e, G, 'nocache_')
+
+
+def test_generate_with_prompt_vs_reference_fixture(GM):
+    m, G = GM
+    e = m.generate(5, batch_size=3, return_for_policy_optimization=True, noise=golden_noise(G, 'prompt_'),
+                   prompt_latents=t(G['prompt_latents_in']), prompt_discrete_actions=t(G['prompt_actions_in']),
+                   prompt_rewards=t(G['prompt_rewards_in']))
+    check_exp(e, G, 'prompt_')
+
+
+def test_chained_generate_with_time_cache_vs_reference_fixture(GM):
+    m, G = GM
+    nz = golden_noise(G, 'chain_')
+    tc = None
+    for i in range(3):
+        e, tc = m.generate(1, batch_size=3, return_for_policy_optimization=True, time_cache=tc, return_time_cache=True,
+                           noise={k: v[i:i + 1] for k, v in nz.items()})
+        check_exp(e, G, f'chain{i}_')
+    assert tc.frames == 3
+    close(tc.kv(), G['chain_final_kv'], atol=1e-5)          # cache export in the reference layout (Lt, 2, B*S, h, t, dh)
+
+
+def test_forward_parallel_equals_cached_sequential(GM):
+    """The reference's strongest invariant (tests/test_dreamer.py:1206-1296), here for the HIP kernels, and
+    both against the reference fixture."""
+    m, _ = GM
+    g = load_golden('forward.npz')
+    lat, sig, acts = t(g['latents']), t(g['signal_levels']), t(g['actions'])
+    pred, (agent, tc) = m(latents=lat, signal_levels=sig, step_sizes=4, discrete_actions=acts)
+    close(pred, g['pred'], atol=1e-5); close(agent, g['agent_embed'], atol=1e-5)
+    close(tc.kv(), g['kv'], atol=1e-5)
+    tc, seq = None, []
+    for i in range(lat.shape[1]):
+        a = None if i == 0 else acts[:, i - 1:i]
+        p, (ag, tc) = m(latents=lat[:, i:i + 1], signal_levels=sig[:, i:i + 1], step_sizes=4, discrete_actions=a, time_cache=tc)
+        seq.append(ag)
+    seq = torch.cat(seq, 1)
+    close(seq, g['seq_agent_embed'], atol=1e-5)
+    close(seq, agent, atol=1e-5)
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(num_discrete_actions=(3, 2), depth=3, time_block_every=1),
+                                dict(dim=128, attn_heads=4, num_latent_tokens=12, dim_latent=16, depth=2, time_block_every=1)])
+def test_generate_vs_oracle_on_fresh_models(kw):
+    m = small_model(**kw)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = 4, 4
+    nz = make_noise(cfg, T, B, 77)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz)
+    e = m.cuda().generate(T, batch_size=B, return_for_policy_optimization=True, noise=nz)
+    Tp = ref['latents'].shape[1]
+    assert e.latents.shape[1] == Tp
+    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed']); close(e.rewards, ref['rewards'])
+    close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'])
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions']) and torch.equal(e.lens.cpu(), ref['lens'])
+
+
+def test_plain_generate_returns_latents_only(GM):
+    m, G = GM
+    nz = golden_noise(G, 'cached_')
+    lat = m.generate(3, batch_size=3, noise=nz)
+    assert torch.is_tensor(lat) and lat.shape == (3, 3, 6, 8) and lat.abs().max() <= 1.
+    lat2, tc = m.generate(3, batch_size=3, noise=nz, return_time_cache=True)
+    assert torch.equal(lat, lat2) and tc.frames == 3          # bitwise reproducible
+
+
+def test_invalid_arguments_raise(GM):
+    m, _ = GM
+    with pytest.raises(AssertionError):
+        m.generate(2, num_steps=3)
+    with pytest.raises(NotImplementedError):
+        m.generate(2, prompt=torch.zeros(1, 3, 8, 8))
+
+
+@pytest.mark.parametrize('B', [1, 2])
+def test_full_size_config_vs_oracle(B):
+    """BASELINE config 2 architecture (dim 512, depth 6, 8 x 64 heads, 32 x 32 latents) at a batch the CPU
+    oracle finishes in seconds."""
+    from dreamer4_amd import DynamicsWorldModel
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4))
+    cfg, W = oracle_config(m), oracle_weights(m)
+    T = 6
+    nz = make_noise(cfg, T, B, 5)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, return_terminals=False)
+    e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
+                          return_log_probs_and_values=True, noise=nz)
+    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed'], atol=5e-4)
+    close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'], atol=5e-4)
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
+
+
+def test_full_size_properties_at_baseline_batch():
+    """Size-independent properties at BASELINE's B=256, H=15: bitwise determinism, trajectory independence
+    (a trajectory's result does not depend on the batch it is generated in), ranges."""
+    from dreamer4_amd import DynamicsWorldModel
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4),
+                          terminal_bias=-10.).cuda()
+    cfg = oracle_config(m)
+    B, T = 256, 16
+    nz = make_noise(cfg, T, B, 9)
+    a = m.generate(T, batch_size=B, return_for_policy_optimization=True, noise=nz)
+    b = m.generate(T, batch_size=B, return_for_policy_optimization=True, noise=nz)
+    for x, y in ((a.latents, b.latents), (a.agent_embed, b.agent_embed), (a.actions.discrete, b.actions.discrete), (a.values, b.values)):
+        assert torch.equal(x, y)
+    assert a.latents.shape == (B, T, 32, 32) and a.rewards.shape == (B, T) and a.actions.discrete.shape == (B, T, 1)
+    assert a.log_probs.discrete.shape == (B, T, 1) and a.values.shape == (B, T) and a.agent_embed.shape == (B, T, 512)
+    assert int(a.actions.discrete.min()) >= 0 and int(a.actions.discrete.max()) < 4
+    assert (a.log_probs.discrete <= 0).all() and torch.isfinite(a.latents).all() and a.latents.abs().max() <= 1.
+    sub = {k: v[:, 100:104].contiguous() for k, v in nz.items()}
+    c = m.generate(T, batch_size=4, return_for_policy_optimization=True, noise=sub)
+    assert torch.equal(c.actions.discrete, a.actions.discrete[100:104])
+    close(c.latents, a.latents[100:104], atol=1e-5); close(c.values, a.values[100:104], atol=1e-5)

@@ -1,0 +1,116 @@
+"""GPU: single-kernel parity through the C-ABI (the same launchers the engine uses)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from dreamer4_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return _lib.load()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def run_gemm(lib, M, N, K, flags=0, bias=False, res=False, ta=False, tb=False, seed=0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    Mp = (M + 3) // 4 * 4          # leading dimensions must be multiples of 4 floats (16-byte rows)
+    A_full = torch.randn((K, Mp) if ta else (M, K), device='cuda', generator=g)
+    A = A_full[:, :M] if ta else A_full
+    W = torch.randn((K, N) if tb else (N, K), device='cuda', generator=g)
+    b = torch.randn(N, device='cuda', generator=g) if bias else None
+    R = torch.randn(M, N, device='cuda', generator=g) if res else None
+    Nout = N // 2 if flags & _lib.GEMM_SWIGLU else N
+    out = torch.full((M, Nout), float('nan'), device='cuda')
+    f = flags | (_lib.GEMM_TRANS_A if ta else 0) | (_lib.GEMM_TRANS_B if tb else 0)
+    _lib.check(lib.d4_gemm(_lib.ptr(A_full), A_full.shape[1], _lib.ptr(W), W.shape[1], _lib.ptr(out), Nout, _lib.ptr(b), _lib.ptr(R), N,
+                           M, N, K, f, 1.1920929e-07, stream()))
+    Ad = (A.t() if ta else A).double()
+    Wd = (W if tb else W.t()).double()
+    X = Ad * torch.rsqrt(Ad.pow(2).mean(-1, keepdim=True) + 1.1920929e-07) if flags & _lib.GEMM_RMS_ROWSCALE else Ad
+    ref = X @ Wd
+    if bias:
+        ref = ref + b.double()
+    if flags & _lib.GEMM_SILU:
+        ref = torch.nn.functional.silu(ref)
+    if flags & _lib.GEMM_SWIGLU:
+        r = ref.reshape(M, N // 64, 2, 32)
+        ref = (r[:, :, 0] * torch.nn.functional.silu(r[:, :, 1])).reshape(M, N // 2)
+    if res:
+        ref = ref + R.double()
+    err = (out.double() - ref).abs().max().item()
+    tol = 2e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
+    assert err <= tol, f'M{M} N{N} K{K} flags{f}: err {err:.3e} > {tol:.3e}'
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (64, 64, 32), (200, 300, 72), (3, 4, 256), (45, 388, 64), (15, 2064, 512),
+                                   (3840, 512, 512), (1, 255, 512), (50000, 512, 512), (96, 1024, 8)])
+def test_gemm_nt(lib, M, N, K):
+    run_gemm(lib, M, N, K)
+    run_gemm(lib, M, N, K, flags=_lib.GEMM_RMS_ROWSCALE, bias=True)
+    run_gemm(lib, M, N, K, flags=_lib.GEMM_SILU, bias=True, res=True)
+
+
+@pytest.mark.parametrize('M,N,K', [(45, 192, 64), (3840, 2752, 512), (256, 128, 32)])
+def test_gemm_swiglu_epilogue(lib, M, N, K):
+    run_gemm(lib, M, N, K, flags=_lib.GEMM_RMS_ROWSCALE | _lib.GEMM_SWIGLU, bias=True)
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(100, 200, 300, False, True), (256, 2048, 4096, True, True), (4, 2048, 4096, True, True),
+                                         (255, 128, 30 * 4, True, True), (128, 64, 40, True, False)])
+def test_gemm_transposed_operands(lib, M, N, K, ta, tb):
+    run_gemm(lib, M, N, K, ta=ta, tb=tb)
+
+
+def test_gemm_is_deterministic(lib):
+    A = torch.randn(3840, 512, device='cuda'); W = torch.randn(1552, 512, device='cuda')
+    outs = []
+    for _ in range(2):
+        o = torch.empty(3840, 1552, device='cuda')
+        _lib.check(lib.d4_gemm(_lib.ptr(A), 512, _lib.ptr(W), 512, _lib.ptr(o), 1552, None, None, 0, 3840, 1552, 512, 1, 1e-7, stream()))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_rejects_misaligned_operands(lib):
+    A = torch.randn(8, 34, device='cuda')
+    with pytest.raises(_lib.D4Error, match='multiples of 4'):
+        _lib.check(lib.d4_gemm(_lib.ptr(A), 34, _lib.ptr(A), 34, _lib.ptr(A), 8, None, None, 0, 8, 8, 34, 0, 0., stream()))
+
+
+@pytest.mark.parametrize('rows,D', [(4, 64), (7, 512), (256, 2048), (5, 8), (0, 64)])
+def test_rmsnorm(lib, rows, D):
+    x = torch.randn(rows, D, device='cuda'); g = torch.randn(D, device='cuda'); y = torch.zeros_like(x)
+    _lib.check(lib.d4_rmsnorm(_lib.ptr(x), D, _lib.ptr(g), _lib.ptr(y), D, rows, D, 1.1920929e-07, stream()))
+    ref = torch.nn.functional.rms_norm(x, (D,), g, eps=None)
+    assert torch.allclose(y, ref, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('bins', [255, 63, 20])
+def test_hl_gauss_bins_to_scalar(lib, bins):
+    logits = torch.randn(300, bins, device='cuda') * 3
+    support = torch.linspace(-20., 20., bins + 1, device='cuda')
+    centers = ((support[:-1] + support[1:]) / 2).contiguous()
+    out = torch.empty(300, device='cuda')
+    _lib.check(lib.d4_hl_gauss_scalar(_lib.ptr(logits), bins, _lib.ptr(centers), _lib.ptr(out), 300, bins, stream()))
+    ref = (logits.softmax(-1) * centers).sum(-1)
+    assert torch.allclose(out, ref, atol=1e-5)
+    assert (out >= -20).all() and (out <= 20).all()           # reference test_hl_gauss_reward_encoder: values within range
+
+
+def test_gae_matches_the_reference_fixture(lib):
+    from util import load_golden, t
+    g = load_golden('learn.npz')
+    r, v = t(g['gae_rewards']).cuda(), t(g['gae_values']).cuda()
+    lens = t(g['gae_lens']).cuda(); tr = t(g['gae_trunc']).to(torch.uint8).cuda(); te = t(g['gae_term']).to(torch.uint8).cuda()
+    out = torch.empty_like(r)
+    _lib.check(lib.d4_gae(_lib.ptr(r), _lib.ptr(v), _lib.ptr(lens), _lib.ptr(tr), _lib.ptr(te), 0.997, 0.95, r.shape[0], r.shape[1],
+                          _lib.ptr(out), stream()))
+    assert torch.allclose(out.cpu(), t(g['gae_returns']), atol=1e-6)

@@ -1,0 +1,111 @@
+"""GPU: learn_from_experience (losses + gradients of both heads) and the native clipped AdamW step against the
+reference fixtures and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from dreamer4_amd import Actions, DreamTrainer, Experience
+from oracle import restate
+from util import golden_model, golden_noise, golden_oracle, load_golden, make_noise, oracle_config, oracle_weights, small_model, t
+
+pytestmark = pytest.mark.gpu
+HEADS = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
+
+
+def close(a, b, atol=1e-5, rtol=1e-4):
+    a = a.detach().float().cpu() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).float()
+    b = b.detach().float().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, atol=atol, rtol=rtol), f'max abs diff {(a - b).abs().max().item():.3e} (scale {b.abs().max().item():.3e})'
+
+
+def fixture_experience(G):
+    return Experience(latents=t(G['cached_latents']), agent_embed=t(G['cached_agent_embed']), rewards=t(G['cached_rewards']),
+                      values=t(G['cached_values']), log_probs=Actions(t(G['cached_log_probs']), None),
+                      actions=Actions(t(G['cached_actions']), None), lens=t(G['cached_lens']), terminals=t(G['cached_terminals']),
+                      is_truncated=~t(G['cached_terminals']), old_action_unembeds=Actions(t(G['cached_unembeds']), None), step_size=16)
+
+
+@pytest.mark.parametrize('objective', ['ppo', 'spo', 'pmpo'])
+def test_learn_vs_reference_fixture(objective):
+    m = golden_model().cuda()
+    G, g = load_golden('generate.npz'), load_golden('learn.npz')
+    pl, vl = m.learn_from_experience(fixture_experience(G), objective=objective)
+    close(pl, g[f'{objective}_policy_loss'], atol=1e-5); close(vl, g[f'{objective}_value_loss'], atol=1e-5)
+    pl.backward(retain_graph=True); vl.backward()                # reference test_action_with_world_model does exactly this
+    P = dict(m.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith(f'{objective}_grad/'):
+            close(P[k.split('/', 1)[1]].grad, v, atol=2e-6, rtol=1e-3); n += 1
+        elif k.startswith(f'{objective}_gnorm/'):
+            close(P[k.split('/', 1)[1]].grad.norm(), v, atol=1e-6, rtol=1e-3); n += 1
+        elif k.startswith(f'{objective}_gsample/'):
+            close(P[k.split('/', 1)[1]].grad.flatten()[::97], v, atol=2e-6, rtol=1e-3)
+    assert n >= 20
+    assert all(p.grad is None for k, p in P.items() if not k.startswith(HEADS)), 'only the two heads learn (D4:5898)'
+
+
+def test_learn_vs_oracle_with_terminations_and_two_action_types():
+    m = small_model(num_discrete_actions=(3, 2))
+    from util import randomize_weights
+    randomize_weights(m, terminal_bias=-0.5)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = 6, 6
+    nz = make_noise(cfg, T, B, 31)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz)
+    assert ref['terminals'].any() and (ref['lens'] < ref['latents'].shape[1]).any()
+    m = m.cuda()
+    e = m.generate(T, batch_size=B, return_for_policy_optimization=True, noise=nz)
+    for obj in ('ppo', 'spo', 'pmpo'):
+        Wg = {k: (v.clone().requires_grad_() if k.startswith(HEADS) else v) for k, v in W.items()}
+        pl_o, vl_o = restate.learn_losses(cfg, Wg, ref, obj)
+        pl_o.backward(); vl_o.backward()
+        m.zero_grad()
+        pl, vl = m.learn_from_experience(e, objective=obj)
+        close(pl, pl_o, atol=2e-5); close(vl, vl_o, atol=2e-5)
+        pl.backward(); vl.backward()
+        for k, p in m.named_parameters():
+            if k.startswith(HEADS) and p.numel() > 0:
+                close(p.grad, Wg[k].grad, atol=5e-6, rtol=2e-3)
+
+
+def test_three_trainer_steps_vs_reference_fixture():
+    """generate -> learn -> clip_grad_norm_(0.5) -> AdamW(3e-4) on each head, natively (trainers.py:1430-1452)."""
+    g = load_golden('trainer.npz')
+    m = golden_model().cuda()
+    _, W0 = golden_oracle()
+    tr = DreamTrainer(m, batch_size=4, generate_timesteps=4)
+    for step in range(3):
+        nz = golden_noise(g, f'step{step}_')
+        dreams = m.generate(5, batch_size=4, return_rewards_per_frame=True, return_agent_actions=True,
+                            return_log_probs_and_values=True, noise=nz)
+        assert np.array_equal(dreams.actions.discrete.cpu().numpy(), g[f'step{step}_actions'])
+        losses = tr.learn(dreams)
+        close(losses[0], g[f'step{step}_policy_loss'], atol=2e-5); close(losses[1], g[f'step{step}_value_loss'], atol=2e-5)
+        close(tr._state['policy']['scratch'][0], g[f'step{step}_policy_gnorm'], atol=1e-5, rtol=1e-3)
+        close(tr._state['value']['scratch'][0], g[f'step{step}_value_gnorm'], atol=1e-5, rtol=1e-3)
+    P = dict(m.named_parameters())
+    for k, v in g.items():
+        if k.startswith('final/'):
+            close(P[k[6:]], v, atol=5e-6)
+        elif k.startswith('final_sample/'):
+            close(P[k[13:]].flatten()[::97], v, atol=5e-6)
+        elif k.startswith('final_delta_norm/'):
+            close((P[k[17:]].detach().cpu() - W0[k[17:]]).norm(), v, atol=1e-5, rtol=1e-2)
+
+
+def test_optimizer_arguments_step_the_heads_like_the_reference():
+    m = small_model().cuda()
+    cfg = oracle_config(m)
+    nz = make_noise(cfg, 4, 3, 5)
+    e = m.generate(4, batch_size=3, return_for_policy_optimization=True, noise=nz)
+    before = [p.detach().clone() for p in m.policy_head_parameters() if p.numel() > 0]
+    popt = torch.optim.AdamW([p for p in m.policy_head_parameters() if p.numel() > 0], lr=1e-3)
+    vopt = torch.optim.AdamW(m.value_head_parameters(), lr=1e-3)
+    pl, vl = m.learn_from_experience(e, policy_optim=popt, value_optim=vopt)
+    assert pl.numel() == 1 and vl.numel() == 1
+    after = [p for p in m.policy_head_parameters() if p.numel() > 0]
+    assert any(not torch.equal(a, b) for a, b in zip(after, before))
+    e2 = m.generate(4, batch_size=3, return_for_policy_optimization=True, noise=nz)       # heads are read in place: no re-prepare needed
+    assert not torch.equal(e2.values, e.values)

@@ -1,0 +1,113 @@
+"""CPU: host-side logic of the product package (no kernels run here)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+import dreamer4_amd
+from dreamer4_amd import Actions, DynamicsWorldModel, Experience, combine_experiences, parallel
+from dreamer4_amd._lib import D4Error
+from util import golden_model, golden_oracle, small_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_keys_match_the_reference_fixture():
+    m = golden_model()
+    _, W = golden_oracle()
+    mine = {k for k, p in m.state_dict().items() if p.numel() > 0}
+    ref = set(W)
+    # keys of modules that are off the imagination path in the reference's state_dict are allowed to be absent here
+    assert not (mine - ref - {'reward_learned_embed'}), sorted(mine - ref)
+    on_path = {k for k in ref if k.startswith(('transformer.', 'policy_head', 'value_head', 'to_', 'latents_to', 'action_embedder',
+                                                'register_tokens', 'signal', 'step_size', 'agent_learned', 'action_learned', 'task_embed'))}
+    assert not (on_path - mine), sorted(on_path - mine)
+
+
+def test_policy_and_value_parameter_groups():
+    m = small_model()
+    names = {id(p): k for k, p in m.named_parameters()}
+    pol = {names[id(p)] for p in m.policy_head_parameters()}
+    assert 'action_embedder.discrete_action_unembed' in pol and all(k.startswith(('policy_head', 'action_embedder')) for k in pol)
+    assert all(names[id(p)].startswith('value_head') for p in m.value_head_parameters())
+
+
+@pytest.mark.parametrize('kw', [dict(num_agents=2), dict(dim_proprio=4), dict(use_time_rnn=True), dict(actor_depth=1),
+                                dict(num_continuous_actions=2), dict(add_state_pred_head=True), dict(mot_temporal=True)])
+def test_out_of_scope_options_raise_instead_of_being_ignored(kw):
+    with pytest.raises(NotImplementedError):
+        DynamicsWorldModel(dim=64, dim_latent=8, num_latent_tokens=6, num_discrete_actions=4, **kw)
+    with pytest.raises(TypeError):
+        DynamicsWorldModel(dim=64, dim_latent=8, num_latent_tokens=6, not_an_option=1)
+
+
+def test_no_cpu_fallback():
+    m = small_model()
+    with pytest.raises(D4Error, match='no CPU fallback'):
+        m.generate(2, batch_size=1, return_for_policy_optimization=True)
+
+
+def test_experience_to_and_combine():
+    a = Experience(latents=torch.zeros(2, 3, 4, 5), rewards=torch.ones(2, 3), actions=Actions(torch.zeros(2, 3, 1, dtype=torch.long), None),
+                   lens=torch.tensor([3, 2]), is_truncated=torch.tensor([True, False]), step_size=16)
+    b = Experience(latents=torch.zeros(1, 5, 4, 5), rewards=torch.ones(1, 5), actions=Actions(torch.zeros(1, 5, 1, dtype=torch.long), None),
+                   step_size=16)
+    c = combine_experiences([a, b])
+    assert c.latents.shape == (3, 5, 4, 5) and c.rewards.shape == (3, 5) and c.actions.discrete.shape == (3, 5, 1)
+    assert c.lens.tolist() == [3, 2, 5] and c.is_truncated.tolist() == [True, False, True] and c.step_size == 16
+    assert c.to('cpu').latents.device.type == 'cpu'
+
+
+def test_shard_range_covers_the_global_batch():
+    assert parallel.world_size() == 1 and parallel.rank() == 0
+    assert parallel.shard_range(10) == (0, 10)
+
+
+DP_SCRIPT = textwrap.dedent('''
+    import os, sys, torch, torch.distributed as dist
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+    from dreamer4_amd import parallel
+    from oracle import restate
+    from util import golden_oracle, load_golden, t
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    parallel.init_from_env('gloo')
+    r, ws = parallel.rank(), parallel.world_size()
+    assert ws == 2
+    # shard ranges tile the global batch, seeds differ per rank
+    lo, hi = parallel.shard_range(5)
+    spans = [None, None]; dist.all_gather_object(spans, (lo, hi))
+    assert spans == [(0, 3), (3, 5)], spans
+    assert parallel.rank_seed(1234) == 1234 + r
+    # global statistics: per-rank partial sums + all-reduce == single process over the whole batch (SURVEY.md 8e)
+    cfg, W = golden_oracle(); G = load_golden('generate.npz')
+    B = 3
+    lo, hi = parallel.shard_range(B)
+    full = dict(rewards=t(G['cached_rewards']), values=t(G['cached_values']), lens=t(G['cached_lens']),
+                terminals=t(G['cached_terminals']), is_truncated=~t(G['cached_terminals']))
+    _, _, adv_full, mask_full = restate.returns_and_advantage(cfg, full, normalize=True)
+    local = {{k: v[lo:hi] for k, v in full.items()}}
+    _, _, adv_raw, mask = restate.returns_and_advantage(cfg, local, normalize=False)
+    s = torch.stack([(adv_raw * mask).sum(), mask.float().sum()]); parallel.all_reduce_sum_(s)
+    mean = s[0] / s[1]
+    sq = (((adv_raw - mean) ** 2) * mask).sum().reshape(1); parallel.all_reduce_sum_(sq)
+    adv = (adv_raw - mean) / (sq[0] / s[1]).clamp(min=1e-6).sqrt()
+    assert torch.allclose(adv, adv_full[lo:hi], atol=1e-5), (adv - adv_full[lo:hi]).abs().max()
+    # one flat bucket per head: sum all-reduce of per-rank gradients scaled by the GLOBAL count == full-batch gradient
+    g = torch.full((7,), float(r + 1)); parallel.all_reduce_sum_(g); assert g.tolist() == [3.0] * 7
+    m = torch.tensor([float(r)]); parallel.all_reduce_max_(m); assert m.item() == 1.0
+    parallel.barrier()
+    os.write(1, ('DP_OK_' + str(r) + '|').encode())
+''')
+
+
+def test_two_process_gloo_data_parallel_semantics(tmp_path):
+    script = tmp_path / 'dp.py'
+    script.write_text(DP_SCRIPT.format(root=ROOT))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29653', str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count('DP_OK_') == 2, out.stdout

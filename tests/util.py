@@ -71,3 +71,60 @@ def small_model(**over):
     kw.update(over)
     torch.manual_seed(0)
     return randomize_weights(DynamicsWorldModel(**kw))
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+import os
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def golden_config_kwargs():
+    w = load_golden('weights.npz')
+    kw = {}
+    for k, v in w.items():
+        if k.startswith('cfg_'):
+            v = v.tolist()
+            kw[k[4:]] = tuple(v) if isinstance(v, list) else v
+    return kw
+
+
+def golden_oracle():
+    """(Config, W) of the fixture model for oracle/restate.py."""
+    w = load_golden('weights.npz')
+    cfg = Config(**golden_config_kwargs())
+    W = {k: torch.from_numpy(v) for k, v in w.items() if not k.startswith(('cfg_', 'meta_'))}
+    return cfg, W
+
+
+def golden_model():
+    """Product model carrying the fixture weights (loaded by reference state_dict key)."""
+    from dreamer4_amd import DynamicsWorldModel
+    kw = golden_config_kwargs()
+    rb, vb = kw.pop('reward_num_bins'), kw.pop('value_num_bins')
+    kw['num_discrete_actions'] = tuple(kw['num_discrete_actions']) if isinstance(kw['num_discrete_actions'], (tuple, list)) else kw['num_discrete_actions']
+    m = DynamicsWorldModel(**kw, reward_encoder_kwargs=dict(num_bins=rb), value_encoder_kwargs=dict(num_bins=vb))
+    _, W = golden_oracle()
+    own = dict(m.named_parameters())
+    missing = [k for k, p in own.items() if p.numel() > 0 and k not in W and k != 'reward_learned_embed']
+    assert not missing, f'fixture lacks keys {missing}'
+    with torch.no_grad():
+        for k, p in own.items():
+            if k in W:
+                assert tuple(p.shape) == tuple(W[k].shape), (k, p.shape, W[k].shape)
+                p.copy_(W[k])
+    return m
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def golden_noise(g, prefix):
+    return {k: t(g[prefix + 'noise_' + k]) for k in ('latent', 'context', 'gumbel_u', 'bern_u')}
