@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark of the imagination hot path (BASELINE.json): imagined latent steps / second
+(whole job) + actor/critic step ms, dim=512 depth=6 H=15, on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one DreamTrainer iteration (dreamer4/trainers.py:1422-1452) on synthetic inputs:
+generate(H+1 frames, B=256 trajectories per GPU, 4 denoising steps + 1 clean step per frame)
+-> learn_from_experience(ppo) -> clip+AdamW on the policy head, then the value head.
+Weights: default init of that architecture under torch.manual_seed(0) with non-trivial head weights
+(SURVEY.md 8d); rollout noise from generator seed 1234 + rank.  Everything is resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+
+  value        = N * B * (H+1) * K / wall     imagined steps per second over the WHOLE step (rollout + learner)
+  roofline     = the dominant kernel (fp32 MFMA GEMM, 128x128 tile class): algorithmic flops of its launches in
+                 the timed region / their summed HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline = the CPU oracle (oracle/restate.py, torch fp32, all host cores) on a bounded sample of the same
+                 workload, rank 0 at N=1 only.  Reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8, attn_dim_head=64,
+            num_spatial_tokens=4, num_register_tokens=8, max_steps=64, multi_token_pred_len=8, num_discrete_actions=4)
+B_LOCAL, HORIZON, NUM_STEPS = 256, 15, 4
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+FLOP_PER_IMAGINED_STEP = 5.23e9        # GEMM flops per generated frame of one trajectory (cfg 2)
+
+
+def build_model(device):
+    from dreamer4_amd import DynamicsWorldModel
+    from dreamer4_amd.synthetic import randomize_weights
+    torch.manual_seed(0)
+    m = DynamicsWorldModel(**CFG2)
+    randomize_weights(m, seed=0, terminal_bias=-10.)     # heads non-trivial; terminal head ~never fires so all H+1 frames count
+    return m.to(device)
+
+
+def cpu_baseline(sample_batch=4, sample_frames=3, max_threads=16):
+    """Oracle on the host cores over a bounded sample of the same workload (same architecture, same call shape)."""
+    from dreamer4_amd import DynamicsWorldModel
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import make_noise, oracle_config, oracle_weights
+    from dreamer4_amd.synthetic import randomize_weights
+    from oracle import restate
+    # torch fp32 on the host: the path is thousands of tiny ops, so more than ~16 intra-op threads only adds
+    # synchronisation cost (256 threads ran this sample 400x slower than 8 on the MI355X host) -> cap and report.
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG2), seed=0, terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    nz = make_noise(cfg, sample_frames, sample_batch, 1234)
+    with torch.no_grad():
+        restate.generate(cfg, W, 1, batch_size=1, noise=make_noise(cfg, 1, 1, 1))        # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        exp = restate.generate(cfg, W, sample_frames, batch_size=sample_batch, noise=nz, num_steps=NUM_STEPS)
+    heads = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
+    Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
+    pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
+    pl.backward(); vl.backward()
+    dt = time.perf_counter() - t0
+    steps = sample_batch * exp['latents'].shape[1]
+    return dict(value=steps / dt, unit='imagined steps/s', cores=cores, kind='port',
+                sample=f'oracle/restate.py generate(B={sample_batch}, frames={sample_frames}, num_steps={NUM_STEPS}) + learn(ppo) '
+                       f'at dim=512 depth=6: {steps} imagined steps in {dt:.1f} s, torch fp32, {cores} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='skip the per-launch HIP-event timing of the GEMMs')
+    args = ap.parse_args()
+
+    from dreamer4_amd import DreamTrainer, _lib, parallel
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    parallel.init_from_env('nccl')                       # RCCL over xGMI
+    rank = parallel.rank()
+
+    model = build_model(device)
+    parallel.broadcast_parameters(model.parameters())
+    trainer = DreamTrainer(model, batch_size=B_LOCAL, generate_timesteps=HORIZON, objective='ppo', seed=1234,
+                           generate_kwargs=dict(return_for_policy_optimization=True, num_steps=NUM_STEPS))
+    lib = _lib.load()
+
+    for _ in range(args.warmup):
+        trainer.train_step()
+    torch.cuda.synchronize()
+
+    timing = not args.no_kernel_timing
+    if timing:
+        lib.d4_profile_enable(1)
+    gen_ms, learn_ms = [], []
+    frames_total = 0
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
+    for k in range(args.steps):
+        ev[3 * k].record()
+        dreams = trainer.generate()
+        ev[3 * k + 1].record()
+        trainer.learn(dreams)
+        ev[3 * k + 2].record()
+        frames_total += dreams.latents.shape[1]
+    parallel.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if timing:
+        lib.d4_profile_enable(0)
+    for k in range(args.steps):
+        gen_ms.append(ev[3 * k].elapsed_time(ev[3 * k + 1]))
+        learn_ms.append(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]))
+
+    wall_t = torch.tensor([wall], device=device, dtype=torch.float64)
+    parallel.all_reduce_max_(wall_t)
+    wall = float(wall_t.item())
+    steps_done = world * B_LOCAL * frames_total              # every rank generates the same number of frames
+    value = steps_done / wall
+
+    roofline = None
+    if timing:
+        ms = (C.c_double * 3)(); fl = (C.c_double * 3)(); cnt = (C.c_int64 * 3)()
+        _lib.check(lib.d4_profile_read(ms, fl, cnt, 3))
+        names = ['gemm_kernel<128,128> fp32 MFMA', 'gemm_kernel<64,128> fp32 MFMA', 'gemm_kernel<64,64> fp32 MFMA']
+        dom = max(range(3), key=lambda i: ms[i])
+        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.
+        roofline = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, kernel=names[dom],
+                        launches=int(cnt[dom]), avg_launch_us=round(1e3 * ms[dom] / max(cnt[dom], 1), 2),
+                        flops_per_launch=round(fl[dom] / max(cnt[dom], 1)),
+                        all_gemm_classes={names[i]: dict(ms=round(ms[i], 2), tflops=round(fl[i] / max(ms[i], 1e-9) / 1e9, 2), launches=int(cnt[i]))
+                                          for i in range(3)},
+                        rollout_algorithmic_tflops=round(FLOP_PER_IMAGINED_STEP * B_LOCAL * (HORIZON + 1) / (sum(gen_ms) / len(gen_ms) * 1e-3) / 1e12, 2))
+
+    if rank != 0:
+        return
+    out = dict(
+        metric='imagined latent steps/sec', value=round(value, 1), unit='imagined steps/s', n_gpus=world, steps=args.steps,
+        warmup=args.warmup, ms_per_step=round(1e3 * wall / args.steps, 2), higher_is_better=True, scaling='weak',
+        vs_baseline=None, dtype='f32', data='synthetic',
+        config=dict(workload='cfg2 Moving-MNIST-latent shape: dim=512 depth=6 heads=8x64 latents=32x32 spatial=4 registers=8; '
+                             'generate(H+1=16 frames, num_steps=4, time cache) + learn_from_experience(ppo) + clip/AdamW both heads',
+                    global_batch=world * B_LOCAL, per_gpu_batch=B_LOCAL, horizon=HORIZON, num_steps=NUM_STEPS, parallelism=f'dp{world}'),
+        generate_ms=round(sum(gen_ms) / len(gen_ms), 2), actor_critic_step_ms=round(sum(learn_ms) / len(learn_ms), 2),
+        rollout_steps_per_sec=round(world * B_LOCAL * (HORIZON + 1) / (sum(gen_ms) / len(gen_ms) * 1e-3), 1),
+        roofline=roofline,
+    )
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+        out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

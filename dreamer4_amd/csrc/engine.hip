@@ -314,9 +314,12 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
 static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const float* x, int ldx, float* y, int ldy,
                     int rows, hipStream_t s) {
     int rc;
-    if ((rc = gemm_simple(x, ldx, fp.w1, e->D, e->ffh, e->inner_pad, rows, 2 * e->inner_pad, e->D,
-                          GEMM_RMS_ROWSCALE | GEMM_SWIGLU, fp.b1, nullptr, 0, s))) return rc;
-    return gemm_simple(e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, rows, e->D, e->inner_pad, 0, out_b, x, ldx, s);
+    GemmArgs g1{x, ldx, fp.w1, e->D, e->ffh, e->inner_pad, fp.b1, nullptr, 0, rows, 2 * e->inner_pad, e->D,
+                GEMM_RMS_ROWSCALE | GEMM_SWIGLU, RMS_EPS, 2.0 * rows * (2.0 * e->inner) * e->D};
+    if ((rc = gemm(g1, s))) return rc;
+    GemmArgs g2{e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, out_b, x, ldx, rows, e->D, e->inner_pad, 0, RMS_EPS,
+                2.0 * rows * (double)e->D * e->inner};
+    return gemm(g2, s);
 }
 
 static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s) {
@@ -740,6 +743,9 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     }
     return 0;
 }
+
+int d4_profile_enable(int on) { return d4::gemm_profile_enable(on); }
+int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { return d4::gemm_profile_read(ms, flops, count, nclass); }
 
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
     D4_REQUIRE(e && name && ptr, "null argument");

@@ -19,6 +19,7 @@
 // fixed permutation; results are deterministic).
 #include "common.h"
 #include "kernels.h"
+#include <vector>
 
 namespace d4 {
 
@@ -247,6 +248,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream --------------------
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+int gemm_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return 0;
+}
+
+// Sums elapsed time / algorithmic flops / launch count per tile class (0: 128x128, 1: 64x128, 2: 64x64) and clears the log.
+int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass) {
+    for (int i = 0; i < nclass; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    for (auto& r : g_prof) {
+        D4_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        D4_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.cls < nclass) { ms[r.cls] += t; flops[r.cls] += r.flops; count[r.cls] += 1; }
+        g_event_pool.push_back(r.a);
+        g_event_pool.push_back(r.b);
+    }
+    g_prof.clear();
+    return 0;
+}
+
+template <int BM, int BN> struct TileClass { static constexpr int value = BM == 128 ? 0 : (BN == 128 ? 1 : 2); };
+
 template <int BM, int BN, int WGM, int WGN, bool TA, bool TB>
 static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
     const int nblk = cdiv(p.M, BM) * cdiv(p.N, BN);
@@ -257,7 +293,14 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    ProfRec rec{};
+    if (g_prof_on) {
+        rec.a = prof_event(); rec.b = prof_event(); rec.cls = TileClass<BM, BN>::value;
+        rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K;
+        hipEventRecord(rec.a, stream);
+    }
     hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, stream, p);
+    if (g_prof_on) { hipEventRecord(rec.b, stream); g_prof.push_back(rec); }
     D4_LAUNCH_CHECK();
     return 0;
 }

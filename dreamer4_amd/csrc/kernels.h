@@ -24,9 +24,12 @@ struct GemmArgs {
     int M, N, K;
     int flags;
     float rms_eps;
+    double algo_flops = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
+int gemm_profile_enable(int on);
+int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 
 // ------------------------------------------------------------------------------------ small attention
 // One wave per (group, head); head dim 64 (lane = feature).  Covers the space attention of the
