@@ -90,12 +90,114 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self attention over the <= 16 tokens of one frame (the trunk's space layers), LDS-staged.
+// The generic kernel above keeps scores in SGPRs, so softclamp's tanh and the softmax exp are evaluated
+// once per (query, key) by ALL 64 lanes redundantly (225 x tanhf x 64 lanes): it is issue-bound.  Here the
+// 16x16 score matrix is spread over the lanes (lane -> 4 (i, j) pairs), so every transcendental is useful
+// work, and a softmax row is one 16-lane DPP row (row_max16 / row_sum16).
+//   per wave: one (frame, head);  LDS per wave: Q,K [16][68] (+4 pad: conflict-free ds_read_b128), P [16][16]
+constexpr int SA_LD = 68;
+constexpr int SA_WAVE_FLOATS = 2 * 16 * SA_LD + 256;
+
+__global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * SA_WAVE_FLOATS];
+    const int wslot = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wslot;
+    if (wid >= p.groups * p.heads) return;
+    const int g = wid / p.heads, h = wid % p.heads;
+    const int lane = threadIdx.x & 63;
+    const int n = p.nk;                                   // == nq <= 16
+    float* Qs = smem + wslot * SA_WAVE_FLOATS;
+    float* Ks = Qs + 16 * SA_LD;
+    float* Ps = Ks + 16 * SA_LD;
+    const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;
+
+    float V[16], vinv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        V[j] = 0.f; vinv[j] = 0.f;
+        float kj = 0.f, qj = 0.f;
+        if (j < n) {
+            kj = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
+            qj = p.q[g * p.q_group_stride + j * p.q_item_stride + h * 64 + lane];
+            float vj = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+            if (p.vres) {
+                const float vr = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                const float w = sigmoidf(p.mix[g * p.m_group_stride + j * p.m_item_stride + h]);
+                vj = lerp_torch(vj, vr, w);
+            }
+            const float nrm = sqrtf(wave_sum(kj * kj));
+            kj = kj / fmaxf(nrm, 1e-12f) * kscale;
+            V[j] = vj;
+            if (p.belief) vinv[j] = 1.f / fmaxf(sqrtf(wave_sum(vj * vj)), 1e-12f);
+        }
+        Ks[j * SA_LD + lane] = kj;
+        Qs[j * SA_LD + lane] = qj;
+    }
+    // (single wave owns this LDS region: program order + lgkmcnt is enough, no block barrier needed)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // scores: pair (i, j) = (4r + lane/16, lane%16), r = 0..3
+    const int jl = lane & 15, il = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + il;
+        const f32x4* qrow = reinterpret_cast<const f32x4*>(Qs + i * SA_LD);
+        const f32x4* krow = reinterpret_cast<const f32x4*>(Ks + jl * SA_LD);
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 a = qrow[c], b = krow[c];
+            acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+        float sc = acc * 0.125f;
+        if (p.softclamp > 0.f) sc = tanhf(sc / p.softclamp) * p.softclamp;
+        const bool ordinary_q = p.mask_special > 0 && i < n - p.mask_special;
+        if (ordinary_q && jl >= n - p.mask_special) sc = -FLT_MAX;
+        const bool valid = jl < n && i < n;
+        const float m = row_max16(valid ? sc : -FLT_MAX);
+        const float e = valid ? expf(sc - m) : 0.f;
+        const float l = row_sum16(e);
+        Ps[i * 16 + jl] = (i < n) ? e / l : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // out[i][d] = sum_j P[i][j] V[j][d]   (lane = d; P rows are LDS broadcasts)
+    for (int i = 0; i < n; ++i) {
+        const f32x4* prow = reinterpret_cast<const f32x4*>(Ps + i * 16);
+        float o = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 pv = prow[c];
+            o += pv[0] * V[4 * c] + pv[1] * V[4 * c + 1] + pv[2] * V[4 * c + 2] + pv[3] * V[4 * c + 3];
+        }
+        if (p.belief) {
+            // V[i] with a run-time i: select through the (unrolled) register array
+            float vi = 0.f, vs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { vi = (j == i) ? V[j] : vi; vs = (j == i) ? vinv[j] : vs; }
+            const float vn = vi * vs;
+            o -= wave_sum(o * vn) * vn;
+        }
+        if (p.gate) o *= sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
+        p.out[g * p.o_group_stride + i * p.o_item_stride + h * 64 + lane] = o;
+    }
+}
+
 int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.nk >= 1 && p.nk <= 64, "small_attn: nk=%d out of range [1,64]", p.nk);
     D4_REQUIRE(!p.belief || p.nq == p.nk, "small_attn: belief needs self attention");
     const int waves = p.groups * p.heads;
     if (waves == 0) return 0;
     dim3 grid(cdiv(waves, 4)), block(256);
+    if (p.nq == p.nk && p.nk <= 16 && p.nq >= 8 && p.q_group_stride != 0) {
+        hipLaunchKernelGGL(space_attn_kernel, grid, block, 0, stream, p);
+        D4_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.nk <= 16) hipLaunchKernelGGL(small_attn_kernel<16>, grid, block, 0, stream, p);
     else if (p.nk <= 32) hipLaunchKernelGGL(small_attn_kernel<32>, grid, block, 0, stream, p);
     else hipLaunchKernelGGL(small_attn_kernel<64>, grid, block, 0, stream, p);

@@ -19,6 +19,8 @@
 // fixed permutation; results are deterministic).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace d4 {
@@ -26,14 +28,15 @@ namespace d4 {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN, int WGM, int WGN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+template <int BM, int BN, int WGM, int WGN, bool TA, bool TB, bool KTAIL>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
+    constexpr int NT = WGM * WGN * 64;          // threads per block
     constexpr int TM = BM / WGM / 32;
     constexpr int TN = BN / WGN / 32;
     static_assert(TM >= 1 && TN >= 1, "tile");
-    constexpr int A_F4 = BM * BK / 4 / 256;   // float4 per thread per A tile
-    constexpr int B_F4 = BN * BK / 4 / 256;
-    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+    constexpr int A_F4 = BM * BK / 4 / NT;    // float4 per thread per A tile
+    constexpr int B_F4 = BN * BK / 4 / NT;
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for the thread count");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                 // [2][BM][LDS_LD]
@@ -58,66 +61,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int bm0 = (bid / nbn) * BM;
     const int bn0 = (bid % nbn) * BN;
 
-    const float* __restrict__ A = p.A;
-    const float* __restrict__ W = p.W;
+    // Operands are read through buffer descriptors (wave-uniform, built from kernel arguments and the block
+    // index only): out-of-range rows fall outside num_records and return 0 in hardware, so the staging loads are
+    // branch-free; logically-invalid lanes (k tail, partial float4 of a transposed operand) are steered to an
+    // out-of-range offset / masked with selects instead of exec-mask branches around each load.
+    constexpr uint32_t OOB = 0x80000000u;
+    const int rowsA = min(BM, p.M - bm0), rowsB = min(BN, p.N - bn0);
+    const float* baseA = TA ? p.A + bm0 : p.A + (int64_t)bm0 * p.lda;
+    const float* baseB = TB ? p.W + bn0 : p.W + (int64_t)bn0 * p.ldw;
+    const int64_t elemsA = TA ? (int64_t)(p.K - 1) * p.lda + rowsA : (int64_t)(rowsA - 1) * p.lda + p.K;
+    const int64_t elemsB = TB ? (int64_t)(p.K - 1) * p.ldw + rowsB : (int64_t)(rowsB - 1) * p.ldw + p.K;
+    // make the descriptor inputs PROVABLY wave-uniform (readfirstlane), otherwise hipcc wraps every buffer load
+    // in a waterfall loop (cdna_hip_programming.md T20)
+    auto uniform_rsrc = [](const float* base, int64_t bytes) {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(baseA, elemsA * 4);
+    const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(baseB, elemsB * 4);
 
     f32x4 ra[A_F4], rb[B_F4];
     float ssq[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) ssq[i] = 0.f;
 
-    // Global -> register staging.  Non-transposed operand: memory is [rows][K], a thread loads a
-    // float4 along K.  Transposed operand (TA/TB): memory is [K][rows]; a thread loads a float4
-    // along rows and scatters it into LDS.
+    // one operand tile -> registers.  Non-transposed: memory [rows][K], float4 along K.  Transposed: memory
+    // [K][rows], float4 along rows (scattered into LDS by store_tile).
+    auto load_operand = [&](auto& regs, const __amdgpu_buffer_rsrc_t rs, int ld, int rows_valid, int k0, auto trans_tag, auto rows_tag) {
+        constexpr bool T = decltype(trans_tag)::value;
+        constexpr int ROWS = decltype(rows_tag)::value;
+        constexpr int NF4 = ROWS * BK / 4 / NT;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int idx = tid + i * NT;
+            if constexpr (!T) {
+                const int r = idx >> 3, c = (idx & 7) * 4;
+                const int gk = k0 + c;
+                uint32_t off = (uint32_t)((r * ld + gk) * 4);
+                if (KTAIL) off = gk < p.K ? off : OOB;
+                f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+                if (KTAIL) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) v[e] = gk + e < p.K ? v[e] : 0.f;
+                }
+                regs[i] = v;
+            } else {
+                const int kk = idx / (ROWS / 4), c = (idx % (ROWS / 4)) * 4;
+                const int gk = k0 + kk;
+                uint32_t off = (uint32_t)((gk * ld + c) * 4);
+                off = (gk < p.K && c < rows_valid) ? off : OOB;
+                f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+#pragma unroll
+                for (int e = 1; e < 4; ++e) v[e] = c + e < rows_valid ? v[e] : 0.f;
+                regs[i] = v;
+            }
+        }
+    };
     auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (!TA) {
-                int idx = tid + i * 256;
-                int r = idx >> 3, c = (idx & 7) * 4;
-                int gr = bm0 + r, gk = k0 + c;
-                if (gr < p.M && gk < p.K) {
-                    const float* src = A + (int64_t)gr * p.lda + gk;
-                    if (gk + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
-                    else { v[0] = src[0]; if (gk + 1 < p.K) v[1] = src[1]; if (gk + 2 < p.K) v[2] = src[2]; }
-                }
-            } else {
-                int idx = tid + i * 256;
-                int kk = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
-                int gk = k0 + kk, gr = bm0 + c;
-                if (gk < p.K && gr < p.M) {
-                    const float* src = A + (int64_t)gk * p.lda + gr;
-                    if (gr + 3 < p.M) v = *reinterpret_cast<const f32x4*>(src);
-                    else { v[0] = src[0]; if (gr + 1 < p.M) v[1] = src[1]; if (gr + 2 < p.M) v[2] = src[2]; }
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (!TB) {
-                int idx = tid + i * 256;
-                int r = idx >> 3, c = (idx & 7) * 4;
-                int gr = bn0 + r, gk = k0 + c;
-                if (gr < p.N && gk < p.K) {
-                    const float* src = W + (int64_t)gr * p.ldw + gk;
-                    if (gk + 3 < p.K) v = *reinterpret_cast<const f32x4*>(src);
-                    else { v[0] = src[0]; if (gk + 1 < p.K) v[1] = src[1]; if (gk + 2 < p.K) v[2] = src[2]; }
-                }
-            } else {
-                int idx = tid + i * 256;
-                int kk = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
-                int gk = k0 + kk, gr = bn0 + c;
-                if (gk < p.K && gr < p.N) {
-                    const float* src = W + (int64_t)gk * p.ldw + gr;
-                    if (gr + 3 < p.N) v = *reinterpret_cast<const f32x4*>(src);
-                    else { v[0] = src[0]; if (gr + 1 < p.N) v[1] = src[1]; if (gr + 2 < p.N) v[2] = src[2]; }
-                }
-            }
-            rb[i] = v;
-        }
+        load_operand(ra, rsA, p.lda, rowsA, k0, std::integral_constant<bool, TA>{}, std::integral_constant<int, BM>{});
+        load_operand(rb, rsB, p.ldw, rowsB, k0, std::integral_constant<bool, TB>{}, std::integral_constant<int, BN>{});
     };
 
     auto store_tile = [&](int buf) {
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         float* bs = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            int idx = tid + i * 256;
+            int idx = tid + i * NT;
             if constexpr (!TA) {
                 int r = idx >> 3, c = (idx & 7) * 4;
                 *reinterpret_cast<f32x4*>(as + r * LDS_LD + c) = ra[i];
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            int idx = tid + i * 256;
+            int idx = tid + i * NT;
             if constexpr (!TB) {
                 int r = idx >> 3, c = (idx & 7) * 4;
                 *reinterpret_cast<f32x4*>(bs + r * LDS_LD + c) = rb[i];
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 s += dpp_f<0xB1>(s);
                 s += dpp_f<0x4E>(s);
                 s += dpp_f<0x141>(s);   // 8 consecutive lanes share one row
-                int r = (tid + i * 256) >> 3;
+                int r = (tid + i * NT) >> 3;
                 if ((tid & 7) == 0) rowscale_s[r] = rsqrtf(s / (float)p.K + p.rms_eps);
             }
         }
@@ -287,11 +292,12 @@ template <int BM, int BN, int WGM, int WGN, bool TA, bool TB>
 static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
     const int nblk = cdiv(p.M, BM) * cdiv(p.N, BN);
     const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD + BM) * sizeof(float);
-    auto k = gemm_kernel<BM, BN, WGM, WGN, TA, TB>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const bool ktail = (p.K % BK) != 0;
+    auto k = ktail ? gemm_kernel<BM, BN, WGM, WGN, TA, TB, true> : gemm_kernel<BM, BN, WGM, WGN, TA, TB, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[ktail]) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[ktail] = true;
     }
     ProfRec rec{};
     if (g_prof_on) {
@@ -299,7 +305,7 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
         rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K;
         hipEventRecord(rec.a, stream);
     }
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(WGM * WGN * 64), lds, stream, p);
     if (g_prof_on) { hipEventRecord(rec.b, stream); g_prof.push_back(rec); }
     D4_LAUNCH_CHECK();
     return 0;
@@ -310,7 +316,11 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
     const int64_t b128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
     // 256 CUs: prefer the big tile once it yields >= ~1.5 blocks per CU.
-    if (b128 >= 384) return launch_cfg<128, 128, 2, 2, TA, TB>(p, stream);
+    if (b128 >= 384) {
+        // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD at the same LDS
+        // footprint as the 4-wave form -> +6..8 % on the K=512 projections (measured, scratch/gpu_gemm_bench.py)
+        return launch_cfg<128, 128, 2, 4, TA, TB>(p, stream);
+    }
     if (swiglu || (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) >= 256) return launch_cfg<64, 128, 2, 2, TA, TB>(p, stream);
     return launch_cfg<64, 64, 2, 2, TA, TB>(p, stream);
 }
