@@ -225,6 +225,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
             if (gm >= p.M) continue;
             const float rs = (p.flags & GEMM_RMS_ROWSCALE) ? rowscale_s[lr] : 1.f;
             if (swiglu) {
+                static_assert(TN >= 1, "");
                 if constexpr (TN % 2 == 0) {
 #pragma unroll
                     for (int j = 0; j < TN; j += 2) {
@@ -319,6 +320,8 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     if (b128 >= 384) {
         // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD at the same LDS
         // footprint as the 4-wave form -> +6..8 % on the K=512 projections (measured, scratch/gpu_gemm_bench.py)
+        // (the SiLU-GLU epilogue pairs two N sub-tiles inside one wave -> 4 x 2 waves, wave tile 32 x 64)
+        if (swiglu) return launch_cfg<128, 128, 4, 2, TA, TB>(p, stream);
         return launch_cfg<128, 128, 2, 4, TA, TB>(p, stream);
     }
     if (swiglu || (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) >= 256) return launch_cfg<64, 128, 2, 2, TA, TB>(p, stream);
@@ -333,6 +336,7 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0, "gemm: operands must be 16-byte aligned");
     D4_REQUIRE(!((p.flags & GEMM_RMS_ROWSCALE) && ta), "gemm: rms rowscale needs a non-transposed A");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (p.N % 64) != 0), "gemm: swiglu needs N %% 64 == 0 (packed pairs)");
+    D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (ta || tb)), "gemm: swiglu epilogue is forward-only");
     if (!ta && !tb) return launch_t<false, false>(p, stream);
     if (!ta && tb) return launch_t<false, true>(p, stream);
     if (ta && tb) return launch_t<true, true>(p, stream);

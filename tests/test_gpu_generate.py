@@ -163,3 +163,21 @@ def test_full_size_properties_at_baseline_batch():
     c = m.generate(T, batch_size=4, return_for_policy_optimization=True, noise=sub)
     assert torch.equal(c.actions.discrete, a.actions.discrete[100:104])
     close(c.latents, a.latents[100:104], atol=1e-5); close(c.values, a.values[100:104], atol=1e-5)
+
+
+def test_full_size_forward_at_baseline_batch_vs_oracle():
+    """One trunk evaluation at BASELINE's B=256 (M = 3840 token rows): this is the shape at which the GEMM launcher
+    switches to its large-tile configurations, so the oracle comparison has to run at this size too."""
+    from dreamer4_amd import DynamicsWorldModel
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4))
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B = 256
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(B, 1, 32, 32, generator=g)
+    sig = torch.full((B, 1), 32)
+    with torch.no_grad():
+        pred_o, agent_o, _ = restate.wm_forward(cfg, W, lat, sig, 16)
+    pred, (agent, _) = m.cuda()(latents=lat, signal_levels=sig, step_sizes=16)
+    close(pred, pred_o, atol=2e-5); close(agent, agent_o, atol=5e-5)
