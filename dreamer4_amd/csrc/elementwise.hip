@@ -146,6 +146,10 @@ __global__ void assemble_kernel(AssembleArgs p) {
             if (p.tasks) v += p.task_embed[p.tasks[b] * D + d];
         }
         p.tokens[i] = v;
+        if (p.compact) {
+            const int rank = (s >= 1 && s <= p.ns) ? s - 1 : (s == p.S - 1 ? p.ns : -1);
+            if (rank >= 0) p.compact[(f * (p.ns + 1) + rank) * D + d] = v;
+        }
     }
 }
 int assemble_tokens(const AssembleArgs& p, hipStream_t s) {
@@ -158,12 +162,12 @@ int assemble_tokens(const AssembleArgs& p, hipStream_t s) {
 
 // to_latent_pred.0 RMSNorm then the LQAP context RMSNorm (D4:4830-4834, 1993): gathered rows only.
 __global__ __launch_bounds__(256) void gather_space_kernel(const float* tokens, float* out, const float* g0, const float* g1,
-                                                           int frames, int S, int D, int ns, float eps) {
+                                                           int frames, int S, int first, int D, int ns, float eps) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= frames * ns) return;
     const int lane = threadIdx.x & 63;
     const int f = r / ns, j = r % ns;
-    const float* xr = tokens + ((int64_t)f * S + 1 + j) * D;
+    const float* xr = tokens + ((int64_t)f * S + first + j) * D;
     float ss = 0.f;
     for (int c = lane; c < D; c += 64) { float v = xr[c]; ss += v * v; }
     const float r0 = rsqrtf(wave_sum(ss) / (float)D + eps);
@@ -174,9 +178,9 @@ __global__ __launch_bounds__(256) void gather_space_kernel(const float* tokens, 
     for (int c = lane; c < D; c += 64) yr[c] = (xr[c] * r0 * g0[c]) * r1 * g1[c];
 }
 int gather_space_double_norm(const float* tokens, float* out, const float* g0, const float* g1,
-                             int frames, int S, int D, int ns, float eps, hipStream_t s) {
+                             int frames, int S, int first, int D, int ns, float eps, hipStream_t s) {
     if (frames == 0) return 0;
-    hipLaunchKernelGGL(gather_space_kernel, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, D, ns, eps);
+    hipLaunchKernelGGL(gather_space_kernel, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, first, D, ns, eps);
     D4_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,7 @@ struct d4_engine {
     int32_t *action_offsets, *action_sizes;
 
     // ---- activations (workspace)
+    float *cslabs, *xfc;                   // row-compacted hiddens (spatial + agent rows) and final tokens
     float *slabs, *xpool, *proj0, *proj, *att, *ffh, *pool_q, *pool_kv, *pool_att, *cq, *ckv, *catt;
     float *lat_in, *lkv, *latt, *space, *gs, *okv, *oatt, *oproj, *pred, *x_lat;
     int32_t* sig;
@@ -95,7 +96,7 @@ int engine_layout(d4_engine* e, bool assign);
 int engine_resolve(d4_engine* e);
 int engine_prepare(d4_engine* e, hipStream_t s);
 int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
-                   const int64_t* tasks, hipStream_t s);
+                   const int64_t* tasks, bool need_agent, hipStream_t s);
 int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, float* out, int ldo,
                 float* save, hipStream_t s);
 int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s);

@@ -65,6 +65,8 @@ int engine_layout(d4_engine* e, bool assign) {
 
     e->slabs = fl((size_t)e->nslab * M * D);
     e->xpool = fl(M * D);
+    e->cslabs = fl((size_t)e->nslab * Fr * (ns + 1) * D);
+    e->xfc = fl(Fr * (ns + 1) * D);
     e->proj0 = fl(M * e->Nproj0);
     e->proj = fl(M * e->Nproj);
     e->att = fl(M * hd);
@@ -253,6 +255,13 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
     return gemm(g, s);
 }
 
+static int gemm_c2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags,
+                   const float* bias, const float* R, int ldr, float* C2, int S, int ns, double algo, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS, algo};
+    g.C2 = C2; g.ldc2 = N; g.c2_S = S; g.c2_lo = 1; g.c2_hi = 1 + ns;
+    return gemm(g, s);
+}
+
 int engine_prepare(d4_engine* e, hipStream_t s) {
     const d4_config& c = e->c;
     D4_REQUIRE(e->ws != nullptr, "workspace not set");
@@ -312,23 +321,25 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------- forward
 static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const float* x, int ldx, float* y, int ldy,
-                    int rows, hipStream_t s) {
+                    int rows, hipStream_t s, float* y_compact = nullptr) {
     int rc;
     GemmArgs g1{x, ldx, fp.w1, e->D, e->ffh, e->inner_pad, fp.b1, nullptr, 0, rows, 2 * e->inner_pad, e->D,
                 GEMM_RMS_ROWSCALE | GEMM_SWIGLU, RMS_EPS, 2.0 * rows * (2.0 * e->inner) * e->D};
     if ((rc = gemm(g1, s))) return rc;
     GemmArgs g2{e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, out_b, x, ldx, rows, e->D, e->inner_pad, 0, RMS_EPS,
                 2.0 * rows * (double)e->D * e->inner};
+    if (y_compact) { g2.C2 = y_compact; g2.ldc2 = e->D; g2.c2_S = e->S; g2.c2_lo = 1; g2.c2_hi = 1 + e->c.num_spatial_tokens; }
     return gemm(g2, s);
 }
 
-static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s) {
+static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s, const float* hiddens = nullptr) {
+    if (!hiddens) hiddens = e->slabs;
     const d4_config& c = e->c;
     const int D = e->D, hp = e->hp;
     const AttnW& a = e->pools[p];
     int rc;
     if ((rc = gemm_simple(x, D, e->pq_w[p], D, e->pool_q, e->ldpq, M, hp + e->php, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
-    if ((rc = gemm_simple(e->slabs, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
     SmallAttnArgs sa{};
     sa.q = e->pool_q; sa.q_group_stride = e->ldpq; sa.q_item_stride = 0;
     sa.k = e->pool_kv; sa.k_group_stride = 2 * hp; sa.k_item_stride = (int64_t)M * 2 * hp;
@@ -341,9 +352,10 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     return gemm_simple(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, s);
 }
 
-// Inputs expected in e->sig / e->pact (device).  Results: e->pred [B*Tq][n][dl], e->xpool rows (agent = row S-1).
+// Inputs expected in e->sig / e->pact (device).  Results: e->pred [B*Tq][n][dl], e->xfc [B*Tq][ns+1][D] (agent = row ns;
+// only valid when need_agent).
 int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
-                   const int64_t* tasks, hipStream_t s) {
+                   const int64_t* tasks, bool need_agent, hipStream_t s) {
     const d4_config& c = e->c;
     D4_REQUIRE(e->prepared, "engine not prepared");
     D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
@@ -372,6 +384,8 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     // ---- pack tokens (D4:7182-7222)
     float* slab0 = e->slabs;
     auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
+    const int nkeep = ns + 1, Mc = Fr * nkeep;                  // rows the final pool / latent head / agent read
+    auto cslab = [&](int j) { return e->cslabs + (size_t)j * Mc * D; };
     {
         AssembleArgs a{};
         a.tokens = slab0; a.space = e->space; a.signal_embed = e->signal_embed; a.step_embed = e->step_embed;
@@ -380,6 +394,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         a.signal_levels = e->sig; a.prev_actions = e->na > 0 ? e->pact : nullptr; a.tasks = tasks;
         a.action_offsets = e->action_offsets;
         a.B = B; a.Tq = Tq; a.S = S; a.D = D; a.ns = ns; a.nr = c.num_register_tokens; a.na = e->na; a.step_log2 = step_log2;
+        a.compact = e->cslabs;
         D4_REQUIRE(tasks == nullptr || c.num_tasks > 0, "tasks given but num_tasks == 0");
         if ((rc = assemble_tokens(a, s))) return rc;
     }
@@ -418,22 +433,28 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         }
         float* h1 = slab(2 * l + 1);
         float* h2 = slab(2 * l + 2);
-        if ((rc = gemm_simple(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, s))) return rc;
-        if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s))) return rc;
+        if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, ns, 0, s))) return rc;
+        if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2)))) return rc;
         if (l != c.depth - 1) {
             if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s))) return rc;
             x_in = e->xpool;
         }
     }
 
-    // ---- agent token cross-attends its frame, then its own feedforward (D4:3227-3238)
-    float* xf = e->xpool;
-    if ((rc = copy_rows(slab(2 * c.depth), D, xf, D, M, D, s))) return rc;
-    {
-        float* agent_rows = xf + (size_t)(S - 1) * D;
-        const int lda = S * D;
-        if ((rc = gemm_simple(agent_rows, lda, e->cq_w, D, e->cq, e->ldcq, Fr, hd + h, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
-        if ((rc = gemm_simple(xf, D, e->ckv_w, D, e->ckv, 2 * hd, M, 2 * hd, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    // ---- final stage on the compacted rows.  Only the ns spatial tokens (-> latent prediction) and the agent token
+    // (-> heads) of each frame are consumed downstream, and every remaining op is per token, so the final attention
+    // pool runs on (ns + 1) of the S rows per frame — the K/V projection of its 2*depth+1 hiddens is the largest
+    // single GEMM of an evaluation.  xfc [Fr][ns+1][D]: rows 0..ns-1 spatial tokens, row ns the agent token.
+    float* xfc = e->xfc;
+    const float* last = slab(2 * c.depth);
+    if ((rc = copy_rows(cslab(2 * c.depth), D, xfc, D, Mc, D, s))) return rc;
+    if (need_agent) {
+        // agent token cross-attends the non-special tokens of its frame, then its own feedforward (D4:3227-3238)
+        const float* agent_in = last + (size_t)(S - 1) * D;
+        float* agent_rows = xfc + (size_t)ns * D;
+        const int lda = S * D, ldc = nkeep * D;
+        if ((rc = gemm_simple(agent_in, lda, e->cq_w, D, e->cq, e->ldcq, Fr, hd + h, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        if ((rc = gemm_simple(last, D, e->ckv_w, D, e->ckv, 2 * hd, M, 2 * hd, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
         SmallAttnArgs sa{};
         sa.q = e->cq; sa.q_group_stride = e->ldcq; sa.q_item_stride = 0;
         sa.k = e->ckv; sa.k_group_stride = (int64_t)S * 2 * hd; sa.k_item_stride = 2 * hd;
@@ -443,14 +464,14 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         sa.out = e->catt; sa.o_group_stride = hd; sa.o_item_stride = 0;
         sa.groups = Fr; sa.heads = h; sa.nq = 1; sa.nk = S - 1;
         if ((rc = small_attn(sa, s))) return rc;
-        if ((rc = gemm_simple(e->catt, hd, e->cross.to_out, hd, agent_rows, lda, Fr, D, hd, 0, nullptr, agent_rows, lda, s))) return rc;
-        if ((rc = ff_block(e, e->ffp[c.depth], e->sff.out_b, agent_rows, lda, agent_rows, lda, Fr, s))) return rc;
+        if ((rc = gemm_simple(e->catt, hd, e->cross.to_out, hd, agent_rows, ldc, Fr, D, hd, 0, nullptr, agent_in, lda, s))) return rc;
+        if ((rc = ff_block(e, e->ffp[c.depth], e->sff.out_b, agent_rows, ldc, agent_rows, ldc, Fr, s))) return rc;
     }
-    // ---- final attention pool over every layer hidden (D4:3242-3243)
-    if ((rc = pool_block(e, c.depth - 1, xf, xf, e->nslab, M, s))) return rc;
+    // ---- final attention pool over every layer hidden (D4:3242-3243), compact rows
+    if ((rc = pool_block(e, c.depth - 1, xfc, xfc, e->nslab, Mc, s, e->cslabs))) return rc;
 
     // ---- to_latent_pred: RMSNorm -> LQAP (n queries over the ns spatial tokens) -> Linear  (D4:7251)
-    if ((rc = gather_space_double_norm(xf, e->gs, e->latent_norm, e->lq_out.norm_ctx, Fr, S, D, ns, RMS_EPS, s))) return rc;
+    if ((rc = gather_space_double_norm(xfc, e->gs, e->latent_norm, e->lq_out.norm_ctx, Fr, nkeep, 0, D, ns, RMS_EPS, s))) return rc;
     if ((rc = gemm_simple(e->gs, D, e->lout_kv_w, D, e->okv, 2 * hd, Fr * ns, 2 * hd, D, 0, nullptr, nullptr, 0, s))) return rc;
     {
         SmallAttnArgs sa{};
@@ -640,11 +661,12 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
         else D4_HIP(hipMemsetAsync(e->pact, 0xFF, sizeof(int64_t) * Fr * e->na, s));     // -1 => zero token
     }
     const int t0 = use_cache ? e->cache_frames : 0;
-    if ((rc = d4::engine_forward(e, latents, batch, frames, t0, sl, tasks, s))) return rc;
+    if ((rc = d4::engine_forward(e, latents, batch, frames, t0, sl, tasks, true, s))) return rc;
     if (commit_cache) e->cache_frames = t0 + frames;
     const int n_el = e->c.num_latent_tokens * e->c.dim_latent;
     if (pred && (rc = d4::copy_rows(e->pred, n_el, pred, n_el, Fr, n_el, s))) return rc;
-    if (agent_embed && (rc = d4::copy_rows(e->xpool + (size_t)(e->S - 1) * e->D, e->S * e->D, agent_embed, e->D, Fr, e->D, s))) return rc;
+    const int nkeep = e->c.num_spatial_tokens + 1;
+    if (agent_embed && (rc = d4::copy_rows(e->xfc + (size_t)(nkeep - 1) * e->D, nkeep * e->D, agent_embed, e->D, Fr, e->D, s))) return rc;
     return 0;
 }
 
@@ -688,7 +710,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                 lat = e->lat_in;
             }
             if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, Tq, na, cur + 1 - Tq, T, sig_val, c.max_steps - 1, s))) return rc;
-            if ((rc = d4::engine_forward(e, lat, B, Tq, t0, sl, io->tasks, s))) return rc;
+            if ((rc = d4::engine_forward(e, lat, B, Tq, t0, sl, io->tasks, last, s))) return rc;
             if (last) { if (commit) e->cache_frames = t0 + Tq; break; }
             const float tt = (float)sig_val / (float)c.max_steps;
             if ((rc = d4::euler_step(e->x_lat, n_el, e->pred + (size_t)(Tq - 1) * n_el, Tq * n_el, B, n_el,
@@ -696,8 +718,9 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
         }
 
         // ---- heads on the agent embedding of the clean step (D4:6595-6662)
-        const float* agent_row = e->xpool + ((size_t)(Tq - 1) * S + (S - 1)) * D;
-        if ((rc = d4::copy_rows(agent_row, Tq * S * D, e->agent_c, D, B, D, s))) return rc;
+        const int nkeep = c.num_spatial_tokens + 1;
+        const float* agent_row = e->xfc + ((size_t)(Tq - 1) * nkeep + (nkeep - 1)) * D;
+        if ((rc = d4::copy_rows(agent_row, Tq * nkeep * D, e->agent_c, D, B, D, s))) return rc;
         if (io->agent_embed && (rc = d4::copy_rows(e->agent_c, D, io->agent_embed + (size_t)f * D, F * D, B, D, s))) return rc;
         // reward: Ensemble member 0 of [RMSNorm -> Linear]                     D4:6598-6601
         if ((rc = d4::rmsnorm_rows(e->agent_c, D, e->reward_norm, e->hnorm, D, B, D, d4::RMS_EPS, s))) return rc;
@@ -750,7 +773,7 @@ int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { ret
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
     D4_REQUIRE(e && name && ptr, "null argument");
     struct { const char* n; float* p; } tbl[] = {
-        {"slabs", e->slabs}, {"xpool", e->xpool}, {"proj0", e->proj0}, {"proj", e->proj}, {"att", e->att},
+        {"slabs", e->slabs}, {"xpool", e->xpool}, {"xfc", e->xfc}, {"cslabs", e->cslabs}, {"proj0", e->proj0}, {"proj", e->proj}, {"att", e->att},
         {"ffh", e->ffh}, {"pool_q", e->pool_q}, {"pool_kv", e->pool_kv}, {"pool_att", e->pool_att}, {"cq", e->cq},
         {"ckv", e->ckv}, {"catt", e->catt}, {"lkv", e->lkv}, {"latt", e->latt}, {"space", e->space}, {"gs", e->gs},
         {"okv", e->okv}, {"oatt", e->oatt}, {"oproj", e->oproj}, {"pred", e->pred}, {"x_lat", e->x_lat},

@@ -248,6 +248,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
                     if (p.R) v += p.R[(int64_t)gm * p.ldr + gn];
                     if (p.flags & GEMM_ACCUMULATE) v += p.C[(int64_t)gm * p.ldc + gn];
                     p.C[(int64_t)gm * p.ldc + gn] = v;
+                    if (p.C2) {
+                        const int ts = gm % p.c2_S;
+                        const int keep = p.c2_hi - p.c2_lo;
+                        const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : (ts == p.c2_S - 1 ? keep : -1);
+                        if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + 1) + rank) * p.ldc2 + gn] = v;
+                    }
                 }
             }
         }

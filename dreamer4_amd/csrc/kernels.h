@@ -24,7 +24,10 @@ struct GemmArgs {
     int M, N, K;
     int flags;
     float rms_eps;
-    double algo_flops = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
+    double algo_flops = 0;
+    // optional second, row-compacted copy of the output: token rows s = gm % c2_S with c2_lo <= s < c2_hi or s == c2_S - 1
+    // land in C2 at row (gm / c2_S) * (c2_hi - c2_lo + 1) + rank  (the rows the final pool / latent head need)
+    float* C2 = nullptr; int ldc2 = 0, c2_S = 0, c2_lo = 0, c2_hi = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
@@ -92,13 +95,14 @@ struct AssembleArgs {
     const int64_t* tasks;          // [B] or null
     const int32_t* action_offsets; // [na] (device)
     int B, Tq, S, D, ns, nr, na, step_log2;
+    float* compact;                // optional [B*Tq][ns + 1][D]: spatial + agent rows only
 };
 int assemble_tokens(const AssembleArgs& p, hipStream_t s);
 
 // gather the spatial-token rows of every frame, RMSNorm(gamma0) then (statistics only) second RMS for the
 // LQAP context norm folded downstream is NOT possible -> both norms applied here.
 int gather_space_double_norm(const float* tokens, float* out, const float* g0, const float* g1,
-                             int frames, int S, int D, int ns, float eps, hipStream_t s);
+                             int frames, int S, int first, int D, int ns, float eps, hipStream_t s);
 
 int euler_step(float* x, int ldx, const float* pred, int ldp, int B, int n_el, float one_minus_t, float dt, hipStream_t s);
 int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
