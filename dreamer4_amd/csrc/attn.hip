@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
 
     // out[i][d] = sum_j P[i][j] V[j][d]   (lane = d; P rows are LDS broadcasts)
     for (int i = 0; i < n; ++i) {
+        int orank = i;
+        if (p.q_hi > 0) {
+            if (i >= p.q_lo && i < p.q_hi) orank = i - p.q_lo;
+            else if (i == n - 1) orank = p.q_hi - p.q_lo;
+            else continue;
+        }
         const f32x4* prow = reinterpret_cast<const f32x4*>(Ps + i * 16);
         float o = 0.f;
 #pragma unroll
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
             o -= wave_sum(o * vn) * vn;
         }
         if (p.gate) o *= sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
-        p.out[g * p.o_group_stride + i * p.o_item_stride + h * 64 + lane] = o;
+        p.out[g * p.o_group_stride + orank * p.o_item_stride + h * 64 + lane] = o;
     }
 }
 

@@ -67,6 +67,8 @@ int engine_layout(d4_engine* e, bool assign) {
     e->xpool = fl(M * D);
     e->cslabs = fl((size_t)e->nslab * Fr * (ns + 1) * D);
     e->xfc = fl(Fr * (ns + 1) * D);
+    e->xpool_c = fl(Fr * (ns + 1) * D);
+    e->att_c = fl(Fr * (ns + 1) * hd);
     e->proj0 = fl(M * e->Nproj0);
     e->proj = fl(M * e->Nproj);
     e->att = fl(M * hd);
@@ -332,7 +334,8 @@ static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const fl
     return gemm(g2, s);
 }
 
-static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s, const float* hiddens = nullptr) {
+static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s, const float* hiddens = nullptr,
+                      float* y_compact = nullptr) {
     if (!hiddens) hiddens = e->slabs;
     const d4_config& c = e->c;
     const int D = e->D, hp = e->hp;
@@ -349,6 +352,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     sa.out = e->pool_att; sa.o_group_stride = hp; sa.o_item_stride = 0;
     sa.groups = M; sa.heads = c.pool_heads; sa.nq = 1; sa.nk = L;
     if ((rc = small_attn(sa, s))) return rc;
+    if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, e->S, c.num_spatial_tokens, 0, s);
     return gemm_simple(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, s);
 }
 
@@ -429,14 +433,27 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
             sa.out = e->att; sa.o_group_stride = (int64_t)S * hd; sa.o_item_stride = hd;
             sa.groups = Fr; sa.heads = h; sa.nq = S; sa.nk = S;
             sa.softclamp = c.attn_softclamp_value; sa.mask_special = 1; sa.belief = 1;
+            if (!need_agent && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8) {
+                sa.q_lo = 1; sa.q_hi = 1 + ns;
+                sa.out = e->att_c; sa.o_group_stride = (int64_t)nkeep * hd;
+            }
             if ((rc = small_attn(sa, s))) return rc;
+        }
+        // Denoise steps (no agent embedding wanted): nothing downstream reads the last layer's flow / register /
+        // action rows, so its output projection and feedforward run on the compacted rows only.
+        const bool compact_tail = !need_agent && l == c.depth - 1 && !e->is_time[l] && c.depth >= 2 && S <= 16 && S >= 8;
+        if (compact_tail) {
+            if ((rc = gemm_simple(e->att_c, hd, a.to_out, hd, cslab(2 * l + 1), D, Mc, D, hd, 0, nullptr, e->xpool_c, D, s))) return rc;
+            if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, cslab(2 * l + 1), D, cslab(2 * l + 2), D, Mc, s))) return rc;
+            break;
         }
         float* h1 = slab(2 * l + 1);
         float* h2 = slab(2 * l + 2);
         if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, ns, 0, s))) return rc;
         if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2)))) return rc;
         if (l != c.depth - 1) {
-            if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s))) return rc;
+            float* xc = (!need_agent && l == c.depth - 2 && !e->is_time[c.depth - 1] && S <= 16 && S >= 8) ? e->xpool_c : nullptr;
+            if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s, nullptr, xc))) return rc;
             x_in = e->xpool;
         }
     }

@@ -50,6 +50,9 @@ struct SmallAttnArgs {
     float softclamp;      // <= 0 : none
     int mask_special;     // number of trailing "special" keys ordinary queries may not see
     int belief;           // subtract the component of out along l2norm(v_i) (requires nq == nk, self attention)
+    // space_attn only: restrict the QUERIES to tokens [q_lo, q_hi) plus the last token; outputs are written at item
+    // rank (i - q_lo, or q_hi - q_lo for the last token).  q_hi == 0 -> all queries, natural order.
+    int q_lo = 0, q_hi = 0;
 };
 int small_attn(const SmallAttnArgs& p, hipStream_t stream);
 
