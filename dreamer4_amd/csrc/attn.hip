@@ -212,6 +212,94 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// AttentionPool (D4:2143-2177) with the value side restructured (see PoolMixArgs).  One wave per token row.
+template <int ITER>
+__global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
+    constexpr int PH = 4, LMAX = 64;
+    __shared__ float psh[4][LMAX * PH];
+    const int wslot = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wslot;
+    if (m >= p.M) return;
+    const int lane = threadIdx.x & 63;
+    float* ps = psh[wslot];
+    const int L = p.L, D = p.D;
+
+    float qh[PH], ksc[PH], mx[PH];
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        qh[h] = p.q[(int64_t)m * p.ldq + h * 64 + lane];
+        ksc[h] = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;
+        mx[h] = -FLT_MAX;
+    }
+    for (int l = 0; l < L; ++l) {
+        const float* kr = p.k + ((int64_t)l * p.M + m) * p.ldk;
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            const float kv = kr[h * 64 + lane];
+            const float nrm = sqrtf(wave_sum(kv * kv));
+            const float sc = wave_sum(qh[h] * (kv / fmaxf(nrm, 1e-12f) * ksc[h])) * 0.125f;
+            mx[h] = fmaxf(mx[h], sc);
+            if (lane == 0) ps[l * PH + h] = sc;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float den[PH], gate[PH];
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        float d = 0.f;
+        for (int l = 0; l < L; ++l) d += expf(ps[l * PH + h] - mx[h]);
+        den[h] = d;
+        gate[h] = sigmoidf(p.q[(int64_t)m * p.ldq + PH * 64 + h]);
+    }
+    f32x4 acc[PH][ITER];
+#pragma unroll
+    for (int h = 0; h < PH; ++h)
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nf4 = D / 4;
+    for (int l = 0; l < L; ++l) {
+        const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)l * p.M + m) * D);
+        f32x4 v[ITER];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            v[i] = c4 < nf4 ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * gate[h] * rstd;
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        f32x4* ur = reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nf4) ur[c4] = acc[h][i];
+        }
+    }
+}
+
+int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
+    D4_REQUIRE(p.heads == 4, "pool_mix: 4 pool heads expected (AttentionPool default, D4:2147)");
+    D4_REQUIRE(p.L >= 1 && p.L <= 64 && p.D % 4 == 0 && p.D <= 1024, "pool_mix: L=%d D=%d out of range", p.L, p.D);
+    if (p.M == 0) return 0;
+    dim3 grid(cdiv(p.M, 4)), block(256);
+    if (p.D <= 256) hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p);
+    else if (p.D <= 512) hipLaunchKernelGGL(pool_mix_kernel<2>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(pool_mix_kernel<4>, grid, block, 0, stream, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // time axis
 
 __device__ __forceinline__ float rotate_half_lane(float x, int lane, float pos, const float* inv_freq) {

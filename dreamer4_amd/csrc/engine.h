@@ -76,7 +76,7 @@ struct d4_engine {
     int32_t *action_offsets, *action_sizes;
 
     // ---- activations (workspace)
-    float *cslabs, *xfc, *xpool_c, *att_c;                   // row-compacted hiddens (spatial + agent rows) and final tokens
+    float *cslabs, *xfc, *xpool_c, *att_c, *pool_u;                   // row-compacted hiddens (spatial + agent rows) and final tokens
     float *slabs, *xpool, *proj0, *proj, *att, *ffh, *pool_q, *pool_kv, *pool_att, *cq, *ckv, *catt;
     float *lat_in, *lkv, *latt, *space, *gs, *okv, *oatt, *oproj, *pred, *x_lat;
     int32_t* sig;

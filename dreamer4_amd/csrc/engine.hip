@@ -76,6 +76,7 @@ int engine_layout(d4_engine* e, bool assign) {
     e->pool_q = fl(M * e->ldpq);
     e->pool_kv = fl((size_t)e->nslab * M * 2 * hp);
     e->pool_att = fl(M * hp);
+    e->pool_u = fl(M * (size_t)e->php * D);
     e->cq = fl(Fr * e->ldcq);
     e->ckv = fl(M * 2 * hd);
     e->catt = fl(Fr * hd);
@@ -342,6 +343,17 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     const AttnW& a = e->pools[p];
     int rc;
     if ((rc = gemm_simple(x, D, e->pq_w[p], D, e->pool_q, e->ldpq, M, hp + e->php, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    if (c.pool_heads == 4 && D <= 1024) {
+        // keys only: [L*M][hp]; values come from ONE per-head projection of the softmax-weighted normalised hiddens
+        if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, hp, L * M, hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        PoolMixArgs pm{};
+        pm.q = e->pool_q; pm.ldq = e->ldpq; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
+        pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
+        if ((rc = pool_mix(pm, s))) return rc;
+        GemmArgs gv{e->pool_u, c.pool_heads * D, e->pkv_w[p] + (size_t)hp * D, D, e->pool_att, hp, nullptr, nullptr, 0, M, 64, D, 0, RMS_EPS};
+        gv.batch = c.pool_heads; gv.strideA = D; gv.strideW = (int64_t)64 * D; gv.strideC = 64;
+        if ((rc = gemm(gv, s))) return rc;
+    } else {
     if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
     SmallAttnArgs sa{};
     sa.q = e->pool_q; sa.q_group_stride = e->ldpq; sa.q_item_stride = 0;
@@ -352,6 +364,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     sa.out = e->pool_att; sa.o_group_stride = hp; sa.o_item_stride = 0;
     sa.groups = M; sa.heads = c.pool_heads; sa.nq = 1; sa.nk = L;
     if ((rc = small_attn(sa, s))) return rc;
+    }
     if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, e->S, c.num_spatial_tokens, 0, s);
     return gemm_simple(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, s);
 }

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
     // out-of-range offset / masked with selects instead of exec-mask branches around each load.
     constexpr uint32_t OOB = 0x80000000u;
     const int rowsA = min(BM, p.M - bm0), rowsB = min(BN, p.N - bn0);
+    const int bz = blockIdx.y;
+    p.A += bz * p.strideA; p.W += bz * p.strideW; p.C += bz * p.strideC;
+    if (p.R) p.R += bz * p.strideC;
     const float* baseA = TA ? p.A + bm0 : p.A + (int64_t)bm0 * p.lda;
     const float* baseB = TB ? p.W + bn0 : p.W + (int64_t)bn0 * p.ldw;
     const int64_t elemsA = TA ? (int64_t)(p.K - 1) * p.lda + rowsA : (int64_t)(rowsA - 1) * p.lda + p.K;
@@ -309,10 +312,10 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
     ProfRec rec{};
     if (g_prof_on) {
         rec.a = prof_event(); rec.b = prof_event(); rec.cls = TileClass<BM, BN>::value;
-        rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K;
+        rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
         hipEventRecord(rec.a, stream);
     }
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(WGM * WGN * 64), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(nblk, p.batch > 0 ? p.batch : 1), dim3(WGM * WGN * 64), lds, stream, p);
     if (g_prof_on) { hipEventRecord(rec.b, stream); g_prof.push_back(rec); }
     D4_LAUNCH_CHECK();
     return 0;
@@ -321,7 +324,8 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
 template <bool TA, bool TB>
 static int launch_t(const GemmArgs& p, hipStream_t stream) {
     const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
-    const int64_t b128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int nb = p.batch > 0 ? p.batch : 1;
+    const int64_t b128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
     // 256 CUs: prefer the big tile once it yields >= ~1.5 blocks per CU.
     if (b128 >= 384) {
         // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD at the same LDS
@@ -330,7 +334,7 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
         if (swiglu) return launch_cfg<128, 128, 4, 2, TA, TB>(p, stream);
         return launch_cfg<128, 128, 2, 4, TA, TB>(p, stream);
     }
-    if (swiglu || (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) >= 256) return launch_cfg<64, 128, 2, 2, TA, TB>(p, stream);
+    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 256)) return launch_cfg<64, 128, 2, 2, TA, TB>(p, stream);
     return launch_cfg<64, 64, 2, 2, TA, TB>(p, stream);
 }
 

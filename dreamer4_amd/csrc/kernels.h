@@ -27,7 +27,9 @@ struct GemmArgs {
     double algo_flops = 0;
     // optional second, row-compacted copy of the output: token rows s = gm % c2_S with c2_lo <= s < c2_hi or s == c2_S - 1
     // land in C2 at row (gm / c2_S) * (c2_hi - c2_lo + 1) + rank  (the rows the final pool / latent head need)
-    float* C2 = nullptr; int ldc2 = 0, c2_S = 0, c2_lo = 0, c2_hi = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
+    float* C2 = nullptr; int ldc2 = 0, c2_S = 0, c2_lo = 0, c2_hi = 0;
+    // strided batch (blockIdx.y): A += b * strideA, W += b * strideW, C/R += b * strideC   (elements)
+    int batch = 1; int64_t strideA = 0, strideW = 0, strideC = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
@@ -55,6 +57,20 @@ struct SmallAttnArgs {
     int q_lo = 0, q_hi = 0;
 };
 int small_attn(const SmallAttnArgs& p, hipStream_t stream);
+
+// AttentionPool core, value-side restructured: scores over the L hiddens from projected keys, then the softmax-
+// weighted (and gated) sum of the NORMALISED hiddens per head, u[m][h][:] = sigmoid(gate) * sum_l p[l][h] * h_l[m] / rms(h_l[m]);
+// the value projection is then ONE [D -> 64] GEMM per head on u instead of L projections (linear in the hiddens).
+struct PoolMixArgs {
+    const float* q; int ldq;           // [M][ldq]: q @ 0 (heads*64), gate logits @ heads*64
+    const float* k; int ldk;           // [L*M][ldk]: projected keys, row l*M + m
+    const float* hid; int D;           // [L*M][D] hiddens
+    const float* k_gamma;              // [heads][64]
+    float* u;                          // [M][heads][D]
+    int M, L, heads;
+    float eps;
+};
+int pool_mix(const PoolMixArgs& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------ time attention
 // Causal attention along time for every token column (b, s) with a preallocated KV cache.
