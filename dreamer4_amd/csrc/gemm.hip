@@ -25,12 +25,12 @@
 
 namespace d4 {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN, int WGM, int WGN, bool TA, bool TB, bool KTAIL>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
-    constexpr int NT = WGM * WGN * 64;          // threads per block
+template <int BM, int BN, int WGM, int WGN, int BK, int KS, bool TA, bool TB, bool KTAIL>
+__global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
+    constexpr int LDS_LD = BK + 4;
+    constexpr int RF4 = BK / 4;                 // float4 per tile row
+    constexpr int NT = WGM * WGN * 64 * KS;     // threads per block (KS > 1: intra-block split of each k-tile across wave groups)
     constexpr int TM = BM / WGM / 32;
     constexpr int TN = BN / WGN / 32;
     static_assert(TM >= 1 && TN >= 1, "tile");
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) % (WGM * WGN);
+    const int ks = (tid >> 6) / (WGM * WGN);    // which share of the k-steps of every tile this wave group takes
     const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware block order: consecutive blocks on one XCD share the same A row-panel.
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
         for (int i = 0; i < NF4; ++i) {
             const int idx = tid + i * NT;
             if constexpr (!T) {
-                const int r = idx >> 3, c = (idx & 7) * 4;
+                const int r = idx / RF4, c = (idx % RF4) * 4;
                 const int gk = k0 + c;
                 uint32_t off = (uint32_t)((r * ld + gk) * 4);
                 if (KTAIL) off = gk < p.K ? off : OOB;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
         for (int i = 0; i < A_F4; ++i) {
             int idx = tid + i * NT;
             if constexpr (!TA) {
-                int r = idx >> 3, c = (idx & 7) * 4;
+                int r = idx / RF4, c = (idx % RF4) * 4;
                 *reinterpret_cast<f32x4*>(as + r * LDS_LD + c) = ra[i];
                 ssq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
             } else {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
         for (int i = 0; i < B_F4; ++i) {
             int idx = tid + i * NT;
             if constexpr (!TB) {
-                int r = idx >> 3, c = (idx & 7) * 4;
+                int r = idx / RF4, c = (idx % RF4) * 4;
                 *reinterpret_cast<f32x4*>(bs + r * LDS_LD + c) = rb[i];
             } else {
                 int kk = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
         const float* bs = Bs + cur * BN * LDS_LD + (wn * TN * 32 + lrow) * LDS_LD + lhalf * 4;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
+            if (KS > 1 && (q % KS) != ks) continue;
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_LD + q * 8);
@@ -200,6 +202,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
+    // ---- intra-block split-K: fold the partner group's accumulators through LDS (fixed order: group 0 + group 1)
+    if constexpr (KS > 1) {
+        static_assert(KS == 2, "");
+        constexpr int GT = WGM * WGN * 64;
+        float* xch = smem;                       // the operand tiles are dead after the last barrier of the main loop
+        const int gt = tid % GT;
+        if (ks == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) xch[((i * TN + j) * 16 + e) * GT + gt] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += xch[((i * TN + j) * 16 + e) * GT + gt];
+        }
+    }
+
     // ---- per-row 1/rms of A (RMSNorm folded into the GEMM) -----------------------------------
     if (p.flags & GEMM_RMS_ROWSCALE) {
         if constexpr (!TA) {
@@ -208,15 +235,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(GemmArgs p) {
                 float s = ssq[i];
                 s += dpp_f<0xB1>(s);
                 s += dpp_f<0x4E>(s);
-                s += dpp_f<0x141>(s);   // 8 consecutive lanes share one row
-                int r = (tid + i * NT) >> 3;
-                if ((tid & 7) == 0) rowscale_s[r] = rsqrtf(s / (float)p.K + p.rms_eps);
+                s += dpp_f<0x141>(s);   // RF4 (8 or 16) consecutive lanes share one row
+                if (RF4 == 16) s += dpp_f<0x140>(s);
+                int r = (tid + i * NT) / RF4;
+                if ((tid % RF4) == 0) rowscale_s[r] = rsqrtf(s / (float)p.K + p.rms_eps);
             }
         }
         __syncthreads();
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
+    if (KS > 1 && ks != 0) return;
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
 #pragma unroll
@@ -298,12 +327,13 @@ int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass) {
 
 template <int BM, int BN> struct TileClass { static constexpr int value = BM == 128 ? 0 : (BN == 128 ? 1 : 2); };
 
-template <int BM, int BN, int WGM, int WGN, bool TA, bool TB>
+template <int BM, int BN, int WGM, int WGN, int BK, int KS, bool TA, bool TB>
 static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
+    constexpr int LDS_LD = BK + 4;
     const int nblk = cdiv(p.M, BM) * cdiv(p.N, BN);
     const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD + BM) * sizeof(float);
     const bool ktail = (p.K % BK) != 0;
-    auto k = ktail ? gemm_kernel<BM, BN, WGM, WGN, TA, TB, true> : gemm_kernel<BM, BN, WGM, WGN, TA, TB, false>;
+    auto k = ktail ? gemm_kernel<BM, BN, WGM, WGN, BK, KS, TA, TB, true> : gemm_kernel<BM, BN, WGM, WGN, BK, KS, TA, TB, false>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[ktail]) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -315,7 +345,7 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
         rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
         hipEventRecord(rec.a, stream);
     }
-    hipLaunchKernelGGL(k, dim3(nblk, p.batch > 0 ? p.batch : 1), dim3(WGM * WGN * 64), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(nblk, p.batch > 0 ? p.batch : 1), dim3(WGM * WGN * 64 * KS), lds, stream, p);
     if (g_prof_on) { hipEventRecord(rec.b, stream); g_prof.push_back(rec); }
     D4_LAUNCH_CHECK();
     return 0;
@@ -331,11 +361,13 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
         // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD at the same LDS
         // footprint as the 4-wave form -> +6..8 % on the K=512 projections (measured, scratch/gpu_gemm_bench.py)
         // (the SiLU-GLU epilogue pairs two N sub-tiles inside one wave -> 4 x 2 waves, wave tile 32 x 64)
-        if (swiglu) return launch_cfg<128, 128, 4, 2, TA, TB>(p, stream);
-        return launch_cfg<128, 128, 2, 4, TA, TB>(p, stream);
+        if (swiglu) return launch_cfg<128, 128, 4, 2, 32, 1, TA, TB>(p, stream);
+        return launch_cfg<128, 128, 2, 4, 32, 1, TA, TB>(p, stream);
     }
-    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 256)) return launch_cfg<64, 128, 2, 2, TA, TB>(p, stream);
-    return launch_cfg<64, 64, 2, 2, TA, TB>(p, stream);
+    // (measured on MI355X, scratch/gpu_gemm_bench.py: BK = 64 and an intra-block split of the k-steps over 8 waves
+    //  (KS = 2) change these small-tile shapes by < 2 % — they are bound by the ~5 us fixed cost per launch.)
+    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 256)) return launch_cfg<64, 128, 2, 2, 32, 1, TA, TB>(p, stream);
+    return launch_cfg<64, 64, 2, 2, 32, 1, TA, TB>(p, stream);
 }
 
 int gemm(const GemmArgs& p, hipStream_t stream) {
