@@ -48,8 +48,9 @@ def build_model(device):
     return m.to(device)
 
 
-def cpu_baseline(sample_batch=4, sample_frames=3, max_threads=16):
-    """Oracle on the host cores over a bounded sample of the same workload (same architecture, same call shape)."""
+def cpu_baseline(max_threads=16, target_s=12.0):
+    """Oracle on the host cores over a bounded sample of the same workload (same architecture, same call shape).
+    The sample is grown until it costs roughly `target_s` seconds of CPU work (the host's speed is not known up front)."""
     from dreamer4_amd import DynamicsWorldModel
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from util import make_noise, oracle_config, oracle_weights
@@ -62,19 +63,28 @@ def cpu_baseline(sample_batch=4, sample_frames=3, max_threads=16):
     torch.manual_seed(0)
     m = randomize_weights(DynamicsWorldModel(**CFG2), seed=0, terminal_bias=-10.)
     cfg, W = oracle_config(m), oracle_weights(m)
-    nz = make_noise(cfg, sample_frames, sample_batch, 1234)
-    with torch.no_grad():
-        restate.generate(cfg, W, 1, batch_size=1, noise=make_noise(cfg, 1, 1, 1))        # warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
-        exp = restate.generate(cfg, W, sample_frames, batch_size=sample_batch, noise=nz, num_steps=NUM_STEPS)
     heads = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
-    Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
-    pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
-    pl.backward(); vl.backward()
-    dt = time.perf_counter() - t0
-    steps = sample_batch * exp['latents'].shape[1]
+
+    def run(batch, frames):
+        nz = make_noise(cfg, frames, batch, 1234)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            exp = restate.generate(cfg, W, frames, batch_size=batch, noise=nz, num_steps=NUM_STEPS)
+        Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
+        pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
+        pl.backward(); vl.backward()
+        return batch * exp['latents'].shape[1], time.perf_counter() - t0
+
+    run(1, 1)                                           # warm-up (thread pool, allocator)
+    batch, frames = 4, 3
+    steps, dt = run(batch, frames)
+    if dt < 0.5 * target_s:                             # grow once towards the target, bounded
+        scale = min(target_s / max(dt, 1e-3), 64.)
+        frames = min(HORIZON + 1, max(frames, int(frames * min(scale, 4.))))
+        batch = int(min(64, max(batch, batch * scale * 3 / frames)))
+        steps, dt = run(batch, frames)
     return dict(value=steps / dt, unit='imagined steps/s', cores=cores, kind='port',
-                sample=f'oracle/restate.py generate(B={sample_batch}, frames={sample_frames}, num_steps={NUM_STEPS}) + learn(ppo) '
+                sample=f'oracle/restate.py generate(B={batch}, frames={frames}, num_steps={NUM_STEPS}) + learn(ppo) '
                        f'at dim=512 depth=6: {steps} imagined steps in {dt:.1f} s, torch fp32, {cores} threads')
 
 
@@ -109,7 +119,7 @@ def main():
 
     timing = not args.no_kernel_timing
     if timing:
-        lib.d4_profile_enable(1)
+        lib.d4_profile_enable(1)      # 1 = the large-tile GEMM class only (the dominant kernel): keeps the event overhead small
     gen_ms, learn_ms = [], []
     frames_total = 0
     parallel.barrier()

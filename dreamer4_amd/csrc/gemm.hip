@@ -294,7 +294,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream --------------------
 struct ProfRec { hipEvent_t a, b; int cls; double flops; };
-static bool g_prof_on = false;
+static int g_prof_mask = 0;            // bit c set: time launches of tile class c
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 
@@ -305,8 +305,8 @@ static hipEvent_t prof_event() {
     return e;
 }
 
-int gemm_profile_enable(int on) {
-    g_prof_on = on != 0;
+int gemm_profile_enable(int mask) {
+    g_prof_mask = mask;
     return 0;
 }
 
@@ -340,6 +340,7 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
         attr_set[ktail] = true;
     }
     ProfRec rec{};
+    const bool g_prof_on = (g_prof_mask >> TileClass<BM, BN>::value) & 1;
     if (g_prof_on) {
         rec.a = prof_event(); rec.b = prof_event(); rec.cls = TileClass<BM, BN>::value;
         rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);

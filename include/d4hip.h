@@ -177,10 +177,10 @@ int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                   float grad_scale, float* scratch, void* stream);
 
-/* Measurement hook (bench.py roofline leg): when enabled every GEMM launch is bracketed by HIP events on its
- * launch stream; d4_profile_read sums elapsed ms / algorithmic flops / launches per tile class
+/* Measurement hook (bench.py roofline leg): `mask` bit c enables tile class c; every GEMM launch of an enabled class is
+ * bracketed by HIP events on its launch stream; d4_profile_read sums elapsed ms / algorithmic flops / launches per tile class
  * (0: 128x128, 1: 64x128, 2: 64x64 block tiles) and clears the log. */
-int d4_profile_enable(int on);
+int d4_profile_enable(int mask);
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 
 /* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */
