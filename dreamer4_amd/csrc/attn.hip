@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
 constexpr int SA_LD = 68;
 constexpr int SA_WAVE_FLOATS = 2 * 16 * SA_LD + 256;
 
-__global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
+__global__ __launch_bounds__(256, 2) void space_attn_kernel(SmallAttnArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[4 * SA_WAVE_FLOATS];
     const int wslot = threadIdx.x >> 6;
     const int wid = blockIdx.x * 4 + wslot;
@@ -113,27 +113,34 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
     float* Ps = Ks + 16 * SA_LD;
     const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;
 
-    float V[16], vinv[16];
+    // phase 1: issue every global load of the frame before the first dependent reduction (memory-level parallelism:
+    // 4 x n independent 256-byte row loads in flight per wave instead of one load -> wait -> reduce chain per token)
+    float V[16], vinv[16], Kr[16], Qr[16], Rr[16], Wm[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        V[j] = 0.f; vinv[j] = 0.f;
-        float kj = 0.f, qj = 0.f;
+        V[j] = Kr[j] = Qr[j] = Rr[j] = Wm[j] = 0.f;
         if (j < n) {
-            kj = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
-            qj = p.q[g * p.q_group_stride + j * p.q_item_stride + h * 64 + lane];
-            float vj = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+            Kr[j] = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
+            Qr[j] = p.q[g * p.q_group_stride + j * p.q_item_stride + h * 64 + lane];
+            V[j] = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
             if (p.vres) {
-                const float vr = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
-                const float w = sigmoidf(p.mix[g * p.m_group_stride + j * p.m_item_stride + h]);
-                vj = lerp_torch(vj, vr, w);
+                Rr[j] = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                Wm[j] = p.mix[g * p.m_group_stride + j * p.m_item_stride + h];
             }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        vinv[j] = 0.f;
+        float kj = Kr[j];
+        if (j < n) {
+            if (p.vres) V[j] = lerp_torch(V[j], Rr[j], sigmoidf(Wm[j]));
             const float nrm = sqrtf(wave_sum(kj * kj));
             kj = kj / fmaxf(nrm, 1e-12f) * kscale;
-            V[j] = vj;
-            if (p.belief) vinv[j] = 1.f / fmaxf(sqrtf(wave_sum(vj * vj)), 1e-12f);
+            if (p.belief) vinv[j] = 1.f / fmaxf(sqrtf(wave_sum(V[j] * V[j])), 1e-12f);
         }
         Ks[j * SA_LD + lane] = kj;
-        Qs[j * SA_LD + lane] = qj;
+        Qs[j * SA_LD + lane] = Qr[j];
     }
     // (single wave owns this LDS region: program order + lgkmcnt is enough, no block barrier needed)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
