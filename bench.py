@@ -155,8 +155,15 @@ def main():
         names = ['gemm_kernel<128,128> fp32 MFMA', 'gemm_kernel<64,128> fp32 MFMA', 'gemm_kernel<64,64> fp32 MFMA']
         dom = max(range(3), key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.
+        traffic = None           # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate runs)
+        try:
+            pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            if pj.get('kernel') == names[dom]:
+                traffic = pj['hbm_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None, kernel=names[dom],
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, kernel=names[dom],
                         launches=int(cnt[dom]), avg_launch_us=round(1e3 * ms[dom] / max(cnt[dom], 1), 2),
                         flops_per_launch=round(fl[dom] / max(cnt[dom], 1)),
                         all_gemm_classes={names[i]: dict(ms=round(ms[i], 2), tflops=round(fl[i] / max(ms[i], 1e-9) / 1e9, 2), launches=int(cnt[i]))
