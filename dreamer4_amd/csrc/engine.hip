@@ -676,6 +676,14 @@ static int step_log2_of(int step_size, int* out) {
     return 0;
 }
 
+static int check_step_log2(const d4_engine* e, int sl) {
+    int nlog = 0;
+    while ((1 << nlog) < e->c.max_steps) ++nlog;
+    // step_size_embed has log2(max_steps) rows (D4:4896): the reference raises IndexError for step_size == max_steps
+    D4_REQUIRE(sl < nlog, "step size 2^%d has no step_size_embed row (max_steps = %d allows at most 2^%d)", sl, e->c.max_steps, nlog - 1);
+    return 0;
+}
+
 int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_levels, int step_size,
                   const int64_t* prev_actions, const int64_t* tasks, int batch, int frames,
                   int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream) {
@@ -683,6 +691,7 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
     hipStream_t s = static_cast<hipStream_t>(stream);
     int sl, rc;
     if ((rc = step_log2_of(step_size, &sl))) return rc;
+    if ((rc = check_step_log2(e, sl))) return rc;
     D4_REQUIRE(batch <= e->maxB && frames <= e->maxTq, "batch/frames exceed engine capacity");
     const int Fr = batch * frames;
     D4_HIP(hipMemcpyAsync(e->sig, signal_levels, sizeof(int32_t) * Fr, hipMemcpyDeviceToDevice, s));
@@ -716,6 +725,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     const int step_size = c.max_steps / K;
     int sl, rc;
     if ((rc = step_log2_of(step_size, &sl))) return rc;
+    if ((rc = check_step_log2(e, sl))) return rc;
     const int n_el = c.num_latent_tokens * c.dim_latent;
     const int D = e->D, S = e->S, A = e->A, na = e->na;
     if (!io->use_time_cache) e->cache_frames = 0;

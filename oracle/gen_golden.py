@@ -130,6 +130,19 @@ def main():
             exp_dict(f'chain{i}_', e, out)
     noise_dict('chain_', nz, out)
     out['chain_final_kv'] = npy(tc.main.next_kv_cache)
+    # modes without action sampling (D4:6723-6729): plain latents, and rewards-only
+    nz = make_noise(cfg, 4, B, 105)
+    with injected(nz):
+        lat = m.generate(4, batch_size=B)
+    out['plain_latents'] = npy(lat); noise_dict('plain_', nz, out)
+    nz = make_noise(cfg, 4, B, 106)
+    with injected(nz):
+        e = m.generate(4, batch_size=B, return_rewards_per_frame=True, return_terminals=True)
+    out['rewonly_latents'], out['rewonly_rewards'], out['rewonly_agent_embed'] = npy(e.latents), npy(e.rewards), npy(e.agent_embed)
+    out['rewonly_lens'], out['rewonly_terminals'] = npy(e.lens), npy(e.terminals)
+    assert e.actions is None and e.values is None
+    noise_dict('rewonly_', nz, out)
+
     np.savez(os.path.join(OUT, 'generate.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('generate margins', out['cached_margin'], out['nocache_margin'], out['prompt_margin'],
           'lens', out['cached_lens'], out['nocache_lens'], out['prompt_lens'])

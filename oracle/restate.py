@@ -472,7 +472,7 @@ def value_head_bins(cfg, W, agent_embed):
 def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, tasks=None,
              prompt_latents=None, prompt_discrete_actions=None, prompt_rewards=None,
              cache: TrunkCache | None = None, use_time_cache=True, return_terminals=True,
-             context_signal_noise=0.1, discrete_temperature=1.):
+             context_signal_noise=0.1, discrete_temperature=1., sample_actions=True):
     """DynamicsWorldModel.generate(return_rewards_per_frame, return_agent_actions,
     return_log_probs_and_values[, return_terminals]) D4:6308-6774, with every RNG draw injected:
 
@@ -531,6 +531,13 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
             terminals = terminals | is_term
 
         agent_embeds.append(one)
+        if not sample_actions:                                  # return_agent_actions=False (D4:6625): no action conditioning
+            latents = torch.cat((latents, x), dim=1)
+            ctx_noise = torch.cat((ctx_noise, noise['context'][f][:, None]), dim=1)
+            f += 1
+            if return_terminals and cfg.predict_terminals and bool(terminals.all()):
+                break
+            continue
         pe = policy_head(cfg, W, one)
         policy_embeds.append(pe)
         logits = policy_logits(cfg, W, pe)                                         # b 1 A
@@ -548,6 +555,10 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
     latents = latents.clamp(-1., 1.)
     T = latents.shape[1]
     step_mask = torch.arange(T) < lens[:, None]
+    if not sample_actions:
+        return dict(latents=latents, agent_embed=torch.cat(agent_embeds, dim=1), rewards=rewards, lens=lens, terminals=terminals,
+                    is_truncated=~terminals, episode_return=(rewards * step_mask.float()).sum(dim=-1), step_size=step_size,
+                    cache=time_cache, frames_generated=f)
     policy_embeds = torch.cat(policy_embeds, dim=1)
     return dict(
         latents=latents,

@@ -121,6 +121,9 @@ def test_invalid_arguments_raise(GM):
         m.generate(2, num_steps=3)
     with pytest.raises(NotImplementedError):
         m.generate(2, prompt=torch.zeros(1, 3, 8, 8))
+    from dreamer4_amd._lib import D4Error
+    with pytest.raises(D4Error, match='step_size_embed'):        # the reference hits an IndexError in nn.Embedding here
+        m.generate(2, num_steps=1, noise=None)
 
 
 @pytest.mark.parametrize('B', [1, 2])
@@ -181,3 +184,51 @@ def test_full_size_forward_at_baseline_batch_vs_oracle():
         pred_o, agent_o, _ = restate.wm_forward(cfg, W, lat, sig, 16)
     pred, (agent, _) = m.cuda()(latents=lat, signal_levels=sig, step_sizes=16)
     close(pred, pred_o, atol=2e-5); close(agent, agent_o, atol=5e-5)
+
+
+def test_generate_without_action_sampling_vs_reference_fixture(GM):
+    m, G = GM
+    lat = m.generate(4, batch_size=3, noise=golden_noise(G, 'plain_'))
+    close(lat, G['plain_latents'])
+    e = m.generate(4, batch_size=3, return_rewards_per_frame=True, return_terminals=True, noise=golden_noise(G, 'rewonly_'))
+    assert e.actions is None and e.values is None and e.log_probs is None
+    assert e.latents.shape[1] == G['rewonly_latents'].shape[1]
+    close(e.latents, G['rewonly_latents']); close(e.rewards, G['rewonly_rewards']); close(e.agent_embed, G['rewonly_agent_embed'])
+    assert np.array_equal(e.lens.cpu().numpy(), G['rewonly_lens']) and np.array_equal(e.terminals.cpu().numpy(), G['rewonly_terminals'])
+
+
+def test_env_wrapper_usage_pattern_prompt_plus_time_cache():
+    """DynamicsWorldModelWrapper.step (dreamer4/env.py:445-483): one generated frame per call, all previous latents /
+    actions passed back as the prompt together with the carried time cache (BASELINE config 4's driving pattern)."""
+    m = small_model()
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, steps = 2, 4
+    nz = make_noise(cfg, steps, B, 41)
+    m = m.cuda()
+    lat_hist = torch.zeros(B, 0, 6, 8); act_hist = torch.zeros(B, 0, 1, dtype=torch.long)
+    tc, cache = None, None
+    for i in range(steps):
+        sub = {k: v[i:i + 1] for k, v in nz.items()}
+        kw = dict(prompt_latents=lat_hist, prompt_discrete_actions=act_hist) if i > 0 else {}
+        ref = restate.generate(cfg, W, i + 1, batch_size=B, noise=sub, cache=cache, return_terminals=False,
+                               **({k: v.clone() for k, v in kw.items()}))
+        cache = ref['cache']
+        e, tc = m.generate(i + 1, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
+                           return_log_probs_and_values=True, time_cache=tc, return_time_cache=True, noise=sub, **kw)
+        assert tc.frames == i + 1
+        close(e.latents, ref['latents']); close(e.values, ref['values']); close(e.rewards[:, -1:], ref['rewards'][:, -1:])
+        assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
+        lat_hist, act_hist = e.latents.cpu(), e.actions.discrete.cpu()
+
+
+@pytest.mark.parametrize('B,T,K', [(1, 1, 4), (1, 3, 2), (5, 2, 64), (2, 3, 8)])
+def test_edge_shapes_vs_oracle(B, T, K):
+    m = small_model()
+    cfg, W = oracle_config(m), oracle_weights(m)
+    nz = make_noise(cfg, T, B, 13)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, num_steps=K, return_terminals=False)
+    e = m.cuda().generate(T, batch_size=B, num_steps=K, return_rewards_per_frame=True, return_agent_actions=True,
+                          return_log_probs_and_values=True, noise=nz)
+    assert e.step_size == 64 // K
+    close(e.latents, ref['latents']); close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'])
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
