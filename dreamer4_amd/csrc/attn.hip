@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     v = lerp_torch(v, vr, w);
     const float nrm = sqrtf(wave_sum(k * k));
     k = k / fmaxf(nrm, 1e-12f) * ((p.k_gamma[h * 64 + lane] + 1.f) * 8.f);
-    const int pos = p.t0 + tq;
+    const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
     k = rotate_half_lane(k, lane, (float)pos, p.inv_freq);
     const int64_t col = (int64_t)b * p.S + s;
     const int64_t cols = (int64_t)p.cache_batch * p.S;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
     const int hd = p.H * 64;
     const float* pr = p.proj + (int64_t)row * p.ldp;
-    const int pos = p.t0 + tq;
+    const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
     float q = rotate_half_lane(pr[h * 64 + lane], lane, (float)pos, p.inv_freq);
     const int64_t col = (int64_t)b * p.S + s;
     const int64_t cols = (int64_t)p.cache_batch * p.S;

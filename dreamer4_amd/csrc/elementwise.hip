@@ -231,6 +231,22 @@ int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, i
     return 0;
 }
 
+__global__ void fill_sig_kernel(int32_t* sig, int n, int value) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sig[i] = value;
+}
+int fill_sig(int32_t* sig, int n, int value, hipStream_t s) {
+    hipLaunchKernelGGL(fill_sig_kernel, dim3(cdiv(n, 128)), dim3(128), 0, s, sig, n, value);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void set_frame_state_kernel(int* state, int t0) { state[0] = t0; }
+int set_frame_state(int* state, int t0, hipStream_t s) {
+    hipLaunchKernelGGL(set_frame_state_kernel, dim3(1), dim3(1), 0, s, state, t0);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 // engine cache [Lt][2][cache_batch*S][H][Tcap][64]  <->  reference layout (Lt, 2, B*S, H, frames, 64)   D4:2075, 3256
 __global__ void cache_transfer_kernel(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap,
                                       int frames, int to_ext) {

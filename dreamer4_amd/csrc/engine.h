@@ -54,6 +54,12 @@ struct d4_engine {
     size_t ws_bytes = 0, ws_need = 0;
     bool prepared = false;
     int cache_frames = 0;
+    // captured decode frames: key = (batch, num_steps, step_log2, has_tasks) -> executable graph of the K+1 evaluations
+    struct FrameGraph { int B, K, sl, tasks; hipGraphExec_t exec; };
+    std::vector<FrameGraph> graphs;
+    int graph_max_rows = 4096;
+    bool warm = false;
+    hipStream_t capture_stream = nullptr;             // use graphs when batch * tokens_per_frame <= this (launch-bound regime)
 
     // ---- bound (raw) weights
     std::vector<d4::AttnW> layer_attn;
@@ -81,6 +87,8 @@ struct d4_engine {
     float *lat_in, *lkv, *latt, *space, *gs, *okv, *oatt, *oproj, *pred, *x_lat;
     int32_t* sig;
     int64_t* pact;
+    int* fstate;                           // device frame state {t0} read by the time-attention kernels under graph replay
+    int64_t* tasks_dev;                    // engine-owned copy of the task ids (stable address for captured graphs)
     float* cache;
     float *agent_c, *hbuf[2], *hnorm, *rlogits, *term_pool, *term_logit;
 
@@ -96,7 +104,8 @@ int engine_layout(d4_engine* e, bool assign);
 int engine_resolve(d4_engine* e);
 int engine_prepare(d4_engine* e, hipStream_t s);
 int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
-                   const int64_t* tasks, bool need_agent, hipStream_t s);
+                   const int64_t* tasks, bool need_agent, hipStream_t s, const int* t0_dev = nullptr);
+void engine_drop_graphs(d4_engine* e);
 int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, float* out, int ldo,
                 float* save, hipStream_t s);
 int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s);

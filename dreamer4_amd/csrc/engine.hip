@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace d4;
@@ -92,6 +93,8 @@ int engine_layout(d4_engine* e, bool assign) {
     e->x_lat = fl((size_t)e->maxB * n * dl);
     e->sig = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * Fr));
     e->pact = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * Fr * (e->na > 0 ? e->na : 1)));
+    e->fstate = reinterpret_cast<int*>(alloc_bytes(sizeof(int) * 16));
+    e->tasks_dev = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * e->maxB));
     e->cache = fl((size_t)(e->Lt > 0 ? e->Lt : 1) * 2 * e->maxB * S * c.attn_heads * e->Tcap * 64);
 
     int maxdim = 4 * D;
@@ -371,8 +374,13 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
 
 // Inputs expected in e->sig / e->pact (device).  Results: e->pred [B*Tq][n][dl], e->xfc [B*Tq][ns+1][D] (agent = row ns;
 // only valid when need_agent).
+void engine_drop_graphs(d4_engine* e) {
+    for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    e->graphs.clear();
+}
+
 int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
-                   const int64_t* tasks, bool need_agent, hipStream_t s) {
+                   const int64_t* tasks, bool need_agent, hipStream_t s, const int* t0_dev) {
     const d4_config& c = e->c;
     D4_REQUIRE(e->prepared, "engine not prepared");
     D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
@@ -431,6 +439,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
             ta.out = e->att; ta.ldo = hd; ta.B = B; ta.S = S; ta.H = h; ta.Tq = Tq; ta.t0 = t0; ta.Tcap = e->Tcap;
             ta.softclamp = c.attn_softclamp_value;
             ta.cache_batch = e->maxB;
+            ta.t0_dev = t0_dev;
             if ((rc = time_kv_append(ta, s))) return rc;
             if ((rc = time_attn(ta, s))) return rc;
         } else {
@@ -612,12 +621,19 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth);
     d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth);
     d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth);
+    if (const char* gm = getenv("D4_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);     // 0 disables graph replay
     d4::engine_layout(e, false);
     *out = e;
     return 0;
 }
 
-void d4_engine_destroy(d4_engine* e) { delete e; }
+void d4_engine_destroy(d4_engine* e) {
+    if (e) {
+        d4::engine_drop_graphs(e);
+        if (e->capture_stream) (void)hipStreamDestroy(e->capture_stream);
+    }
+    delete e;
+}
 
 size_t d4_engine_workspace_bytes(const d4_engine* e) { return e ? e->ws_need : 0; }
 
@@ -625,6 +641,7 @@ int d4_engine_set_workspace(d4_engine* e, void* p, size_t bytes) {
     D4_REQUIRE(e && p, "null argument");
     D4_REQUIRE(bytes >= e->ws_need, "workspace too small: %zu < %zu bytes", bytes, e->ws_need);
     D4_REQUIRE(((uintptr_t)p % 256) == 0, "workspace must be 256-byte aligned");
+    d4::engine_drop_graphs(e);
     e->ws = static_cast<char*>(p);
     e->ws_bytes = bytes;
     e->prepared = false;
@@ -637,6 +654,7 @@ int d4_engine_bind(d4_engine* e, const char* key, const float* p, float* grad, i
     D4_REQUIRE(((uintptr_t)p % 16) == 0, "tensor '%s' is not 16-byte aligned", key);
     e->bound[key] = d4::Bound{p, grad, numel};
     e->prepared = false;
+    d4::engine_drop_graphs(e);          // captured graphs bake weight addresses
     return 0;
 }
 
@@ -740,6 +758,62 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
         D4_REQUIRE(Tq <= e->maxTq, "a parallel pass over %d frames exceeds max_parallel_frames %d", Tq, e->maxTq);
         if ((rc = d4::copy_rows(io->noise_latent + (size_t)f * B * n_el, n_el, e->x_lat, n_el, B, n_el, s))) return rc;
 
+        // Launch-bound regime (small batch, cached decode): the K+1 evaluations of a frame are replayed from a captured
+        // hipGraph; everything frame dependent they read (rotary / cache position) comes from device memory.
+        const bool graphable = Tq == 1 && B * S <= e->graph_max_rows && !d4::gemm_profile_active() && e->graph_max_rows > 0;
+        if (graphable) {
+            D4_REQUIRE(t0 + 1 <= e->Tcap || e->Lt == 0, "KV cache capacity %d exceeded (%d + 1 frames)", e->Tcap, t0);
+            if ((rc = d4::set_frame_state(e->fstate, t0, s))) return rc;
+            if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, 1, na, cur, T, 0, c.max_steps - 1, s))) return rc;
+            const int64_t* tasks = nullptr;
+            if (io->tasks) {
+                D4_HIP(hipMemcpyAsync(e->tasks_dev, io->tasks, sizeof(int64_t) * B, hipMemcpyDeviceToDevice, s));
+                tasks = e->tasks_dev;
+            }
+            hipGraphExec_t exec = nullptr;
+            for (auto& g : e->graphs) if (g.B == B && g.K == K && g.sl == sl && g.tasks == (tasks != nullptr)) exec = g.exec;
+            if (!exec) {
+                if (!e->warm) {
+                    // first decode frame of this engine: run it eagerly once (function attributes, lazy module load)
+                    e->warm = true;
+                } else {
+                    // capture on an engine-owned stream (the caller's may be the legacy default stream, which cannot
+                    // capture); the instantiated graph is then launched on the caller's stream
+                    if (!e->capture_stream) D4_HIP(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+                    hipStream_t cs = e->capture_stream;
+                    hipGraph_t graph;
+                    D4_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+                    int crc = 0;
+                    for (int step = 0; step <= K && !crc; ++step) {
+                        const int sig_val = step * step_size < c.max_steps - 1 ? step * step_size : c.max_steps - 1;
+                        if ((crc = d4::fill_sig(e->sig, B, sig_val, cs))) break;
+                        if ((crc = d4::engine_forward(e, e->x_lat, B, 1, t0, sl, tasks, step == K, cs, e->fstate))) break;
+                        if (step == K) break;
+                        const float tt = (float)sig_val / (float)c.max_steps;
+                        crc = d4::euler_step(e->x_lat, n_el, e->pred, n_el, B, n_el, 1.f - tt, (float)step_size / (float)c.max_steps, cs);
+                    }
+                    hipError_t ce = hipStreamEndCapture(cs, &graph);
+                    if (crc) { if (ce == hipSuccess) hipGraphDestroy(graph); return crc; }
+                    D4_HIP(ce);
+                    D4_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                    hipGraphDestroy(graph);
+                    e->graphs.push_back({B, K, sl, tasks != nullptr, exec});
+                }
+            }
+            if (exec) {
+                D4_HIP(hipGraphLaunch(exec, s));
+            } else {
+                for (int step = 0; step <= K; ++step) {
+                    const int sig_val = step * step_size < c.max_steps - 1 ? step * step_size : c.max_steps - 1;
+                    if ((rc = d4::fill_sig(e->sig, B, sig_val, s))) return rc;
+                    if ((rc = d4::engine_forward(e, e->x_lat, B, 1, t0, sl, tasks, step == K, s, e->fstate))) return rc;
+                    if (step == K) break;
+                    const float tt = (float)sig_val / (float)c.max_steps;
+                    if ((rc = d4::euler_step(e->x_lat, n_el, e->pred, n_el, B, n_el, 1.f - tt, (float)step_size / (float)c.max_steps, s))) return rc;
+                }
+            }
+            if (commit) e->cache_frames = t0 + 1;
+        } else
         for (int step = 0; step <= K; ++step) {
             const bool last = step == K;
             const int sig_val = step * step_size < c.max_steps - 1 ? step * step_size : c.max_steps - 1;   // D4:6492

@@ -305,6 +305,8 @@ static hipEvent_t prof_event() {
     return e;
 }
 
+bool gemm_profile_active() { return g_prof_mask != 0; }
+
 int gemm_profile_enable(int mask) {
     g_prof_mask = mask;
     return 0;

@@ -34,6 +34,7 @@ struct GemmArgs {
 
 int gemm(const GemmArgs& p, hipStream_t stream);
 int gemm_profile_enable(int on);
+bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 
 // ------------------------------------------------------------------------------------ small attention
@@ -85,6 +86,7 @@ struct TimeAttnArgs {
     float* out; int ldo;                 // rows (b, tq, s), cols h*64 + lane
     int B, S, H, Tq, t0, Tcap;
     int cache_batch;                     // batch capacity the cache was laid out for
+    const int* t0_dev = nullptr;         // when set, the frame offset is read from device memory (hipGraph replay)
     float softclamp;
 };
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream);   // normalise/rotate/mix new K,V -> cache[t0 .. t0+Tq)
@@ -127,6 +129,8 @@ int euler_step(float* x, int ldx, const float* pred, int ldp, int B, int n_el, f
 int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
 int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
                      int hist_stride, int sig_val, int ctx_sig, hipStream_t s);
+int fill_sig(int32_t* sig, int n, int value, hipStream_t s);
+int set_frame_state(int* state, int t0, hipStream_t s);
 int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, hipStream_t s);
 
 // latents input for a parallel (multi-frame) evaluation: context frames lerp(history, ctx_noise, w), last frame = x

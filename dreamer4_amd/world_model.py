@@ -327,6 +327,10 @@ class DynamicsWorldModel(nn.Module):
             if self._engine is not None and lib.d4_engine_cache_frames(self._engine) > 0 and self._live_cache is not None:
                 keep = (self._live_cache, self._live_cache.kv())
             old = caps or (0, 0, 0, 0)
+            # the KV-cache capacity grows geometrically: the env-wrapper pattern (one more frame per call) would otherwise
+            # rebuild the engine (workspace + weight preparation) on every call
+            if frames > old[1]:
+                frames = max(16, 1 << (frames - 1).bit_length())
             caps = (max(batch, old[0]), max(frames, old[1]), max(parallel, old[2]), max(learn_rows, old[3]))
             if self._engine is not None:
                 lib.d4_engine_destroy(self._engine)
@@ -341,6 +345,7 @@ class DynamicsWorldModel(nn.Module):
             _lib.check(lib.d4_engine_set_workspace(eng, C.c_void_p(base + self._ws_off), nbytes))
             self._bound_sig = None
             self._trunk_version = None
+            self._bind_cache = None
             if keep is not None:
                 tc, kv = keep
                 _lib.check(lib.d4_engine_cache_import(eng, _lib.ptr(kv), tc.batch, tc.frames, self._stream()))
@@ -377,6 +382,12 @@ class DynamicsWorldModel(nn.Module):
 
     def _bind(self):
         lib = _lib.load()
+        # fast path (every call): nothing moved and no trunk weight was written since the last bind/prepare
+        cached = getattr(self, '_bind_cache', None)
+        if cached is not None and self._bound_sig is not None:
+            tensors, trunk = cached
+            if all(t.data_ptr() == p for t, p in tensors) and tuple(t._version for t in trunk) == self._trunk_version:
+                return
         groups = dict(policy=self._flatten_group('policy', self.policy_head_parameters()),
                       value=self._flatten_group('value', self.value_head_parameters()))
         grads = {}
@@ -398,10 +409,12 @@ class DynamicsWorldModel(nn.Module):
             self._bound_sig = sig
             self._trunk_version = None
         head_ids = {id(p) for g in groups.values() for p in g['params']}
-        ver = tuple(t._version for t in tensors.values() if id(t) not in head_ids)
+        trunk = [t for t in tensors.values() if id(t) not in head_ids]
+        ver = tuple(t._version for t in trunk)
         if ver != self._trunk_version:
             _lib.check(lib.d4_engine_prepare(self._engine, self._stream()))
             self._trunk_version = ver
+        self._bind_cache = ([(t, t.data_ptr()) for t in tensors.values()], trunk)
 
     def _export_cache(self, tc: TimeCache):
         lib = _lib.load()
