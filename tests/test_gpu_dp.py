@@ -1,0 +1,19 @@
+"""GPU: the data-parallel path end to end (rollout sharding by trajectory, global advantage statistics through the
+d4_learn all-reduce callback, one flat gradient all-reduce per head, clipped AdamW) equals a single process over the
+global batch.  Two ranks share the one MI355X of the test box over gloo; the 8-GPU RCCL run is the driver's."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_equal_one_process_at_the_global_batch():
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29671', os.path.join(ROOT, 'tests', 'dp_gpu_worker.py')]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count('DPGPU_OK_') == 2, out.stdout
