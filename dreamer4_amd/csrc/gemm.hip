@@ -19,6 +19,7 @@
 // fixed permutation; results are deterministic).
 #include "common.h"
 #include "kernels.h"
+#include <math.h>
 #include <stdlib.h>
 #include <type_traits>
 #include <vector>
@@ -329,6 +330,12 @@ int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass) {
 
 template <int BM, int BN> struct TileClass { static constexpr int value = BM == 128 ? 0 : (BN == 128 ? 1 : 2); };
 
+static inline double tile_cost(const GemmArgs& p, int BM, int BN, int slots) {
+    // co-resident blocks share a CU's matrix pipes: a CU's time ~ (blocks it hosts) x (tile area)
+    const double blocks = (double)cdiv(p.M, BM) * cdiv(p.N, BN) * (p.batch > 0 ? p.batch : 1);
+    return ceil(blocks / slots) * BM * BN;
+}
+
 template <int BM, int BN, int WGM, int WGN, int BK, int KS, bool TA, bool TB>
 static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
     constexpr int LDS_LD = BK + 4;
@@ -365,6 +372,10 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
         // footprint as the 4-wave form -> +6..8 % on the K=512 projections (measured, scratch/gpu_gemm_bench.py)
         // (the SiLU-GLU epilogue pairs two N sub-tiles inside one wave -> 4 x 2 waves, wave tile 32 x 64)
         if (swiglu) return launch_cfg<128, 128, 4, 2, 32, 1, TA, TB>(p, stream);
+        // 128 x 96 tiles when they quantise better onto the 256 CUs (e.g. the fused q|k|v projection, N = 1552:
+        // 30 x 13 = 390 tiles of 128 x 128 leave half the CUs with one block and half with two; 30 x 17 = 510 fit once).
+        // The 4-wave 128 x 96 form is ~20 % less efficient per flop than the 8-wave 128 x 128 one, hence the margin.
+        if (!TA && !TB && tile_cost(p, 128, 96, 256) < 0.8 * tile_cost(p, 128, 128, 256)) return launch_cfg<128, 96, 4, 1, 32, 1, TA, TB>(p, stream);
         return launch_cfg<128, 128, 2, 4, 32, 1, TA, TB>(p, stream);
     }
     // (measured on MI355X, scratch/gpu_gemm_bench.py: BK = 64 and an intra-block split of the k-steps over 8 waves
