@@ -231,24 +231,26 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     float* ps = psh[wslot];
     const int L = p.L, D = p.D;
 
-    float qh[PH], ksc[PH], mx[PH];
+    // scores: the 4 heads x 64 features of a key row are exactly one float4 per lane (head = lane / 16), so the
+    // per-head reductions are 16-lane DPP row reductions and all four heads are scored at once
+    const int hh = lane >> 4;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
+    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + lane * 4);
 #pragma unroll
-    for (int h = 0; h < PH; ++h) {
-        qh[h] = p.q[(int64_t)m * p.ldq + h * 64 + lane];
-        ksc[h] = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;
-        mx[h] = -FLT_MAX;
-    }
+    for (int e = 0; e < 4; ++e) g4[e] = (g4[e] + 1.f) * 8.f;
+    float mxl = -FLT_MAX;
     for (int l = 0; l < L; ++l) {
-        const float* kr = p.k + ((int64_t)l * p.M + m) * p.ldk;
-#pragma unroll
-        for (int h = 0; h < PH; ++h) {
-            const float kv = kr[h * 64 + lane];
-            const float nrm = sqrtf(wave_sum(kv * kv));
-            const float sc = wave_sum(qh[h] * (kv / fmaxf(nrm, 1e-12f) * ksc[h])) * 0.125f;
-            mx[h] = fmaxf(mx[h], sc);
-            if (lane == 0) ps[l * PH + h] = sc;
-        }
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
+        const float nrm = sqrtf(row_sum16(kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3]));
+        const float inv = 1.f / fmaxf(nrm, 1e-12f);
+        const float sc = row_sum16(q4[0] * (kv[0] * inv * g4[0]) + q4[1] * (kv[1] * inv * g4[1]) +
+                                   q4[2] * (kv[2] * inv * g4[2]) + q4[3] * (kv[3] * inv * g4[3])) * 0.125f;
+        mxl = fmaxf(mxl, sc);
+        if ((lane & 15) == 0) ps[l * PH + hh] = sc;
     }
+    float mx[PH];
+#pragma unroll
+    for (int h = 0; h < PH; ++h) mx[h] = readlane_f(mxl, h * 16);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float den[PH], gate[PH];
