@@ -267,16 +267,26 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
 #pragma unroll
         for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nf4 = D / 4;
-    for (int l = 0; l < L; ++l) {
+    // hidden rows are software-pipelined one ahead: the next row's loads are in flight while this row is reduced / mixed
+    f32x4 vn[ITER];
+    auto load_row = [&](int l, f32x4 (&dst)[ITER]) {
         const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)l * p.M + m) * D);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            dst[i] = c4 < nf4 ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_row(0, vn);
+    for (int l = 0; l < L; ++l) {
         f32x4 v[ITER];
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
-            const int c4 = lane + 64 * i;
-            v[i] = c4 < nf4 ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[i] = vn[i];
             ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
         }
+        if (l + 1 < L) load_row(l + 1, vn);
         const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
 #pragma unroll
         for (int h = 0; h < PH; ++h) {
