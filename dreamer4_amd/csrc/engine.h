@@ -79,6 +79,7 @@ struct d4_engine {
     std::vector<float*> pq_w, pkv_w;
     float *cq_w, *ckv_w;
     float *lin_kv_w, *lin_q, *lin_gate, *lout_kv_w, *lout_q, *lout_gate, *qtmp;
+    float *lout_w;                         // [dl][hd] = to_latent_pred.2.weight @ to_latent_pred.1.attn.to_out.weight
     int32_t *action_offsets, *action_sizes;
 
     // ---- activations (workspace)

@@ -61,6 +61,7 @@ int engine_layout(d4_engine* e, bool assign) {
     e->lout_q = fl((size_t)n * hd);
     e->lout_gate = fl((size_t)n * c.attn_heads);
     e->qtmp = fl((size_t)(n > ns ? n : ns) * D);
+    e->lout_w = fl((size_t)dl * hd);
     e->action_offsets = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
     e->action_sizes = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
 
@@ -314,6 +315,9 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
     if ((rc = rmsnorm_rows(e->lq_out_queries, D, e->lq_out.norm, e->qtmp, D, n, D, RMS_EPS, s))) return rc;
     if ((rc = gemm_simple(e->qtmp, D, e->lq_out.to_q, D, e->lout_q, hd, n, hd, D, 0, nullptr, nullptr, 0, s))) return rc;
     if ((rc = gemm_simple(e->qtmp, D, e->lq_out.to_gates, D, e->lout_gate, h, n, h, D, 0, nullptr, nullptr, 0, s))) return rc;
+    // the pool's output projection and the latent Linear are back-to-back linear maps with nothing in between
+    // (D4:2068, 4833): fold them, W[dl][hd] = W_latent[dl][D] . W_out[D][hd]
+    if ((rc = gemm_simple(e->latent_w, D, e->lq_out.to_out, hd, e->lout_w, hd, dl, hd, D, GEMM_TRANS_B, nullptr, nullptr, 0, s))) return rc;
 
     int32_t offs[D4_MAX_ACTION_TYPES] = {0}, sizes[D4_MAX_ACTION_TYPES] = {0};
     int o = 0;
@@ -523,8 +527,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         sa.groups = Fr; sa.heads = h; sa.nq = n; sa.nk = ns;
         if ((rc = small_attn(sa, s))) return rc;
     }
-    if ((rc = gemm_simple(e->oatt, hd, e->lq_out.to_out, hd, e->oproj, D, Fr * n, D, hd, 0, nullptr, nullptr, 0, s))) return rc;
-    if ((rc = gemm_simple(e->oproj, D, e->latent_w, D, e->pred, dl, Fr * n, dl, D, 0, nullptr, nullptr, 0, s))) return rc;
+    if ((rc = gemm_simple(e->oatt, hd, e->lout_w, hd, e->pred, dl, Fr * n, dl, hd, 0, nullptr, nullptr, 0, s))) return rc;
     return 0;
 }
 
