@@ -212,6 +212,24 @@ int silu_rows(const float* z, float* y, int64_t n, hipStream_t s) {
     return 0;
 }
 
+__global__ void splitk_reduce_kernel(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy) {
+    const int64_t n = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i % N);
+        float v = 0.f;
+        for (int k = 0; k < S; ++k) v += part[(int64_t)k * n + i];
+        if (bias) v += bias[c];
+        if (silu) v = siluf(v);
+        y[(int64_t)r * ldy + c] = v;
+    }
+}
+int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy, hipStream_t s) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid1d((int64_t)M * N), dim3(256), 0, s, part, S, M, N, bias, silu, y, ldy);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 // per-evaluation integer inputs: signal level of every frame and the action token source   D4:6492-6523
 __global__ void prep_inputs_kernel(int32_t* sig, int64_t* pact, const int64_t* hist, int B, int Tq, int na, int frame_base,
                                    int hist_stride, int sig_val, int ctx_sig) {

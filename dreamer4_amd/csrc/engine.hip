@@ -108,6 +108,7 @@ int engine_layout(d4_engine* e, bool assign) {
     e->rlogits = fl((size_t)e->maxB * c.reward_num_bins);
     e->term_pool = fl((size_t)e->maxB * dl);
     e->term_logit = fl(e->maxB);
+    e->splitk = fl(hb * 8);                // split-K partials of the head GEMMs (up to 8 K-slices)
 
     // learner
     e->LR = c.max_learn_rows;
@@ -562,7 +563,16 @@ int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, f
             continue;
         } else {
             if ((rc = rmsnorm_rows(cur, ld, m.g[i], xhat, din, rows, din, RMS_EPS, s))) return rc;
-            if ((rc = gemm_simple(xhat, din, m.w[i], din, y, ldy, rows, dout, din, last ? 0 : GEMM_SILU, m.b[i], nullptr, 0, s))) return rc;
+            // few rows x long K (B x 2048 x 2048): a handful of 64 x 64 tiles would each walk all of K serially on a
+            // fraction of the CUs -> slice K across the grid (batched GEMM over K-slices) and combine in fixed order
+            int S = 1;
+            while (S < 8 && din % (2 * S * 32) == 0 && din / (2 * S) >= 256 && (int64_t)cdiv(rows, 64) * cdiv(dout, 64) * S < 1024) S *= 2;
+            if (S > 1 && rows <= e->maxB) {
+                GemmArgs g{xhat, din, m.w[i], din, e->splitk, dout, nullptr, nullptr, 0, rows, dout, din / S, 0, RMS_EPS};
+                g.batch = S; g.strideA = din / S; g.strideW = din / S; g.strideC = (int64_t)rows * dout;
+                if ((rc = gemm(g, s))) return rc;
+                if ((rc = splitk_reduce(e->splitk, S, rows, dout, m.b[i], last ? 0 : 1, y, ldy, s))) return rc;
+            } else if ((rc = gemm_simple(xhat, din, m.w[i], din, y, ldy, rows, dout, din, last ? 0 : GEMM_SILU, m.b[i], nullptr, 0, s))) return rc;
         }
         cur = y; ld = ldy;
     }

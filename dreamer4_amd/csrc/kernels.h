@@ -127,6 +127,8 @@ int gather_space_double_norm(const float* tokens, float* out, const float* g0, c
 
 int euler_step(float* x, int ldx, const float* pred, int ldp, int B, int n_el, float one_minus_t, float dt, hipStream_t s);
 int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
+// y[m][n] = act(sum_s part[s][m][n] + bias[n])   (split-K combine, fixed order)
+int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy, hipStream_t s);
 int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
                      int hist_stride, int sig_val, int ctx_sig, hipStream_t s);
 int fill_sig(int32_t* sig, int n, int value, hipStream_t s);
