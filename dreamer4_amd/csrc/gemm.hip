@@ -367,7 +367,8 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     const int nb = p.batch > 0 ? p.batch : 1;
     const int64_t b128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
     // 256 CUs: prefer the big tile once it yields >= ~1.5 blocks per CU.
-    if (b128 >= 384) {
+    // (long-K backward GEMMs, dW = dZ^T X with K = batch*time rows: one big tile per CU beats two rounds of small ones)
+    if (b128 >= 384 || (b128 >= 192 && p.K >= 2048)) {
         // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD at the same LDS
         // footprint as the 4-wave form -> +6..8 % on the K=512 projections (measured, scratch/gpu_gemm_bench.py)
         // (the SiLU-GLU epilogue pairs two N sub-tiles inside one wave -> 4 x 2 waves, wave tile 32 x 64)
