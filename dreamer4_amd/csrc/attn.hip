@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(SmallAttnArgs p) {
         int orank = i;
         if (p.q_hi > 0) {
             if (i >= p.q_lo && i < p.q_hi) orank = i - p.q_lo;
-            else if (i == n - 1) orank = p.q_hi - p.q_lo;
+            else if (p.q_last && i == n - 1) orank = p.q_hi - p.q_lo;
             else continue;
         }
         const f32x4* prow = reinterpret_cast<const f32x4*>(Ps + i * 16);
@@ -349,8 +349,9 @@ __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     k = k / fmaxf(nrm, 1e-12f) * ((p.k_gamma[h * 64 + lane] + 1.f) * 8.f);
     const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
     k = rotate_half_lane(k, lane, (float)pos, p.inv_freq);
-    const int64_t col = (int64_t)b * p.S + s;
-    const int64_t cols = (int64_t)p.cache_batch * p.S;
+    const int cS = p.cache_S > 0 ? p.cache_S : p.S;
+    const int64_t col = (int64_t)b * cS + s;
+    const int64_t cols = (int64_t)p.cache_batch * cS;
     const int64_t off = ((col * p.H + h) * p.Tcap + pos) * 64 + lane;
     p.cache[off] = k;
     p.cache[cols * p.H * p.Tcap * 64 + off] = v;
@@ -367,8 +368,9 @@ __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const float* pr = p.proj + (int64_t)row * p.ldp;
     const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
     float q = rotate_half_lane(pr[h * 64 + lane], lane, (float)pos, p.inv_freq);
-    const int64_t col = (int64_t)b * p.S + s;
-    const int64_t cols = (int64_t)p.cache_batch * p.S;
+    const int cS = p.cache_S > 0 ? p.cache_S : p.S;
+    const int64_t col = (int64_t)b * cS + s;
+    const int64_t cols = (int64_t)p.cache_batch * cS;
     const float* ck = p.cache + ((col * p.H + h) * p.Tcap) * 64 + lane;
     const float* cv = ck + cols * p.H * p.Tcap * 64;
 

@@ -147,8 +147,8 @@ __global__ void assemble_kernel(AssembleArgs p) {
         }
         p.tokens[i] = v;
         if (p.compact) {
-            const int rank = (s >= 1 && s <= p.ns) ? s - 1 : (s == p.S - 1 ? p.ns : -1);
-            if (rank >= 0) p.compact[(f * (p.ns + 1) + rank) * D + d] = v;
+            const int rank = (s >= 1 && s <= p.ns) ? s - 1 : ((p.has_agent && s == p.S - 1) ? p.ns : -1);
+            if (rank >= 0) p.compact[(f * (p.ns + p.has_agent) + rank) * D + d] = v;
         }
     }
 }

@@ -264,9 +264,9 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
 }
 
 static int gemm_c2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags,
-                   const float* bias, const float* R, int ldr, float* C2, int S, int ns, double algo, hipStream_t s) {
-    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS, algo};
-    g.C2 = C2; g.ldc2 = N; g.c2_S = S; g.c2_lo = 1; g.c2_hi = 1 + ns;
+                   const float* bias, const float* R, int ldr, float* C2, int S, int ns, int has_agent, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS, 0};
+    g.C2 = C2; g.ldc2 = N; g.c2_S = S; g.c2_lo = 1; g.c2_hi = 1 + ns; g.c2_last = has_agent;
     return gemm(g, s);
 }
 
@@ -332,19 +332,19 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------- forward
 static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const float* x, int ldx, float* y, int ldy,
-                    int rows, hipStream_t s, float* y_compact = nullptr) {
+                    int rows, hipStream_t s, float* y_compact = nullptr, int S = 0, int has_agent = 1) {
     int rc;
     GemmArgs g1{x, ldx, fp.w1, e->D, e->ffh, e->inner_pad, fp.b1, nullptr, 0, rows, 2 * e->inner_pad, e->D,
                 GEMM_RMS_ROWSCALE | GEMM_SWIGLU, RMS_EPS, 2.0 * rows * (2.0 * e->inner) * e->D};
     if ((rc = gemm(g1, s))) return rc;
     GemmArgs g2{e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, out_b, x, ldx, rows, e->D, e->inner_pad, 0, RMS_EPS,
                 2.0 * rows * (double)e->D * e->inner};
-    if (y_compact) { g2.C2 = y_compact; g2.ldc2 = e->D; g2.c2_S = e->S; g2.c2_lo = 1; g2.c2_hi = 1 + e->c.num_spatial_tokens; }
+    if (y_compact) { g2.C2 = y_compact; g2.ldc2 = e->D; g2.c2_S = S; g2.c2_lo = 1; g2.c2_hi = 1 + e->c.num_spatial_tokens; g2.c2_last = has_agent; }
     return gemm(g2, s);
 }
 
 static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s, const float* hiddens = nullptr,
-                      float* y_compact = nullptr) {
+                      float* y_compact = nullptr, int S = 0, int has_agent = 1) {
     if (!hiddens) hiddens = e->slabs;
     const d4_config& c = e->c;
     const int D = e->D, hp = e->hp;
@@ -373,7 +373,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     sa.groups = M; sa.heads = c.pool_heads; sa.nq = 1; sa.nk = L;
     if ((rc = small_attn(sa, s))) return rc;
     }
-    if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, e->S, c.num_spatial_tokens, 0, s);
+    if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, S, c.num_spatial_tokens, has_agent, s);
     return gemm_simple(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, s);
 }
 
@@ -391,7 +391,11 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
     D4_REQUIRE(Tq >= 1 && Tq <= e->maxTq, "parallel frames %d exceed max_parallel_frames %d", Tq, e->maxTq);
     D4_REQUIRE(t0 + Tq <= e->Tcap || e->Lt == 0, "KV cache capacity %d exceeded (%d + %d frames)", e->Tcap, t0, Tq);
-    const int D = e->D, hd = e->hd, h = c.attn_heads, S = e->S;
+    // Denoise evaluations (no agent embedding wanted) drop the agent token altogether: it is the one special token, no
+    // ordinary query may attend to it (D4:1781), time attention is per token column, and its own outputs are only read
+    // by the heads of the clean step -> nothing consumed downstream depends on it.  S = tokens present per frame.
+    const int has_agent = need_agent ? 1 : 0;
+    const int D = e->D, hd = e->hd, h = c.attn_heads, S = need_agent ? e->S : e->S - 1;
     const int n = c.num_latent_tokens, dl = c.dim_latent, ns = c.num_spatial_tokens;
     const int Fr = B * Tq, M = Fr * S;
     int rc;
@@ -414,7 +418,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     // ---- pack tokens (D4:7182-7222)
     float* slab0 = e->slabs;
     auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
-    const int nkeep = ns + 1, Mc = Fr * nkeep;                  // rows the final pool / latent head / agent read
+    const int nkeep = ns + has_agent, Mc = Fr * nkeep;          // rows the final pool / latent head / agent read
     auto cslab = [&](int j) { return e->cslabs + (size_t)j * Mc * D; };
     {
         AssembleArgs a{};
@@ -424,7 +428,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         a.signal_levels = e->sig; a.prev_actions = e->na > 0 ? e->pact : nullptr; a.tasks = tasks;
         a.action_offsets = e->action_offsets;
         a.B = B; a.Tq = Tq; a.S = S; a.D = D; a.ns = ns; a.nr = c.num_register_tokens; a.na = e->na; a.step_log2 = step_log2;
-        a.compact = e->cslabs;
+        a.compact = e->cslabs; a.has_agent = has_agent;
         D4_REQUIRE(tasks == nullptr || c.num_tasks > 0, "tasks given but num_tasks == 0");
         if ((rc = assemble_tokens(a, s))) return rc;
     }
@@ -440,10 +444,10 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         if (e->is_time[l]) {
             TimeAttnArgs ta{};
             ta.proj = P; ta.ldp = ldp; ta.vres = vres; ta.ldv = e->Nproj0; ta.k_gamma = a.k_gamma; ta.inv_freq = e->inv_freq;
-            ta.cache = e->cache + (size_t)e->time_index[l] * 2 * e->maxB * S * h * e->Tcap * 64;
+            ta.cache = e->cache + (size_t)e->time_index[l] * 2 * e->maxB * e->S * h * e->Tcap * 64;
             ta.out = e->att; ta.ldo = hd; ta.B = B; ta.S = S; ta.H = h; ta.Tq = Tq; ta.t0 = t0; ta.Tcap = e->Tcap;
             ta.softclamp = c.attn_softclamp_value;
-            ta.cache_batch = e->maxB;
+            ta.cache_batch = e->maxB; ta.cache_S = e->S;
             ta.t0_dev = t0_dev;
             if ((rc = time_kv_append(ta, s))) return rc;
             if ((rc = time_attn(ta, s))) return rc;
@@ -459,9 +463,9 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
             sa.k_gamma = a.k_gamma;
             sa.out = e->att; sa.o_group_stride = (int64_t)S * hd; sa.o_item_stride = hd;
             sa.groups = Fr; sa.heads = h; sa.nq = S; sa.nk = S;
-            sa.softclamp = c.attn_softclamp_value; sa.mask_special = 1; sa.belief = 1;
+            sa.softclamp = c.attn_softclamp_value; sa.mask_special = has_agent; sa.belief = 1;
             if (!need_agent && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8) {
-                sa.q_lo = 1; sa.q_hi = 1 + ns;
+                sa.q_lo = 1; sa.q_hi = 1 + ns; sa.q_last = 0;
                 sa.out = e->att_c; sa.o_group_stride = (int64_t)nkeep * hd;
             }
             if ((rc = small_attn(sa, s))) return rc;
@@ -476,11 +480,11 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         }
         float* h1 = slab(2 * l + 1);
         float* h2 = slab(2 * l + 2);
-        if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, ns, 0, s))) return rc;
-        if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2)))) return rc;
+        if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, ns, has_agent, s))) return rc;
+        if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2), S, has_agent))) return rc;
         if (l != c.depth - 1) {
             float* xc = (!need_agent && l == c.depth - 2 && !e->is_time[c.depth - 1] && S <= 16 && S >= 8) ? e->xpool_c : nullptr;
-            if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s, nullptr, xc))) return rc;
+            if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s, nullptr, xc, S, has_agent))) return rc;
             x_in = e->xpool;
         }
     }

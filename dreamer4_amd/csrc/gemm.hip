@@ -284,8 +284,8 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
                     if (p.C2) {
                         const int ts = gm % p.c2_S;
                         const int keep = p.c2_hi - p.c2_lo;
-                        const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : (ts == p.c2_S - 1 ? keep : -1);
-                        if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + 1) + rank) * p.ldc2 + gn] = v;
+                        const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : ((p.c2_last && ts == p.c2_S - 1) ? keep : -1);
+                        if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + p.c2_last) + rank) * p.ldc2 + gn] = v;
                     }
                 }
             }

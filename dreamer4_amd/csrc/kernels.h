@@ -27,7 +27,7 @@ struct GemmArgs {
     double algo_flops = 0;
     // optional second, row-compacted copy of the output: token rows s = gm % c2_S with c2_lo <= s < c2_hi or s == c2_S - 1
     // land in C2 at row (gm / c2_S) * (c2_hi - c2_lo + 1) + rank  (the rows the final pool / latent head need)
-    float* C2 = nullptr; int ldc2 = 0, c2_S = 0, c2_lo = 0, c2_hi = 0;
+    float* C2 = nullptr; int ldc2 = 0, c2_S = 0, c2_lo = 0, c2_hi = 0, c2_last = 1;    // c2_last = 0: the frame has no trailing agent row
     // strided batch (blockIdx.y): A += b * strideA, W += b * strideW, C/R += b * strideC   (elements)
     int batch = 1; int64_t strideA = 0, strideW = 0, strideC = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
 };
@@ -55,7 +55,7 @@ struct SmallAttnArgs {
     int belief;           // subtract the component of out along l2norm(v_i) (requires nq == nk, self attention)
     // space_attn only: restrict the QUERIES to tokens [q_lo, q_hi) plus the last token; outputs are written at item
     // rank (i - q_lo, or q_hi - q_lo for the last token).  q_hi == 0 -> all queries, natural order.
-    int q_lo = 0, q_hi = 0;
+    int q_lo = 0, q_hi = 0, q_last = 1;   // q_last = 0: do not add the last token to the restricted query set
 };
 int small_attn(const SmallAttnArgs& p, hipStream_t stream);
 
@@ -86,6 +86,7 @@ struct TimeAttnArgs {
     float* out; int ldo;                 // rows (b, tq, s), cols h*64 + lane
     int B, S, H, Tq, t0, Tcap;
     int cache_batch;                     // batch capacity the cache was laid out for
+    int cache_S = 0;                     // tokens per frame the cache was laid out for (0: same as S)
     const int* t0_dev = nullptr;         // when set, the frame offset is read from device memory (hipGraph replay)
     float softclamp;
 };
@@ -116,7 +117,8 @@ struct AssembleArgs {
     const int64_t* tasks;          // [B] or null
     const int32_t* action_offsets; // [na] (device)
     int B, Tq, S, D, ns, nr, na, step_log2;
-    float* compact;                // optional [B*Tq][ns + 1][D]: spatial + agent rows only
+    float* compact;                // optional [B*Tq][ns (+ 1)][D]: spatial (+ agent) rows only
+    int has_agent;                 // 0: the frame is packed without its trailing agent token (S = tokens actually present)
 };
 int assemble_tokens(const AssembleArgs& p, hipStream_t s);
 
