@@ -13,8 +13,9 @@ Weights: default init of that architecture under torch.manual_seed(0) with non-t
 the timed region.  Rank 0 prints ONE JSON line.
 
   value        = N * B * (H+1) * K / wall     imagined steps per second over the WHOLE step (rollout + learner)
-  roofline     = the dominant kernel (fp32 MFMA GEMM, 128x128 tile class): algorithmic flops of its launches in
-                 the timed region / their summed HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak
+  roofline     = the dominant kernel (the fp32 MFMA GEMM tile configuration with the largest share of GPU time, found in the
+                 warm-up step): algorithmic flops of its launches in the timed region / their summed HIP-event durations,
+                 against the 157.3 TFLOP/s fp32 matrix peak
   cpu_baseline = the CPU oracle (oracle/restate.py, torch fp32, all host cores) on a bounded sample of the same
                  workload, rank 0 at N=1 only.  Reported baseline, not the target.
 """
@@ -36,6 +37,7 @@ CFG2 = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8,
             num_spatial_tokens=4, num_register_tokens=8, max_steps=64, multi_token_pred_len=8, num_discrete_actions=4)
 B_LOCAL, HORIZON, NUM_STEPS = 256, 15, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+EVENT_STRIDE = 8                       # timed region: every 8th launch of the dominant GEMM configuration carries an event pair
 FLOP_PER_IMAGINED_STEP = 5.23e9        # GEMM flops per generated frame of one trajectory (cfg 2)
 
 
@@ -113,13 +115,31 @@ def main():
                            generate_kwargs=dict(return_for_policy_optimization=True, num_steps=NUM_STEPS))
     lib = _lib.load()
 
-    for _ in range(args.warmup):
+    timing = not args.no_kernel_timing
+    ncls = lib.d4_profile_classes()
+    names = [lib.d4_profile_class_name(i).decode() + ', false, false, *> fp32 MFMA' for i in range(ncls)]
+    # warm-up: first-use tile autotuning of every GEMM shape happens here; the last warm-up step is also used to find the
+    # dominant tile configuration (all configurations event-timed), so that the timed region only carries events for it
+    dom, warm_classes = None, None
+    for w in range(args.warmup):
+        last = timing and w == args.warmup - 1
+        if last:
+            torch.cuda.synchronize()
+            lib.d4_profile_enable((1 << ncls) - 1)
         trainer.train_step()
+        if last:
+            torch.cuda.synchronize()
+            lib.d4_profile_enable(0)
+            ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
+            _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
+            dom = max(range(ncls), key=lambda i: ms[i])
+            warm_classes = {names[i]: dict(ms=round(ms[i], 2), tflops=round(fl[i] / max(ms[i], 1e-9) / 1e9, 2), launches=int(cnt[i]))
+                            for i in range(ncls) if cnt[i]}
     torch.cuda.synchronize()
 
-    timing = not args.no_kernel_timing
     if timing:
-        lib.d4_profile_enable(1)      # 1 = the large-tile GEMM class only (the dominant kernel): keeps the event overhead small
+        # the dominant configuration only: keeps the event overhead in the timed region small (--warmup 0: all of them)
+        lib.d4_profile_enable(((1 << dom) if dom is not None else (1 << ncls) - 1) | (EVENT_STRIDE << 16))
     gen_ms, learn_ms = [], []
     frames_total = 0
     parallel.barrier()
@@ -150,10 +170,10 @@ def main():
 
     roofline = None
     if timing:
-        ms = (C.c_double * 3)(); fl = (C.c_double * 3)(); cnt = (C.c_int64 * 3)()
-        _lib.check(lib.d4_profile_read(ms, fl, cnt, 3))
-        names = ['gemm_kernel<128,128> fp32 MFMA', 'gemm_kernel<64,128> fp32 MFMA', 'gemm_kernel<64,64> fp32 MFMA']
-        dom = max(range(3), key=lambda i: ms[i])
+        ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
+        _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
+        if dom is None:
+            dom = max(range(ncls), key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.
         traffic = None           # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate runs)
         try:
@@ -164,10 +184,9 @@ def main():
             pass
         roofline = dict(bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, kernel=names[dom],
-                        launches=int(cnt[dom]), avg_launch_us=round(1e3 * ms[dom] / max(cnt[dom], 1), 2),
+                        launches_timed=int(cnt[dom]), event_stride=EVENT_STRIDE, avg_launch_us=round(1e3 * ms[dom] / max(cnt[dom], 1), 2),
                         flops_per_launch=round(fl[dom] / max(cnt[dom], 1)),
-                        all_gemm_classes={names[i]: dict(ms=round(ms[i], 2), tflops=round(fl[i] / max(ms[i], 1e-9) / 1e9, 2), launches=int(cnt[i]))
-                                          for i in range(3)},
+                        all_gemm_configs_one_warmup_step=warm_classes,
                         rollout_algorithmic_tflops=round(FLOP_PER_IMAGINED_STEP * B_LOCAL * (HORIZON + 1) / (sum(gen_ms) / len(gen_ms) * 1e-3) / 1e12, 2))
 
     if rank != 0:

@@ -18,9 +18,13 @@
 // operand for four consecutive k-steps is one ds_read_b128 (summation order inside a k-tile is a
 // fixed permutation; results are deterministic).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "kernels.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <map>
+#include <tuple>
 #include <type_traits>
 #include <vector>
 
@@ -88,7 +92,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(baseA, elemsA * 4);
     const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(baseB, elemsB * 4);
 
-    f32x4 ra[A_F4], rb[B_F4];
+    // Two register sets for the global->LDS staging: the loads of k-tile j+2 are in flight while k-tile j+1 (loaded one
+    // iteration earlier, certainly arrived) is written to the other LDS buffer in the shadow of the MFMAs of tile j.
+    f32x4 ra[2][A_F4], rb[2][B_F4];
     float ssq[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) ssq[i] = 0.f;
@@ -125,37 +131,41 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
             }
         }
     };
-    auto load_tile = [&](int k0) {
-        load_operand(ra, rsA, p.lda, rowsA, k0, std::integral_constant<bool, TA>{}, std::integral_constant<int, BM>{});
-        load_operand(rb, rsB, p.ldw, rowsB, k0, std::integral_constant<bool, TB>{}, std::integral_constant<int, BN>{});
+    auto load_tile = [&](int k0, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        load_operand(ra[SET], rsA, p.lda, rowsA, k0, std::integral_constant<bool, TA>{}, std::integral_constant<int, BM>{});
+        load_operand(rb[SET], rsB, p.ldw, rowsB, k0, std::integral_constant<bool, TB>{}, std::integral_constant<int, BN>{});
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         float* as = As + buf * BM * LDS_LD;
         float* bs = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             int idx = tid + i * NT;
+            const f32x4 v = ra[SET][i];
             if constexpr (!TA) {
                 int r = idx / RF4, c = (idx % RF4) * 4;
-                *reinterpret_cast<f32x4*>(as + r * LDS_LD + c) = ra[i];
-                ssq[i] += ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
+                *reinterpret_cast<f32x4*>(as + r * LDS_LD + c) = v;
+                ssq[i] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
             } else {
                 int kk = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) as[(c + e) * LDS_LD + kk] = ra[i][e];
+                for (int e = 0; e < 4; ++e) as[(c + e) * LDS_LD + kk] = v[e];
             }
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             int idx = tid + i * NT;
+            const f32x4 v = rb[SET][i];
             if constexpr (!TB) {
                 int r = idx / RF4, c = (idx % RF4) * 4;
-                *reinterpret_cast<f32x4*>(bs + r * LDS_LD + c) = rb[i];
+                *reinterpret_cast<f32x4*>(bs + r * LDS_LD + c) = v;
             } else {
                 int kk = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bs[(c + e) * LDS_LD + kk] = rb[i][e];
+                for (int e = 0; e < 4; ++e) bs[(c + e) * LDS_LD + kk] = v[e];
             }
         }
     };
@@ -168,22 +178,23 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, Set0{});
+    store_tile(0, Set0{});
+    if (nk > 1) load_tile(BK, Set0{});            // k-tile j lives in register set (j - 1) & 1 until it is staged
+    if (nk > 2) load_tile(2 * BK, Set1{});
     __syncthreads();
 
     const int lrow = lane & 31;
     const int lhalf = lane >> 5;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
-
+    auto mfma_steps = [&](int cur, int q0, int q1) {
         const float* as = As + cur * BM * LDS_LD + (wm * TM * 32 + lrow) * LDS_LD + lhalf * 4;
         const float* bs = Bs + cur * BN * LDS_LD + (wn * TN * 32 + lrow) * LDS_LD + lhalf * 4;
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
+        for (int q = q0; q < q1; ++q) {
             if (KS > 1 && (q % KS) != ks) continue;
             f32x4 af[TM], bf[TN];
 #pragma unroll
@@ -198,9 +209,18 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+    auto iteration = [&](int kt, auto set_tag) {
+        const int cur = kt & 1;
+        mfma_steps(cur, 0, 1);
+        if (kt + 1 < nk) store_tile(cur ^ 1, set_tag);          // k-tile kt+1: in registers since the previous iteration
+        if (kt + 3 < nk) load_tile((kt + 3) * BK, set_tag);     // refill the set just drained
+        mfma_steps(cur, 1, BK / 8);
         __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        iteration(kt, Set0{});
+        if (kt + 1 < nk) iteration(kt + 1, Set1{});
     }
 
     // ---- intra-block split-K: fold the partner group's accumulators through LDS (fixed order: group 0 + group 1)
@@ -235,8 +255,8 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
             for (int i = 0; i < A_F4; ++i) {
                 float s = ssq[i];
                 s += dpp_f<0xB1>(s);
-                s += dpp_f<0x4E>(s);
-                s += dpp_f<0x141>(s);   // RF4 (8 or 16) consecutive lanes share one row
+                s += dpp_f<0x4E>(s);    // RF4 (4, 8 or 16) consecutive lanes share one row
+                if (RF4 >= 8) s += dpp_f<0x141>(s);
                 if (RF4 == 16) s += dpp_f<0x140>(s);
                 int r = (tid + i * NT) / RF4;
                 if ((tid % RF4) == 0) rowscale_s[r] = rsqrtf(s / (float)p.K + p.rms_eps);
@@ -294,8 +314,10 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream --------------------
-struct ProfRec { hipEvent_t a, b; int cls; double flops; };
-static int g_prof_mask = 0;            // bit c set: time launches of tile class c
+struct ProfRec { hipEvent_t a, b; int cls; double flops; int M, N, K, flags, batch, bm, bn; };
+static int g_prof_mask = 0;            // bit c set: time launches of tile configuration c
+static int g_prof_stride = 1;          // ... every g_prof_stride-th of them
+static int g_prof_tick = 0;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
 
@@ -309,6 +331,9 @@ static hipEvent_t prof_event() {
 bool gemm_profile_active() { return g_prof_mask != 0; }
 
 int gemm_profile_enable(int mask) {
+    g_prof_stride = (mask >> 16) > 0 ? (mask >> 16) : 1;
+    mask &= 0xFFFF;
+    g_prof_tick = 0;
     g_prof_mask = mask;
     return 0;
 }
@@ -316,19 +341,35 @@ int gemm_profile_enable(int mask) {
 // Sums elapsed time / algorithmic flops / launch count per tile class (0: 128x128, 1: 64x128, 2: 64x64) and clears the log.
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass) {
     for (int i = 0; i < nclass; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    // D4_GEMM_LOG=1: also print a per-shape table (launches, total ms, TFLOP/s) to stderr
+    static const bool log_shapes = getenv("D4_GEMM_LOG") != nullptr;
+    struct Agg { ProfRec r; double ms, fl; int64_t n; };
+    std::vector<Agg> shapes;
     for (auto& r : g_prof) {
         D4_HIP(hipEventSynchronize(r.b));
         float t = 0.f;
         D4_HIP(hipEventElapsedTime(&t, r.a, r.b));
         if (r.cls < nclass) { ms[r.cls] += t; flops[r.cls] += r.flops; count[r.cls] += 1; }
+        if (log_shapes) {
+            bool hit = false;
+            for (auto& a : shapes)
+                if (a.r.M == r.M && a.r.N == r.N && a.r.K == r.K && a.r.flags == r.flags && a.r.batch == r.batch) { a.ms += t; a.fl += r.flops; a.n += 1; hit = true; break; }
+            if (!hit) shapes.push_back(Agg{r, t, r.flops, 1});
+        }
         g_event_pool.push_back(r.a);
         g_event_pool.push_back(r.b);
+    }
+    if (log_shapes) {
+        double tot = 0;
+        for (auto& a : shapes) tot += a.ms;
+        for (auto& a : shapes)
+            fprintf(stderr, "[d4 gemm] M %6d N %5d K %5d batch %2d flags %3d tile %3dx%-3d : %6lld launches %9.3f ms (%5.1f %%) avg %7.1f us %6.1f TF/s\n",
+                    a.r.M, a.r.N, a.r.K, a.r.batch, a.r.flags, a.r.bm, a.r.bn, (long long)a.n, a.ms, 100 * a.ms / tot, 1e3 * a.ms / a.n, a.fl / a.ms / 1e9);
     }
     g_prof.clear();
     return 0;
 }
 
-template <int BM, int BN> struct TileClass { static constexpr int value = BM == 128 ? 0 : (BN == 128 ? 1 : 2); };
 
 static inline double tile_cost(const GemmArgs& p, int BM, int BN, int slots) {
     // co-resident blocks share a CU's matrix pipes: a CU's time ~ (blocks it hosts) x (tile area)
@@ -337,7 +378,7 @@ static inline double tile_cost(const GemmArgs& p, int BM, int BN, int slots) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int KS, bool TA, bool TB>
-static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
+static int launch_cfg(const GemmArgs& p, hipStream_t stream, int cls) {
     constexpr int LDS_LD = BK + 4;
     const int nblk = cdiv(p.M, BM) * cdiv(p.N, BN);
     const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD + BM) * sizeof(float);
@@ -349,40 +390,156 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream) {
         attr_set[ktail] = true;
     }
     ProfRec rec{};
-    const bool g_prof_on = (g_prof_mask >> TileClass<BM, BN>::value) & 1;
+    const bool g_prof_on = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
     if (g_prof_on) {
-        rec.a = prof_event(); rec.b = prof_event(); rec.cls = TileClass<BM, BN>::value;
+        rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+        rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.flags = p.flags; rec.batch = p.batch; rec.bm = BM; rec.bn = BN;
         rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
-        hipEventRecord(rec.a, stream);
+        // the two events ride on the dispatch itself (its begin / end timestamps): no extra barrier packets on the stream,
+        // and the elapsed time is the kernel's own duration (what rocprofv3 --kernel-trace reports)
+        hipExtLaunchKernelGGL(k, dim3(nblk, p.batch > 0 ? p.batch : 1), dim3(WGM * WGN * 64 * KS), (uint32_t)lds, stream, rec.a, rec.b, 0, p);
+        g_prof.push_back(rec);
+    } else {
+        hipLaunchKernelGGL(k, dim3(nblk, p.batch > 0 ? p.batch : 1), dim3(WGM * WGN * 64 * KS), lds, stream, p);
     }
-    hipLaunchKernelGGL(k, dim3(nblk, p.batch > 0 ? p.batch : 1), dim3(WGM * WGN * 64 * KS), lds, stream, p);
-    if (g_prof_on) { hipEventRecord(rec.b, stream); g_prof.push_back(rec); }
     D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- tile configurations and their selection ---------------------------------------------------------------
+// All configurations walk k in the same order with the same MFMA, so every output element is the same
+// bit pattern whichever one runs: the choice is a pure performance decision.
+enum TileCfg { T128x128_2x4 = 0, T128x128_4x2, T128x96_4x1, T64x128_2x2, T64x64_2x2, T256x128_4x4, T64x128_k16, T64x64_k16, N_TILE_CFG };
+static const char* const kTileName[N_TILE_CFG] = {"128x128/2x4", "128x128/4x2", "128x96/4x1", "64x128/2x2", "64x64/2x2", "256x128/4x4", "64x128/2x2/k16", "64x64/2x2/k16"};
+
+// rocprofv3 shows the instantiation as d4::gemm_kernel<BM, BN, WGM, WGN, BK, 1, transA, transB, ktail>
+static const char* const kTileKernel[N_TILE_CFG] = {
+    "gemm_kernel<128, 128, 2, 4, 32, 1", "gemm_kernel<128, 128, 4, 2, 32, 1", "gemm_kernel<128, 96, 4, 1, 32, 1", "gemm_kernel<64, 128, 2, 2, 32, 1",
+    "gemm_kernel<64, 64, 2, 2, 32, 1", "gemm_kernel<256, 128, 4, 4, 32, 1", "gemm_kernel<64, 128, 2, 2, 16, 1", "gemm_kernel<64, 64, 2, 2, 16, 1"};
+int gemm_profile_classes() { return N_TILE_CFG; }
+const char* gemm_profile_class_name(int c) { return c >= 0 && c < N_TILE_CFG ? kTileKernel[c] : ""; }
+
+template <bool TA, bool TB>
+static bool cfg_valid(int id, const GemmArgs& p) {
+    const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+    switch (id) {
+        case T128x128_2x4: return !swiglu;
+        case T128x128_4x2: return true;
+        case T128x96_4x1: return !swiglu && !TA && !TB;
+        case T64x128_2x2: return true;
+        case T64x64_2x2: return !swiglu;
+        case T256x128_4x4: return !swiglu && !TA && !TB;
+        case T64x128_k16: return !TA && !TB;
+        case T64x64_k16: return !swiglu && !TA && !TB;
+    }
+    return false;
+}
+
+template <bool TA, bool TB>
+static int launch_id(int id, const GemmArgs& p, hipStream_t stream) {
+    switch (id) {
+        // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD
+        case T128x128_2x4: return launch_cfg<128, 128, 2, 4, 32, 1, TA, TB>(p, stream, id);
+        // (the SiLU-GLU epilogue pairs two N sub-tiles inside one wave -> 4 x 2 waves, wave tile 32 x 64)
+        case T128x128_4x2: return launch_cfg<128, 128, 4, 2, 32, 1, TA, TB>(p, stream, id);
+        case T128x96_4x1:
+            if constexpr (!TA && !TB) return launch_cfg<128, 96, 4, 1, 32, 1, TA, TB>(p, stream, id);
+            break;
+        case T64x128_2x2: return launch_cfg<64, 128, 2, 2, 32, 1, TA, TB>(p, stream, id);
+        case T64x64_2x2: return launch_cfg<64, 64, 2, 2, 32, 1, TA, TB>(p, stream, id);
+        case T256x128_4x4:
+            if constexpr (!TA && !TB) return launch_cfg<256, 128, 4, 4, 32, 1, TA, TB>(p, stream, id);
+            break;
+        case T64x128_k16:
+            if constexpr (!TA && !TB) return launch_cfg<64, 128, 2, 2, 16, 1, TA, TB>(p, stream, id);
+            break;
+        case T64x64_k16:
+            if constexpr (!TA && !TB) return launch_cfg<64, 64, 2, 2, 16, 1, TA, TB>(p, stream, id);
+            break;
+    }
+    D4_REQUIRE(false, "gemm: tile configuration %d not available for this operand layout", id);
+}
+
+// Static choice (used for shapes that cannot be timed: tiny, non-idempotent, or first seen under stream capture).
+template <bool TA, bool TB>
+static int heuristic_cfg(const GemmArgs& p) {
+    const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+    const int nb = p.batch > 0 ? p.batch : 1;
+    const int64_t b128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
+    // 256 CUs: prefer the big tile once it yields >= ~1.5 blocks per CU; long-K backward GEMMs (dW = dZ^T X with
+    // K = batch*time rows) take it earlier: one big tile per CU beats two rounds of small ones.
+    if (b128 >= 360 || (b128 >= 192 && p.K >= 2048)) {
+        if (swiglu) return T128x128_4x2;
+        // 128 x 96 tiles when they quantise better onto the 256 CUs (the fused q|k|v projection, N = 1552: 30 x 13 = 390
+        // tiles of 128 x 128 leave half the CUs with one block and half with two; 30 x 17 = 510 fit once).
+        if (!TA && !TB && tile_cost(p, 128, 96, 256) < 0.8 * tile_cost(p, 128, 128, 256)) return T128x96_4x1;
+        return T128x128_2x4;
+    }
+    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 256)) return T64x128_2x2;
+    return T64x64_2x2;
+}
+
+// Shape -> configuration, filled by timing every valid configuration the first time a shape is seen (the engine's
+// shapes are fixed by (batch, frames, config), a few dozen in all).  D4_GEMM_AUTOTUNE=0 keeps the static choice.
+struct TuneKey {
+    int M, N, K, flags, batch;
+    bool operator<(const TuneKey& o) const { return std::tie(M, N, K, flags, batch) < std::tie(o.M, o.N, o.K, o.flags, o.batch); }
+};
+static std::map<TuneKey, int> g_tuned;
+
+template <bool TA, bool TB>
+static int autotune(const GemmArgs& p, hipStream_t stream, int* best_out) {
+    hipEvent_t e0 = prof_event(), e1 = prof_event();
+    const int saved_mask = g_prof_mask;
+    g_prof_mask = 0;
+    int best = -1, rc = 0;
+    float best_ms = 0.f;
+    for (int id = 0; id < N_TILE_CFG && !rc; ++id) {
+        if (!cfg_valid<TA, TB>(id, p)) continue;
+        if ((id == T256x128_4x4 || id == T128x128_2x4 || id == T128x128_4x2) && (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * (p.batch > 0 ? p.batch : 1) < 64) continue;
+        if ((rc = launch_id<TA, TB>(id, p, stream))) break;              // warm (attribute set, code resident)
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2 && !rc; ++rep) {                       // best of two timed pairs
+            hipEventRecord(e0, stream);
+            if ((rc = launch_id<TA, TB>(id, p, stream))) break;
+            if ((rc = launch_id<TA, TB>(id, p, stream))) break;
+            hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+            float t = 0.f;
+            hipEventElapsedTime(&t, e0, e1);
+            ms = t < ms ? t : ms;
+        }
+        if (!rc && (best < 0 || ms < best_ms)) { best = id; best_ms = ms; }
+    }
+    g_prof_mask = saved_mask;
+    g_event_pool.push_back(e0);
+    g_event_pool.push_back(e1);
+    if (rc) return rc;
+    D4_REQUIRE(best >= 0, "gemm: no tile configuration for M=%d N=%d K=%d flags=%d", p.M, p.N, p.K, p.flags);
+    if (getenv("D4_GEMM_LOG"))
+        fprintf(stderr, "[d4 gemm] tuned M %6d N %5d K %5d batch %2d flags %3d -> %s (%.1f us)\n", p.M, p.N, p.K, p.batch, p.flags, kTileName[best], 500.f * best_ms);
+    *best_out = best;
     return 0;
 }
 
 template <bool TA, bool TB>
 static int launch_t(const GemmArgs& p, hipStream_t stream) {
-    const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+    static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
     const int nb = p.batch > 0 ? p.batch : 1;
-    const int64_t b128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
-    // 256 CUs: prefer the big tile once it yields >= ~1.5 blocks per CU.
-    // (long-K backward GEMMs, dW = dZ^T X with K = batch*time rows: one big tile per CU beats two rounds of small ones)
-    if (b128 >= 384 || (b128 >= 192 && p.K >= 2048)) {
-        // 8 waves (2 x 4, wave tile 64 x 32): two co-resident blocks put 4 waves on every SIMD at the same LDS
-        // footprint as the 4-wave form -> +6..8 % on the K=512 projections (measured, scratch/gpu_gemm_bench.py)
-        // (the SiLU-GLU epilogue pairs two N sub-tiles inside one wave -> 4 x 2 waves, wave tile 32 x 64)
-        if (swiglu) return launch_cfg<128, 128, 4, 2, 32, 1, TA, TB>(p, stream);
-        // 128 x 96 tiles when they quantise better onto the 256 CUs (e.g. the fused q|k|v projection, N = 1552:
-        // 30 x 13 = 390 tiles of 128 x 128 leave half the CUs with one block and half with two; 30 x 17 = 510 fit once).
-        // The 4-wave 128 x 96 form is ~20 % less efficient per flop than the 8-wave 128 x 128 one, hence the margin.
-        if (!TA && !TB && tile_cost(p, 128, 96, 256) < 0.8 * tile_cost(p, 128, 128, 256)) return launch_cfg<128, 96, 4, 1, 32, 1, TA, TB>(p, stream);
-        return launch_cfg<128, 128, 2, 4, 32, 1, TA, TB>(p, stream);
-    }
-    // (measured on MI355X, scratch/gpu_gemm_bench.py: BK = 64 and an intra-block split of the k-steps over 8 waves
-    //  (KS = 2) change these small-tile shapes by < 2 % — they are bound by the ~5 us fixed cost per launch.)
-    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 256)) return launch_cfg<64, 128, 2, 2, 32, 1, TA, TB>(p, stream);
-    return launch_cfg<64, 64, 2, 2, 32, 1, TA, TB>(p, stream);
+    const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) return launch_id<TA, TB>(it->second, p, stream);
+    // timing repeats the launch, so the call must be idempotent (no accumulate, no in-place residual), worth it
+    // (>= 0.1 GFLOP), and the stream must not be capturing
+    const bool idempotent = !(p.flags & GEMM_ACCUMULATE) && p.R != p.C && p.A != p.C;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
+        return launch_id<TA, TB>(heuristic_cfg<TA, TB>(p), p, stream);
+    int best = 0;
+    if (int rc = autotune<TA, TB>(p, stream, &best)) return rc;
+    g_tuned[key] = best;
+    return launch_id<TA, TB>(best, p, stream);
 }
 
 int gemm(const GemmArgs& p, hipStream_t stream) {

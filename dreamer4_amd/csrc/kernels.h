@@ -36,6 +36,8 @@ int gemm(const GemmArgs& p, hipStream_t stream);
 int gemm_profile_enable(int on);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
+int gemm_profile_classes();
+const char* gemm_profile_class_name(int c);
 
 // ------------------------------------------------------------------------------------ small attention
 // One wave per (group, head); head dim 64 (lane = feature).  Covers the space attention of the

@@ -177,11 +177,14 @@ int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                   float grad_scale, float* scratch, void* stream);
 
-/* Measurement hook (bench.py roofline leg): `mask` bit c enables tile class c; every GEMM launch of an enabled class is
- * bracketed by HIP events on its launch stream; d4_profile_read sums elapsed ms / algorithmic flops / launches per tile class
- * (0: 128x128, 1: 64x128, 2: 64x64 block tiles) and clears the log. */
+/* Measurement hook (bench.py roofline leg): `mask` bit c (c < 16) enables tile configuration c of the GEMM kernel; every
+ * (mask >> 16)-th launch (0 -> every launch) of an enabled configuration carries a HIP event pair on its dispatch (launch stream); d4_profile_read sums elapsed ms / algorithmic flops /
+ * launches per configuration and clears the log.  d4_profile_classes() configurations exist; d4_profile_class_name(c) is the
+ * prefix of the kernel name rocprofv3 reports for configuration c ("gemm_kernel<BM, BN, WGM, WGN, BK, 1"). */
 int d4_profile_enable(int mask);
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass);
+int d4_profile_classes(void);
+const char* d4_profile_class_name(int c);
 
 /* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr);
