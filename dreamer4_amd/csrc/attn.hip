@@ -21,34 +21,56 @@ __device__ __forceinline__ float lerp_torch(float a, float b, float w) {
     return (fabsf(w) < 0.5f) ? a + w * d : b - d * (1.f - w);
 }
 
+// Generic form: one block (4 waves) per (group, head).  Wave w prepares keys w, w+4, ... (value-residual mix, key l2-norm)
+// into LDS, then owns queries w, w+4, ...; scores are wave reductions, so they live in SGPRs.
 template <int NKM>
 __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= p.groups * p.heads) return;
-    const int g = wid / p.heads, h = wid % p.heads;
+    __shared__ float Ks[NKM * 64], Vs[NKM * 64];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int lane = threadIdx.x & 63;
     const int nk = p.nk, nq = p.nq;
     const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;   // (gamma + 1) * sqrt(64)
 
+    {
+        constexpr int PER = (NKM + 3) / 4;
+        float kr[PER], vr[PER], rr[PER], wm[PER];
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int j = w + 4 * t;
+            kr[t] = vr[t] = rr[t] = wm[t] = 0.f;
+            if (j < nk) {
+                kr[t] = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
+                vr[t] = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+                if (p.vres) {
+                    rr[t] = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                    wm[t] = p.mix[g * p.m_group_stride + j * p.m_item_stride + h];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int j = w + 4 * t;
+            if (j < nk) {
+                float vj = vr[t];
+                if (p.vres) vj = lerp_torch(vj, rr[t], sigmoidf(wm[t]));
+                const float nrm = sqrtf(wave_sum(kr[t] * kr[t]));
+                Ks[j * 64 + lane] = kr[t] / fmaxf(nrm, 1e-12f) * kscale;
+                Vs[j * 64 + lane] = vj;
+            }
+        }
+    }
+    __syncthreads();
+    if (w >= nq) return;
+
     float K[NKM], V[NKM];
 #pragma unroll
     for (int j = 0; j < NKM; ++j) {
-        K[j] = 0.f; V[j] = 0.f;
-        if (j < nk) {
-            float kj = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
-            float vj = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
-            if (p.vres) {
-                float vr = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
-                float w = sigmoidf(p.mix[g * p.m_group_stride + j * p.m_item_stride + h]);
-                vj = lerp_torch(vj, vr, w);
-            }
-            float nrm = sqrtf(wave_sum(kj * kj));
-            K[j] = kj / fmaxf(nrm, 1e-12f) * kscale;
-            V[j] = vj;
-        }
+        K[j] = j < nk ? Ks[j * 64 + lane] : 0.f;
+        V[j] = j < nk ? Vs[j * 64 + lane] : 0.f;
     }
 
-    for (int i = 0; i < nq; ++i) {
+    for (int i = w; i < nq; i += 4) {
         const float qi = p.q[g * p.q_group_stride + i * p.q_item_stride + h * 64 + lane];
         float s[NKM];
         float m = -FLT_MAX;
@@ -75,13 +97,8 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
         }
         float o = acc / l;
         if (p.belief) {
-            // v_i (self attention): re-read and re-mix rather than index the register array dynamically
-            float vi = p.v[g * p.v_group_stride + i * p.v_item_stride + h * 64 + lane];
-            if (p.vres) {
-                float vr = p.vres[g * p.r_group_stride + i * p.r_item_stride + h * 64 + lane];
-                float w = sigmoidf(p.mix[g * p.m_group_stride + i * p.m_item_stride + h]);
-                vi = lerp_torch(vi, vr, w);
-            }
+            // v_i (self attention): the mixed value row of token i
+            const float vi = Vs[i * 64 + lane];
             float vn = vi / fmaxf(sqrtf(wave_sum(vi * vi)), 1e-12f);
             o -= wave_sum(o * vn) * vn;
         }
@@ -98,59 +115,60 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
 // work, and a softmax row is one 16-lane DPP row (row_max16 / row_sum16).
 //   per wave: one (frame, head);  LDS per wave: Q,K [16][68] (+4 pad: conflict-free ds_read_b128), P [16][16]
 constexpr int SA_LD = 68;
-constexpr int SA_WAVE_FLOATS = 2 * 16 * SA_LD + 256;
 
-__global__ __launch_bounds__(256, 2) void space_attn_kernel(SmallAttnArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * SA_WAVE_FLOATS];
-    const int wslot = threadIdx.x >> 6;
-    const int wid = blockIdx.x * 4 + wslot;
-    if (wid >= p.groups * p.heads) return;
-    const int g = wid / p.heads, h = wid % p.heads;
+// One block (4 waves) per (frame, head); n = nq = nk <= 16 tokens.  Wave w prepares tokens w, w+4, w+8, w+12 (value-residual
+// mix, key l2-norm, 1/|v| for the belief projection) into LDS, then owns query rows 4w..4w+3: scores for the four rows in one
+// pass (lane = (row, key) pair), softmax over 16-lane rows, P.V with lane = feature.  8192 short waves instead of 2048 long
+// ones: the kernel is a chain of dependent reductions, so the win is latency hiding, not bandwidth.
+__global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float Qs[16 * SA_LD];
+    __shared__ __attribute__((aligned(16))) float Ks[16 * SA_LD];
+    __shared__ __attribute__((aligned(16))) float Vs[16 * SA_LD];
+    __shared__ __attribute__((aligned(16))) float Ps[16 * 16];
+    __shared__ float vinv_s[16];
+    const int w = threadIdx.x >> 6;
+    const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int lane = threadIdx.x & 63;
     const int n = p.nk;                                   // == nq <= 16
-    float* Qs = smem + wslot * SA_WAVE_FLOATS;
-    float* Ks = Qs + 16 * SA_LD;
-    float* Ps = Ks + 16 * SA_LD;
     const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;
 
-    // phase 1: issue every global load of the frame before the first dependent reduction (memory-level parallelism:
-    // 4 x n independent 256-byte row loads in flight per wave instead of one load -> wait -> reduce chain per token)
-    float V[16], vinv[16], Kr[16], Qr[16], Rr[16], Wm[16];
+    // phase 1: all global loads of this wave's tokens before the first dependent reduction
+    float V[4], Kr[4], Qr[4], Rr[4], Wm[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        V[j] = Kr[j] = Qr[j] = Rr[j] = Wm[j] = 0.f;
+    for (int t = 0; t < 4; ++t) {
+        const int j = w + 4 * t;
+        V[t] = Kr[t] = Qr[t] = Rr[t] = Wm[t] = 0.f;
         if (j < n) {
-            Kr[j] = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
-            Qr[j] = p.q[g * p.q_group_stride + j * p.q_item_stride + h * 64 + lane];
-            V[j] = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+            Kr[t] = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
+            Qr[t] = p.q[g * p.q_group_stride + j * p.q_item_stride + h * 64 + lane];
+            V[t] = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
             if (p.vres) {
-                Rr[j] = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
-                Wm[j] = p.mix[g * p.m_group_stride + j * p.m_item_stride + h];
+                Rr[t] = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                Wm[t] = p.mix[g * p.m_group_stride + j * p.m_item_stride + h];
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        vinv[j] = 0.f;
-        float kj = Kr[j];
+    for (int t = 0; t < 4; ++t) {
+        const int j = w + 4 * t;
+        float kj = Kr[t], vi = 0.f;
         if (j < n) {
-            if (p.vres) V[j] = lerp_torch(V[j], Rr[j], sigmoidf(Wm[j]));
+            if (p.vres) V[t] = lerp_torch(V[t], Rr[t], sigmoidf(Wm[t]));
             const float nrm = sqrtf(wave_sum(kj * kj));
             kj = kj / fmaxf(nrm, 1e-12f) * kscale;
-            if (p.belief) vinv[j] = 1.f / fmaxf(sqrtf(wave_sum(V[j] * V[j])), 1e-12f);
+            if (p.belief) vi = 1.f / fmaxf(sqrtf(wave_sum(V[t] * V[t])), 1e-12f);
         }
         Ks[j * SA_LD + lane] = kj;
-        Qs[j * SA_LD + lane] = Qr[j];
+        Qs[j * SA_LD + lane] = Qr[t];
+        Vs[j * SA_LD + lane] = V[t];
+        if (lane == 0) vinv_s[j] = vi;
     }
-    // (single wave owns this LDS region: program order + lgkmcnt is enough, no block barrier needed)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
 
-    // scores: pair (i, j) = (4r + lane/16, lane%16), r = 0..3
+    // scores of query rows 4w .. 4w+3: pair (i, j) = (4w + lane/16, lane%16)
     const int jl = lane & 15, il = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = 4 * r + il;
+    {
+        const int i = 4 * w + il;
         const f32x4* qrow = reinterpret_cast<const f32x4*>(Qs + i * SA_LD);
         const f32x4* krow = reinterpret_cast<const f32x4*>(Ks + jl * SA_LD);
         float acc = 0.f;
@@ -169,11 +187,18 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(SmallAttnArgs p) {
         const float l = row_sum16(e);
         Ps[i * 16 + jl] = (i < n) ? e / l : 0.f;
     }
+    // (each wave reads back only the P rows it wrote: program order + lgkmcnt is enough)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // out[i][d] = sum_j P[i][j] V[j][d]   (lane = d; P rows are LDS broadcasts)
-    for (int i = 0; i < n; ++i) {
+    float Vr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Vr[j] = Vs[j * SA_LD + lane];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = 4 * w + t;
+        if (i >= n) break;
         int orank = i;
         if (p.q_hi > 0) {
             if (i >= p.q_lo && i < p.q_hi) orank = i - p.q_lo;
@@ -185,14 +210,10 @@ __global__ __launch_bounds__(256, 2) void space_attn_kernel(SmallAttnArgs p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const f32x4 pv = prow[c];
-            o += pv[0] * V[4 * c] + pv[1] * V[4 * c + 1] + pv[2] * V[4 * c + 2] + pv[3] * V[4 * c + 3];
+            o += pv[0] * Vr[4 * c] + pv[1] * Vr[4 * c + 1] + pv[2] * Vr[4 * c + 2] + pv[3] * Vr[4 * c + 3];
         }
         if (p.belief) {
-            // V[i] with a run-time i: select through the (unrolled) register array
-            float vi = 0.f, vs = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { vi = (j == i) ? V[j] : vi; vs = (j == i) ? vinv[j] : vs; }
-            const float vn = vi * vs;
+            const float vn = Vs[i * SA_LD + lane] * vinv_s[i];
             o -= wave_sum(o * vn) * vn;
         }
         if (p.gate) o *= sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
@@ -205,15 +226,15 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(!p.belief || p.nq == p.nk, "small_attn: belief needs self attention");
     const int waves = p.groups * p.heads;
     if (waves == 0) return 0;
-    dim3 grid(cdiv(waves, 4)), block(256);
+    dim3 block(256);
     if (p.nq == p.nk && p.nk <= 16 && p.nq >= 8 && p.q_group_stride != 0) {
-        hipLaunchKernelGGL(space_attn_kernel, grid, block, 0, stream, p);
+        hipLaunchKernelGGL(space_attn_kernel, dim3(waves), block, 0, stream, p);
         D4_LAUNCH_CHECK();
         return 0;
     }
-    if (p.nk <= 16) hipLaunchKernelGGL(small_attn_kernel<16>, grid, block, 0, stream, p);
-    else if (p.nk <= 32) hipLaunchKernelGGL(small_attn_kernel<32>, grid, block, 0, stream, p);
-    else hipLaunchKernelGGL(small_attn_kernel<64>, grid, block, 0, stream, p);
+    if (p.nk <= 16) hipLaunchKernelGGL(small_attn_kernel<16>, dim3(waves), block, 0, stream, p);
+    else if (p.nk <= 32) hipLaunchKernelGGL(small_attn_kernel<32>, dim3(waves), block, 0, stream, p);
+    else hipLaunchKernelGGL(small_attn_kernel<64>, dim3(waves), block, 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
 }
