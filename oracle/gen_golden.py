@@ -12,6 +12,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   weights.npz      reference state_dict of the fixture model
   generate.npz     generate() in four modes: cached, no time cache, 2-frame prompt, 3 chained calls
   forward.npz      one parallel forward over 4 frames (+ the same frames fed one at a time with the cache)
+  blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
 """
@@ -154,9 +155,28 @@ def main():
     lat = torch.randn(B, Tf, 6, 8, generator=g)
     sig = torch.randint(0, 64, (B, Tf), generator=g)
     acts = torch.randint(0, 4, (B, Tf, 1), generator=g)
+    # block-level intermediates of the same parallel forward, taken with forward hooks on the reference's own modules:
+    # every layer hidden (the list the attention pools read, D4:3040/3172/3216), each pool's output, the final pool's
+    # input / output and the learned-query pool that turns latents into spatial tokens -> blocks.npz
+    blocks, hooks = {}, []
+    tr = m.transformer
+    def final_pool_hook(mod, args, kwargs, output):
+        hid = kwargs['hiddens'] if 'hiddens' in kwargs else args[1]
+        blocks['hiddens'] = npy(torch.stack(list(hid)))
+        blocks['final_pool_in'] = npy(args[0]); blocks['final_pool_out'] = npy(output)
+    hooks.append(tr.final_attn_pool.register_forward_hook(final_pool_hook, with_kwargs=True))
+    for i, pool in enumerate(tr.attn_pools):
+        if pool is None:
+            continue
+        hooks.append(pool.register_forward_hook(lambda mod, args, output, i=i: blocks.__setitem__(f'pool_out_{i}', npy(output))))
+    hooks.append(m.latents_to_spatial_tokens.register_forward_hook(lambda mod, args, output: blocks.__setitem__('spatial_tokens', npy(output))))
     with torch.no_grad():
         pred, (emb, inter) = m(latents=lat, signal_levels=sig, step_sizes=4, discrete_actions=acts, latent_is_noised=True,
                                return_pred_only=True, return_intermediates=True)
+        for hk in hooks:
+            hk.remove()
+        np.savez(os.path.join(OUT, 'blocks.npz'), **blocks, **{'meta_' + k: np.array(v) for k, v in META.items()})
+        print('blocks:', {k: v.shape for k, v in blocks.items()})
         out.update(latents=npy(lat), signal_levels=npy(sig), actions=npy(acts), pred=npy(pred.flow[:, :, 0]),
                    agent_embed=npy(emb.agent[:, :, 0]), kv=npy(inter.main.next_kv_cache))
         tc, seq_agent, seq_pred = None, [], []

@@ -257,7 +257,7 @@ class TrunkCache:
     token_count: int = 0
 
 
-def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='transformer.'):
+def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='transformer.', trace: dict | None = None):
     """AxialSpaceTimeTransformer.forward D4:2927-3267 (defaults: value residual, attn pools,
     final special cross-attn, no final norm).  tokens (b, t, s, d).  When a non-empty cache is
     given and t > 1 only the last frame is processed (D4:2960-2961)."""
@@ -303,6 +303,8 @@ def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='tr
 
         if i != cfg.depth - 1:
             tokens = attention_pool(cfg, W, f'{pre}attn_pools.{i}.', tokens, layer_hiddens)
+            if trace is not None:
+                trace[f'pool_out_{i}'] = tokens
 
     # agent token cross-attends the non-special tokens of its frame   D4:3227-3238
     non_special, special = tokens[:, :, :-1], tokens[:, :, -1:]
@@ -314,7 +316,12 @@ def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='tr
     special = special + feedforward(W, pre + 'final_special_ff.fn.', special)
     tokens = torch.cat((non_special, special), dim=2)
 
+    if trace is not None:
+        trace['hiddens'] = torch.stack(layer_hiddens)
+        trace['final_pool_in'] = tokens
     tokens = attention_pool(cfg, W, pre + 'final_attn_pool.', tokens, layer_hiddens)
+    if trace is not None:
+        trace['final_pool_out'] = tokens
 
     new_cache = TrunkCache(kv=new_kv, token_count=token_count + t)
     return tokens, new_cache
@@ -338,7 +345,7 @@ def action_tokens(cfg: Config, W, actions, time, batch):
 
 
 def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, tasks=None,
-               cache: TrunkCache | None = None):
+               cache: TrunkCache | None = None, trace: dict | None = None):
     """DynamicsWorldModel.forward(latent_is_noised=True, return_pred_only=True,
     return_intermediates=True)  D4:6792-7295.
 
@@ -366,7 +373,9 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
     agent = agent[:, None].expand(b, t, -1, -1)
 
     tokens = torch.cat((flow_tok, space, regs, act_tok[:, :, None], agent), dim=2)
-    tokens, new_cache = transformer(cfg, W, tokens, cache)
+    if trace is not None:
+        trace['spatial_tokens'] = space
+    tokens, new_cache = transformer(cfg, W, tokens, cache, trace=trace)
 
     ns = cfg.num_spatial_tokens
     space_out = tokens[:, :, 1:1 + ns]

@@ -90,6 +90,27 @@ def test_forward_parallel_equals_cached_sequential(GM):
     close(seq, agent, atol=1e-5)
 
 
+def test_block_intermediates_vs_reference_fixture(GM):
+    """Engine-internal activations after one parallel forward against the reference's block-level fixture: the residual
+    stream after every attention / feedforward block (the hiddens the attention pools read), the spatial tokens, the last
+    in-loop pool output and the final pool output on the rows the engine keeps (spatial + agent)."""
+    from dreamer4_amd.world_model import _debug_buffer
+    m, _ = GM
+    g, b = load_golden('forward.npz'), load_golden('blocks.npz')
+    lat, sig, acts = t(g['latents']), t(g['signal_levels']), t(g['actions'])
+    m(latents=lat, signal_levels=sig, step_sizes=4, discrete_actions=acts)
+    nslab, B, T, S, D = b['hiddens'].shape
+    ns = m.num_spatial_tokens
+    hid = _debug_buffer(m, 'slabs', (nslab, B, T, S, D))
+    for j in range(nslab):
+        close(hid[j], b['hiddens'][j], atol=2e-5)
+    close(_debug_buffer(m, 'space', (B, T, ns, D)), b['spatial_tokens'][:, :, 0], atol=2e-5)
+    close(_debug_buffer(m, 'xpool', (B, T, S, D)), b[f'pool_out_{(nslab - 1) // 2 - 2}'], atol=2e-5)
+    xfc = _debug_buffer(m, 'xfc', (B, T, ns + 1, D))
+    close(xfc[:, :, :ns], b['final_pool_out'][:, :, 1:1 + ns], atol=2e-5)
+    close(xfc[:, :, ns], b['final_pool_out'][:, :, -1], atol=2e-5)
+
+
 @pytest.mark.parametrize('kw', [dict(), dict(num_discrete_actions=(3, 2), depth=3, time_block_every=1),
                                 dict(dim=128, attn_heads=4, num_latent_tokens=12, dim_latent=16, depth=2, time_block_every=1)])
 def test_generate_vs_oracle_on_fresh_models(kw):
@@ -141,6 +162,24 @@ def test_full_size_config_vs_oracle(B):
                           return_log_probs_and_values=True, noise=nz)
     close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed'], atol=5e-4)
     close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'], atol=5e-4)
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
+
+
+def test_config5_shape_vs_oracle():
+    """BASELINE config 5 architecture in fp32 with a discrete action space (dim 1024, depth 12 -> time layers 4, 8, 12,
+    attention inner width 8 x 64 = 512 < dim, 64 x 32 latents): the engine is not specialised to dim 512."""
+    from dreamer4_amd import DynamicsWorldModel
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_discrete_actions=4))
+    cfg, W = oracle_config(m), oracle_weights(m)
+    assert sum(cfg.is_time) == 3
+    B, T = 2, 3
+    nz = make_noise(cfg, T, B, 9)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, return_terminals=False)
+    e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
+                          return_log_probs_and_values=True, noise=nz)
+    close(e.latents, ref['latents'], atol=5e-4); close(e.agent_embed, ref['agent_embed'], atol=1e-3)
+    close(e.values, ref['values'], atol=5e-4); close(e.log_probs.discrete, ref['log_probs'], atol=1e-3)
     assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
 
 
