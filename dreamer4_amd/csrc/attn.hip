@@ -245,12 +245,24 @@ template <int ITER>
 __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     constexpr int PH = 4, LMAX = 64;
     __shared__ float psh[4][LMAX * PH];
+    __shared__ f32x4 gws[PH * ITER * 64];                 // head-gate weights [PH][D] of the pool (norm gamma folded)
+    const int L = p.L, D = p.D;
+    const int nf4 = D / 4;
+    for (int i = threadIdx.x; i < PH * ITER * 64; i += 256) {        // (columns past D are zero: they meet zero-padded rows)
+        const int h = i / (ITER * 64), c4 = i % (ITER * 64);
+        gws[i] = c4 < nf4 ? reinterpret_cast<const f32x4*>(p.gate_w)[h * nf4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
     const int wslot = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wslot;
     if (m >= p.M) return;
     const int lane = threadIdx.x & 63;
     float* ps = psh[wslot];
-    const int L = p.L, D = p.D;
+
+    // gate_h = sigmoid(RMSNorm(x) . gate_w[h]) scales the whole head output, so it is applied once after the mix; for the
+    // in-loop pools x IS the last hidden row of the loop.  (gate weights: staged once per block in LDS, see above)
+    const bool x_is_last_hidden = p.x == p.hid + (int64_t)(L - 1) * p.M * D && p.ldx == D;
+    float glog[PH] = {0.f, 0.f, 0.f, 0.f};
 
     // scores: the 4 heads x 64 features of a key row are exactly one float4 per lane (head = lane / 16), so the
     // per-head reductions are 16-lane DPP row reductions and all four heads are scored at once
@@ -274,20 +286,18 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     for (int h = 0; h < PH; ++h) mx[h] = readlane_f(mxl, h * 16);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float den[PH], gate[PH];
+    float den[PH];
 #pragma unroll
     for (int h = 0; h < PH; ++h) {
         float d = 0.f;
         for (int l = 0; l < L; ++l) d += expf(ps[l * PH + h] - mx[h]);
         den[h] = d;
-        gate[h] = sigmoidf(p.q[(int64_t)m * p.ldq + PH * 64 + h]);
     }
     f32x4 acc[PH][ITER];
 #pragma unroll
     for (int h = 0; h < PH; ++h)
 #pragma unroll
         for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nf4 = D / 4;
     // hidden rows are software-pipelined one ahead: the next row's loads are in flight while this row is reduced / mixed
     f32x4 vn[ITER];
     auto load_row = [&](int l, f32x4 (&dst)[ITER]) {
@@ -311,10 +321,44 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
         const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
 #pragma unroll
         for (int h = 0; h < PH; ++h) {
-            const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * gate[h] * rstd;
+            const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * rstd;
 #pragma unroll
             for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
         }
+        if (l == L - 1 && x_is_last_hidden) {
+#pragma unroll
+            for (int h = 0; h < PH; ++h) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += v[i][0] * g[0] + v[i][1] * g[1] + v[i][2] * g[2] + v[i][3] * g[3]; }
+                glog[h] = wave_sum(d) * rstd;
+            }
+        }
+    }
+    if (!x_is_last_hidden) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx);
+        f32x4 xv[ITER];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            xv[i] = c4 < nf4 ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += xv[i][0] * g[0] + xv[i][1] * g[1] + xv[i][2] * g[2] + xv[i][3] * g[3]; }
+            glog[h] = wave_sum(d) * rstd;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        const float gate = sigmoidf(glog[h]);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) acc[h][i] = acc[h][i] * gate;
     }
 #pragma unroll
     for (int h = 0; h < PH; ++h) {

@@ -350,12 +350,14 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     const int D = e->D, hp = e->hp;
     const AttnW& a = e->pools[p];
     int rc;
-    if ((rc = gemm_simple(x, D, e->pq_w[p], D, e->pool_q, e->ldpq, M, hp + e->php, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
-    if (c.pool_heads == 4 && D <= 1024) {
+    const bool mix_path = c.pool_heads == 4 && D <= 1024;
+    // (mix path: the head-gate logits are computed inside pool_mix; hp = 256 columns are exactly two / four tile columns)
+    if ((rc = gemm_simple(x, D, e->pq_w[p], D, e->pool_q, e->ldpq, M, mix_path ? hp : hp + e->php, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    if (mix_path) {
         // keys only: [L*M][hp]; values come from ONE per-head projection of the softmax-weighted normalised hiddens
         if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, hp, L * M, hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
         PoolMixArgs pm{};
-        pm.q = e->pool_q; pm.ldq = e->ldpq; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
+        pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
         if ((rc = pool_mix(pm, s))) return rc;
         GemmArgs gv{e->pool_u, c.pool_heads * D, e->pkv_w[p] + (size_t)hp * D, D, e->pool_att, hp, nullptr, nullptr, 0, M, 64, D, 0, RMS_EPS};

@@ -65,7 +65,9 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream);
 // weighted (and gated) sum of the NORMALISED hiddens per head, u[m][h][:] = sigmoid(gate) * sum_l p[l][h] * h_l[m] / rms(h_l[m]);
 // the value projection is then ONE [D -> 64] GEMM per head on u instead of L projections (linear in the hiddens).
 struct PoolMixArgs {
-    const float* q; int ldq;           // [M][ldq]: q @ 0 (heads*64), gate logits @ heads*64
+    const float* q; int ldq;           // [M][ldq]: projected queries (heads*64)
+    const float* x; int ldx;           // [M][D] pool input tokens (the head gates are sigmoid(RMSNorm(x) . gate_w[h]), computed here:
+    const float* gate_w;               //  [heads][D], norm gamma folded — 4 extra columns would cost the query GEMM a whole tile column)
     const float* k; int ldk;           // [L*M][ldk]: projected keys, row l*M + m
     const float* hid; int D;           // [L*M][D] hiddens
     const float* k_gamma;              // [heads][64]
