@@ -487,6 +487,34 @@ struct TuneKey {
 };
 static std::map<TuneKey, int> g_tuned;
 
+// D4_GEMM_TUNE_CACHE=<file>: the shape -> configuration table is read at first use and every new entry is appended, so a
+// later process (a profiler pass, a restarted trainer) starts with the choices already made and never re-times.
+static const char* tune_cache_path() {
+    static const char* path = getenv("D4_GEMM_TUNE_CACHE");
+    return path;
+}
+static void tune_cache_load() {
+    static bool loaded = false;
+    if (loaded) return;
+    loaded = true;
+    const char* path = tune_cache_path();
+    if (!path) return;
+    if (FILE* f = fopen(path, "r")) {
+        TuneKey k; int id;
+        while (fscanf(f, "%d %d %d %d %d %d", &k.M, &k.N, &k.K, &k.flags, &k.batch, &id) == 6)
+            if (id >= 0 && id < N_TILE_CFG) g_tuned[k] = id;
+        fclose(f);
+    }
+}
+static void tune_cache_append(const TuneKey& k, int id) {
+    const char* path = tune_cache_path();
+    if (!path) return;
+    if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "%d %d %d %d %d %d\n", k.M, k.N, k.K, k.flags, k.batch, id);
+        fclose(f);
+    }
+}
+
 template <bool TA, bool TB>
 static int autotune(const GemmArgs& p, hipStream_t stream, int* best_out) {
     hipEvent_t e0 = prof_event(), e1 = prof_event();
@@ -527,8 +555,9 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
     const int nb = p.batch > 0 ? p.batch : 1;
     const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
+    tune_cache_load();
     auto it = g_tuned.find(key);
-    if (it != g_tuned.end()) return launch_id<TA, TB>(it->second, p, stream);
+    if (it != g_tuned.end() && cfg_valid<TA, TB>(it->second, p)) return launch_id<TA, TB>(it->second, p, stream);
     // timing repeats the launch, so the call must be idempotent (no accumulate, no in-place residual), worth it
     // (>= 0.1 GFLOP), and the stream must not be capturing
     const bool idempotent = !(p.flags & GEMM_ACCUMULATE) && p.R != p.C && p.A != p.C;
@@ -539,6 +568,7 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     int best = 0;
     if (int rc = autotune<TA, TB>(p, stream, &best)) return rc;
     g_tuned[key] = best;
+    tune_cache_append(key, best);
     return launch_id<TA, TB>(best, p, stream);
 }
 
