@@ -812,10 +812,10 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                         crc = d4::euler_step(e->x_lat, n_el, e->pred, n_el, B, n_el, 1.f - tt, (float)step_size / (float)c.max_steps, cs);
                     }
                     hipError_t ce = hipStreamEndCapture(cs, &graph);
-                    if (crc) { if (ce == hipSuccess) hipGraphDestroy(graph); return crc; }
+                    if (crc) { if (ce == hipSuccess) (void)hipGraphDestroy(graph); return crc; }
                     D4_HIP(ce);
                     D4_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                    hipGraphDestroy(graph);
+                    (void)hipGraphDestroy(graph);
                     e->graphs.push_back({B, K, sl, tasks != nullptr, exec});
                 }
             }

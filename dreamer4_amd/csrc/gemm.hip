@@ -324,7 +324,7 @@ static std::vector<hipEvent_t> g_event_pool;
 static hipEvent_t prof_event() {
     if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 
@@ -528,13 +528,13 @@ static int autotune(const GemmArgs& p, hipStream_t stream, int* best_out) {
         if ((rc = launch_id<TA, TB>(id, p, stream))) break;              // warm (attribute set, code resident)
         float ms = 1e30f;
         for (int rep = 0; rep < 2 && !rc; ++rep) {                       // best of two timed pairs
-            hipEventRecord(e0, stream);
+            (void)hipEventRecord(e0, stream);
             if ((rc = launch_id<TA, TB>(id, p, stream))) break;
             if ((rc = launch_id<TA, TB>(id, p, stream))) break;
-            hipEventRecord(e1, stream);
+            (void)hipEventRecord(e1, stream);
             if (hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
             float t = 0.f;
-            hipEventElapsedTime(&t, e0, e1);
+            (void)hipEventElapsedTime(&t, e0, e1);
             ms = t < ms ? t : ms;
         }
         if (!rc && (best < 0 || ms < best_ms)) { best = id; best_ms = ms; }
@@ -581,6 +581,7 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(!((p.flags & GEMM_RMS_ROWSCALE) && ta), "gemm: rms rowscale needs a non-transposed A");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (p.N % 64) != 0), "gemm: swiglu needs N %% 64 == 0 (packed pairs)");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (ta || tb)), "gemm: swiglu epilogue is forward-only");
+    if (gemm_skinny_applicable(p)) return gemm_skinny(p, stream);
     if (!ta && !tb) return launch_t<false, false>(p, stream);
     if (!ta && tb) return launch_t<false, true>(p, stream);
     if (ta && tb) return launch_t<true, true>(p, stream);

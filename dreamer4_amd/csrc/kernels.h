@@ -33,6 +33,8 @@ struct GemmArgs {
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
+bool gemm_skinny_applicable(const GemmArgs& p);            // M <= 16 rows: VALU kernel that streams W once (gemm_skinny.hip)
+int gemm_skinny(const GemmArgs& p, hipStream_t stream);
 int gemm_profile_enable(int on);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);

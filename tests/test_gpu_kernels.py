@@ -51,14 +51,15 @@ def run_gemm(lib, M, N, K, flags=0, bias=False, res=False, ta=False, tb=False, s
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 32), (64, 64, 32), (200, 300, 72), (3, 4, 256), (45, 388, 64), (15, 2064, 512),
-                                   (3840, 512, 512), (1, 255, 512), (50000, 512, 512), (96, 1024, 8)])
+                                   (3840, 512, 512), (1, 255, 512), (50000, 512, 512), (96, 1024, 8), (14, 512, 1376), (16, 1552, 512), (8, 1024, 16),
+                                   (4, 2048, 2048), (17, 512, 512)])
 def test_gemm_nt(lib, M, N, K):
     run_gemm(lib, M, N, K)
     run_gemm(lib, M, N, K, flags=_lib.GEMM_RMS_ROWSCALE, bias=True)
     run_gemm(lib, M, N, K, flags=_lib.GEMM_SILU, bias=True, res=True)
 
 
-@pytest.mark.parametrize('M,N,K', [(45, 192, 64), (3840, 2752, 512), (256, 128, 32)])
+@pytest.mark.parametrize('M,N,K', [(45, 192, 64), (3840, 2752, 512), (256, 128, 32), (15, 2752, 512), (1, 64, 2048), (16, 192, 1376)])
 def test_gemm_swiglu_epilogue(lib, M, N, K):
     run_gemm(lib, M, N, K, flags=_lib.GEMM_RMS_ROWSCALE | _lib.GEMM_SWIGLU, bias=True)
 
