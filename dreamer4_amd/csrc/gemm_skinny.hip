@@ -24,6 +24,11 @@ template <bool SWIGLU, int TM>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     constexpr int RB = SK_ROWS * TM;                             // rows per block (blockIdx.y = row group)
     const int m0 = blockIdx.y * RB;
+    {   // strided batch (blockIdx.z), as in gemm_kernel
+        const int bz = blockIdx.z;
+        p.A += bz * p.strideA; p.W += bz * p.strideW; p.C += bz * p.strideC;
+        if (p.R) p.R += bz * p.strideC;
+    }
     __shared__ float red[4 * RB * SK_RED];                       // [4 k-quarters][RB rows][16 cols | ssq]
     const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
     const int nl = lane & 15, kk = lane >> 4;
@@ -134,14 +139,14 @@ static int skinny_tm(const GemmArgs& p) { return p.M > 32 ? 4 : (p.M > 16 ? 2 : 
 // Few rows = the tiled kernel would have fewer than 64 tiles of 64 x 64 (a quarter of the CUs) to work with.
 bool gemm_skinny_applicable(const GemmArgs& p) {
     static const bool on = !(getenv("D4_GEMM_SKINNY") && atoi(getenv("D4_GEMM_SKINNY")) == 0);
-    return on && p.M >= 1 && p.M <= 256 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) < 64 && !(p.flags & (GEMM_TRANS_A | GEMM_TRANS_B)) &&
-           p.batch <= 1 && (p.K % 4) == 0;
+    return on && p.M >= 1 && p.M <= 256 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * (p.batch > 0 ? p.batch : 1) < 64 &&
+           !(p.flags & (GEMM_TRANS_A | GEMM_TRANS_B)) && (p.K % 4) == 0 && (p.C2 == nullptr || p.batch <= 1);
 }
 
 template <bool SWIGLU, int TM>
 static int launch_skinny(const GemmArgs& p, hipStream_t stream) {
     const int blocks = SWIGLU ? (p.N / 64) * 4 : cdiv(p.N, SKN);
-    hipLaunchKernelGGL((gemm_skinny_kernel<SWIGLU, TM>), dim3(blocks, cdiv(p.M, SK_ROWS * TM)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((gemm_skinny_kernel<SWIGLU, TM>), dim3(blocks, cdiv(p.M, SK_ROWS * TM), p.batch > 0 ? p.batch : 1), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
 }
