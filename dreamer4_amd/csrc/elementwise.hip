@@ -95,22 +95,48 @@ int pad_cols(const float* W, float* out, int rows, int cols, int cols_pad, hipSt
 }
 
 // ---------------------------------------------------------------------------------- RMSNorm (explicit; head MLPs)
-// one wave per row
+// one wave per row; the row is held in registers (16-byte loads, all in flight at once) when it is aligned and D <= 4096
+template <bool VEC>
 __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* x, int ldx, const float* gamma, float* y, int ldy,
                                                            int rows, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* xr = x + (int64_t)row * ldx;
+    float* yr = y + (int64_t)row * ldy;
+    if (VEC) {
+        constexpr int MAXI = 16;
+        const int nf4 = D >> 2;
+        f32x4 v[MAXI];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c4 = lane + 64 * i;
+            v[i] = c4 < nf4 ? reinterpret_cast<const f32x4*>(xr)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nf4) {
+                const f32x4 g = gamma ? reinterpret_cast<const f32x4*>(gamma)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
+                reinterpret_cast<f32x4*>(yr)[c4] = f32x4{v[i][0] * rstd * g[0], v[i][1] * rstd * g[1], v[i][2] * rstd * g[2], v[i][3] * rstd * g[3]};
+            }
+        }
+        return;
+    }
     float ss = 0.f;
     for (int c = lane; c < D; c += 64) { float v = xr[c]; ss += v * v; }
     const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
-    float* yr = y + (int64_t)row * ldy;
     for (int c = lane; c < D; c += 64) yr[c] = xr[c] * rstd * (gamma ? gamma[c] : 1.f);
 }
 int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int D, float eps, hipStream_t s) {
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, y, ldy, rows, D, eps);
+    const bool vec = (D % 4) == 0 && D <= 4096 && (ldx % 4) == 0 && (ldy % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+                     (gamma == nullptr || ((uintptr_t)gamma % 16) == 0);
+    if (vec) hipLaunchKernelGGL(rmsnorm_rows_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, y, ldy, rows, D, eps);
+    else hipLaunchKernelGGL(rmsnorm_rows_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, y, ldy, rows, D, eps);
     D4_LAUNCH_CHECK();
     return 0;
 }
