@@ -139,7 +139,8 @@ static int skinny_tm(const GemmArgs& p) { return p.M > 32 ? 4 : (p.M > 16 ? 2 : 
 // Few rows = the tiled kernel would have fewer than 64 tiles of 64 x 64 (a quarter of the CUs) to work with.
 bool gemm_skinny_applicable(const GemmArgs& p) {
     static const bool on = !(getenv("D4_GEMM_SKINNY") && atoi(getenv("D4_GEMM_SKINNY")) == 0);
-    return on && p.M >= 1 && p.M <= 256 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * (p.batch > 0 ? p.batch : 1) < 64 &&
+    static const int max_tiles = getenv("D4_SKINNY_TILES") ? atoi(getenv("D4_SKINNY_TILES")) : 64;
+    return on && p.M >= 1 && p.M <= 256 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * (p.batch > 0 ? p.batch : 1) < max_tiles &&
            !(p.flags & (GEMM_TRANS_A | GEMM_TRANS_B)) && (p.K % 4) == 0 && (p.C2 == nullptr || p.batch <= 1);
 }
 
