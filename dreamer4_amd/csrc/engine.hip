@@ -147,6 +147,7 @@ struct Resolver {
     int rc = 0;
     const float* get(const char* key, int64_t numel, float** grad = nullptr) {
         auto it = e->bound.find(key);
+        if (it == e->bound.end() && numel == 0) return nullptr;      // empty parameter (e.g. no register tokens): nothing to bind
         if (it == e->bound.end()) {
             if (!rc) set_error("weight '%s' is not bound (expected %lld elements)", key, (long long)numel);
             rc = 4;
@@ -913,6 +914,7 @@ int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
         {"ckv", e->ckv}, {"catt", e->catt}, {"lkv", e->lkv}, {"latt", e->latt}, {"space", e->space}, {"gs", e->gs},
         {"okv", e->okv}, {"oatt", e->oatt}, {"oproj", e->oproj}, {"pred", e->pred}, {"x_lat", e->x_lat},
         {"cache", e->cache}, {"lin_q", e->lin_q}, {"lin_gate", e->lin_gate}, {"lout_q", e->lout_q},
+        {"l_logits", e->l_logits}, {"l_dlogits", e->l_dlogits}, {"l_adv", e->l_adv}, {"l_returns", e->l_returns}, {"l_mask", e->l_mask},
     };
     for (auto& t : tbl) if (!strcmp(t.n, name)) { *ptr = t.p; return 0; }
     D4_REQUIRE(false, "unknown debug buffer '%s'", name);

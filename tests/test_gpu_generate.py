@@ -127,6 +127,45 @@ def test_generate_vs_oracle_on_fresh_models(kw):
     assert torch.equal(e.actions.discrete.cpu(), ref['actions']) and torch.equal(e.lens.cpu(), ref['lens'])
 
 
+def _sweep_configs():
+    import random
+    rng = random.Random(2024)
+    out = []
+    for i in range(20):
+        depth = rng.choice([1, 2, 3, 5])
+        out.append(dict(
+            dim=rng.choice([32, 64, 96, 160]), attn_heads=rng.choice([1, 2, 3]), depth=depth,
+            time_block_every=rng.choice([1, 2, 4]), num_latent_tokens=rng.choice([3, 5, 9, 16]), dim_latent=rng.choice([4, 8, 12]),
+            num_spatial_tokens=rng.choice([1, 2, 4, 6]), num_register_tokens=rng.choice([0, 1, 3, 8]),
+            num_discrete_actions=rng.choice([2, 5, (2, 3), (4, 2, 3)]), num_tasks=rng.choice([0, 2]),
+            multi_token_pred_len=rng.choice([1, 4, 8]), max_steps=rng.choice([16, 64])))
+    return out
+
+
+@pytest.mark.parametrize('i', range(20))
+def test_generate_vs_oracle_random_config_sweep(i):
+    """Seeded random architectures (token counts, head counts, depths with and without time layers, several action types,
+    odd widths) x random call shapes, HIP vs the CPU oracle; integers exact."""
+    import random
+    kw = _sweep_configs()[i]
+    if kw['num_spatial_tokens'] == kw['num_latent_tokens']:
+        kw['num_spatial_tokens'] += 1
+    rng = random.Random(77 + i)
+    m = small_model(**kw)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = rng.choice([1, 2, 5]), rng.choice([1, 3, 4])
+    K = rng.choice([k for k in (2, 4, 8) if k <= kw['max_steps'] // 2])
+    use_cache = rng.random() < 0.7
+    nz = make_noise(cfg, T, B, 500 + i)
+    tasks = torch.randint(0, kw['num_tasks'], (B,), generator=torch.Generator().manual_seed(i)) if kw['num_tasks'] else None
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, num_steps=K, tasks=tasks, use_time_cache=use_cache)
+    e = m.cuda().generate(T, batch_size=B, num_steps=K, return_for_policy_optimization=True, noise=nz, tasks=tasks, use_time_cache=use_cache)
+    assert e.latents.shape[1] == ref['latents'].shape[1]
+    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed']); close(e.rewards, ref['rewards'])
+    close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'])
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions']) and torch.equal(e.lens.cpu(), ref['lens'])
+
+
 def test_plain_generate_returns_latents_only(GM):
     m, G = GM
     nz = golden_noise(G, 'cached_')

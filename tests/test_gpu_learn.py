@@ -70,6 +70,57 @@ def test_learn_vs_oracle_with_terminations_and_two_action_types():
                 close(p.grad, Wg[k].grad, atol=5e-6, rtol=2e-3)
 
 
+@pytest.mark.parametrize('i', range(6))
+def test_learn_vs_oracle_random_config_sweep(i):
+    """Seeded random architectures / batch shapes / objectives (with early terminations so that the masks matter):
+    losses and the gradients of both heads, HIP vs the oracle's autograd."""
+    import random
+    from util import randomize_weights
+    rng = random.Random(900 + i)
+    kw = dict(dim=rng.choice([32, 64, 96]), attn_heads=rng.choice([1, 2]), depth=rng.choice([1, 2, 3]), time_block_every=rng.choice([1, 2]),
+              num_latent_tokens=rng.choice([3, 6]), dim_latent=rng.choice([4, 8]), num_spatial_tokens=rng.choice([1, 2, 4]),
+              num_register_tokens=rng.choice([0, 2, 8]), num_discrete_actions=rng.choice([3, (2, 3), (4, 2, 2)]), num_tasks=0,
+              multi_token_pred_len=rng.choice([1, 8]))
+    m = randomize_weights(small_model(**kw), terminal_bias=rng.choice([-0.5, -2.0]))
+    with torch.no_grad():       # logits of O(5), not O(300): fp32 rounding of a logit is then ~1e-6 in the log-prob, and the
+        dict(m.named_parameters())['action_embedder.discrete_action_unembed'].mul_(0.02)    # delight gate exp(-lp*adv) stays tame
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = rng.choice([2, 5, 9]), rng.choice([2, 4, 7])
+    nz = make_noise(cfg, T, B, 40 + i)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz)
+    m = m.cuda()
+    # the learner is compared on IDENTICAL inputs (the oracle's own rollout): z-scored advantages over a handful of samples
+    # amplify the ~1e-6 rollout differences far beyond any kernel error otherwise
+    e = Experience(latents=ref['latents'], agent_embed=ref['agent_embed'], rewards=ref['rewards'], values=ref['values'],
+                   log_probs=Actions(ref['log_probs'], None), actions=Actions(ref['actions'], None), lens=ref['lens'],
+                   terminals=ref['terminals'], is_truncated=ref['is_truncated'], old_action_unembeds=Actions(ref['old_action_unembeds'], None),
+                   step_size=ref['step_size'])
+    obj = ('ppo', 'spo', 'pmpo')[i % 3]
+    Wg = {k: (v.clone().requires_grad_() if k.startswith(HEADS) else v) for k, v in W.items()}
+    pl_o, vl_o = restate.learn_losses(cfg, Wg, ref, obj)
+    pl_o.backward(); vl_o.backward()
+    pl, vl = m.learn_from_experience(e, objective=obj)
+    pl.backward(); vl.backward()
+    # Tolerance from the problem's own conditioning.  In the oracle the recomputed log-prob equals the stored one bit for bit
+    # (ratio == 1 exactly) and the advantage is a difference of nearly equal returns / values; on the GPU the policy MLP and
+    # the GAE accumulate in another order, so those quantities move by ~1e-6 relative — for the log-probs that is 1e-6 of the
+    # LOGIT magnitude (hundreds with these random heads, i.e. ratio = 1 +- 2e-4) — which z-scoring over a handful of valid
+    # steps (or pmpo's raw advantages) amplifies further.  So the oracle is run a second time on inputs perturbed at that
+    # level, and the GPU must stay within 20x of what that perturbation does (+ 1e-5 of the tensor's scale).
+    gen = torch.Generator().manual_seed(i)
+    jig = lambda x, r: x * (1 + r * (2 * torch.rand(x.shape, generator=gen) - 1))
+    ref2 = dict(ref, values=jig(ref['values'], 2e-6), rewards=jig(ref['rewards'], 2e-6), agent_embed=jig(ref['agent_embed'], 2e-6),
+                log_probs=ref['log_probs'] + 1e-6 * ref['old_action_unembeds'].abs().max() * (2 * torch.rand(ref['log_probs'].shape, generator=gen) - 1))
+    Wp = {k: (v.clone().requires_grad_() if k.startswith(HEADS) else v) for k, v in W.items()}
+    pl_p, vl_p = restate.learn_losses(cfg, Wp, ref2, obj)
+    pl_p.backward(); vl_p.backward()
+    close(pl, pl_o, atol=2e-5 + 20 * abs(float(pl_p) - float(pl_o))); close(vl, vl_o, atol=2e-5 + 20 * abs(float(vl_p) - float(vl_o)))
+    for k, p in m.named_parameters():
+        if k.startswith(HEADS) and p.numel() > 0:
+            sens = (Wp[k].grad - Wg[k].grad).abs().max().item()
+            close(p.grad, Wg[k].grad, atol=20 * sens + 1e-5 * Wg[k].grad.abs().max().item() + 1e-9, rtol=1e-4)
+
+
 def test_three_trainer_steps_vs_reference_fixture():
     """generate -> learn -> clip_grad_norm_(0.5) -> AdamW(3e-4) on each head, natively (trainers.py:1430-1452)."""
     g = load_golden('trainer.npz')
