@@ -75,24 +75,34 @@ __global__ __launch_bounds__(1024) void reduce1_kernel(const float* a, const flo
     if (threadIdx.x == 0) *out = sh[0];
 }
 
-// column sums: out[c] = sum_r x[r][c]; block = 64 columns x 16 row lanes, fixed order
+// column sums: out[c] = sum_r x[r][c]; block = 16 columns x 64 row lanes (4x more blocks than a 64-column block: the
+// [4096][2048] bias-gradient reductions are latency bound, not bandwidth bound), 8 loads in flight per thread, fixed order
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int ld, int rows, int cols, float* out) {
-    __shared__ float sh[16][65];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    __shared__ float sh[64][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < cols)
-        for (int r = rl; r < rows; r += 16) s += x[(int64_t)r * ld + c];
-    sh[rl][threadIdx.x & 63] = s;
+    if (c < cols) {
+        int r = rl;
+        for (; r + 7 * 64 < rows; r += 8 * 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(int64_t)(r + u * 64) * ld + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < rows; r += 64) s += x[(int64_t)r * ld + c];
+    }
+    sh[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < cols) {
         float t = 0.f;
-        for (int i = 0; i < 16; ++i) t += sh[i][threadIdx.x & 63];
+        for (int i = 0; i < 64; ++i) t += sh[i][cl];
         out[c] = t;
     }
 }
 static int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, s, x, ld, rows, cols, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 16)), dim3(1024), 0, s, x, ld, rows, cols, out);
     D4_LAUNCH_CHECK();
     return 0;
 }

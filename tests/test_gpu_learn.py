@@ -114,7 +114,7 @@ def test_learn_vs_oracle_random_config_sweep(i):
     Wp = {k: (v.clone().requires_grad_() if k.startswith(HEADS) else v) for k, v in W.items()}
     pl_p, vl_p = restate.learn_losses(cfg, Wp, ref2, obj)
     pl_p.backward(); vl_p.backward()
-    close(pl, pl_o, atol=2e-5 + 20 * abs(float(pl_p) - float(pl_o))); close(vl, vl_o, atol=2e-5 + 20 * abs(float(vl_p) - float(vl_o)))
+    close(pl, pl_o, atol=2e-5 + 20 * abs(pl_p.item() - pl_o.item())); close(vl, vl_o, atol=2e-5 + 20 * abs(vl_p.item() - vl_o.item()))
     for k, p in m.named_parameters():
         if k.startswith(HEADS) and p.numel() > 0:
             sens = (Wp[k].grad - Wg[k].grad).abs().max().item()
