@@ -37,7 +37,7 @@ CFG2 = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8,
             num_spatial_tokens=4, num_register_tokens=8, max_steps=64, multi_token_pred_len=8, num_discrete_actions=4)
 B_LOCAL, HORIZON, NUM_STEPS = 256, 15, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-EVENT_STRIDE = 8                       # timed region: every 8th launch of the dominant GEMM configuration carries an event pair
+EVENT_STRIDE = 7                       # timed region: every 7th launch of the dominant GEMM configuration carries an event pair (7 is co-prime to the ~30-launch per-evaluation pattern, so every shape is sampled)
 FLOP_PER_IMAGINED_STEP = 5.23e9        # GEMM flops per generated frame of one trajectory (cfg 2)
 
 
