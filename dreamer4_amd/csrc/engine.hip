@@ -904,6 +904,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
 int d4_profile_enable(int on) { return d4::gemm_profile_enable(on); }
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { return d4::gemm_profile_read(ms, flops, count, nclass); }
 int d4_profile_classes(void) { return d4::gemm_profile_classes(); }
+int d4_gemm_force_config(int id) { return d4::gemm_force_config(id); }
 const char* d4_profile_class_name(int c) { return d4::gemm_profile_class_name(c); }
 
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {

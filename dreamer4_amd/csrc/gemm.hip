@@ -95,9 +95,17 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
     // Two register sets for the global->LDS staging: the loads of k-tile j+2 are in flight while k-tile j+1 (loaded one
     // iteration earlier, certainly arrived) is written to the other LDS buffer in the shadow of the MFMAs of tile j.
     f32x4 ra[2][A_F4], rb[2][B_F4];
-    float ssq[A_F4];
+    // Row sums of squares for the folded RMSNorm, in ONE canonical order whatever the tile configuration: eight running sums
+    // per row (16-byte chunk index mod 8 along k), each fed in k order with an explicitly fused a0^2 + a1^2 + a2^2 + a3^2, then
+    // the tree ((0+1)+(2+3)) + ((4+5)+(6+7)).  With BK = 32 a thread owns one chunk position; with BK = 16 it owns position c of
+    // even k-tiles and 4 + c of odd ones.  (Needed for the tuner's freedom: every configuration must give the same bits.)
+    static_assert(BK == 16 || BK == 32, "canonical row-sum order is defined for BK = 16 / 32");
+    constexpr int NPAR = 32 / BK;
+    float ssq[A_F4][NPAR];
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) ssq[i] = 0.f;
+    for (int i = 0; i < A_F4; ++i)
+#pragma unroll
+        for (int h = 0; h < NPAR; ++h) ssq[i][h] = 0.f;
 
     // one operand tile -> registers.  Non-transposed: memory [rows][K], float4 along K.  Transposed: memory
     // [K][rows], float4 along rows (scattered into LDS by store_tile).
@@ -137,8 +145,9 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
         load_operand(rb[SET], rsB, p.ldw, rowsB, k0, std::integral_constant<bool, TB>{}, std::integral_constant<int, BN>{});
     };
 
-    auto store_tile = [&](int buf, auto set_tag) {
+    auto store_tile = [&](int buf, auto set_tag, auto parity_tag) {
         constexpr int SET = decltype(set_tag)::value;
+        constexpr int PAR = decltype(parity_tag)::value % NPAR;
         float* as = As + buf * BM * LDS_LD;
         float* bs = Bs + buf * BN * LDS_LD;
 #pragma unroll
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
             if constexpr (!TA) {
                 int r = idx / RF4, c = (idx % RF4) * 4;
                 *reinterpret_cast<f32x4*>(as + r * LDS_LD + c) = v;
-                ssq[i] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                ssq[i][PAR] = ssq[i][PAR] + __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], v[0] * v[0])));
             } else {
                 int kk = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
 #pragma unroll
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
     using Set1 = std::integral_constant<int, 1>;
     const int nk = (p.K + BK - 1) / BK;
     load_tile(0, Set0{});
-    store_tile(0, Set0{});
+    store_tile(0, Set0{}, Set0{});
     if (nk > 1) load_tile(BK, Set0{});            // k-tile j lives in register set (j - 1) & 1 until it is staged
     if (nk > 2) load_tile(2 * BK, Set1{});
     __syncthreads();
@@ -210,17 +219,17 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
     };
-    auto iteration = [&](int kt, auto set_tag) {
+    auto iteration = [&](int kt, auto set_tag, auto next_parity) {
         const int cur = kt & 1;
         mfma_steps(cur, 0, 1);
-        if (kt + 1 < nk) store_tile(cur ^ 1, set_tag);          // k-tile kt+1: in registers since the previous iteration
+        if (kt + 1 < nk) store_tile(cur ^ 1, set_tag, next_parity);   // k-tile kt+1: in registers since the previous iteration
         if (kt + 3 < nk) load_tile((kt + 3) * BK, set_tag);     // refill the set just drained
         mfma_steps(cur, 1, BK / 8);
         __syncthreads();
     };
     for (int kt = 0; kt < nk; kt += 2) {
-        iteration(kt, Set0{});
-        if (kt + 1 < nk) iteration(kt + 1, Set1{});
+        iteration(kt, Set0{}, Set1{});                            // kt even: the tile staged is odd
+        if (kt + 1 < nk) iteration(kt + 1, Set1{}, Set0{});
     }
 
     // ---- intra-block split-K: fold the partner group's accumulators through LDS (fixed order: group 0 + group 1)
@@ -253,11 +262,17 @@ __global__ __launch_bounds__(WGM * WGN * 64 * KS) void gemm_kernel(GemmArgs p) {
         if constexpr (!TA) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                float s = ssq[i];
+                float s = ssq[i][0];
                 s += dpp_f<0xB1>(s);
-                s += dpp_f<0x4E>(s);    // RF4 (4, 8 or 16) consecutive lanes share one row
-                if (RF4 >= 8) s += dpp_f<0x141>(s);
-                if (RF4 == 16) s += dpp_f<0x140>(s);
+                s += dpp_f<0x4E>(s);    // RF4 (4 or 8) consecutive lanes share one row
+                if constexpr (NPAR == 1) {
+                    s += dpp_f<0x141>(s);                          // (0123) + (4567): the other half of the row's 8 lanes
+                } else {
+                    float s1 = ssq[i][1];
+                    s1 += dpp_f<0xB1>(s1);
+                    s1 += dpp_f<0x4E>(s1);
+                    s = s + s1;                                    // (0123) + (4567)
+                }
                 int r = (tid + i * NT) / RF4;
                 if ((tid % RF4) == 0) rowscale_s[r] = rsqrtf(s / (float)p.K + p.rms_eps);
             }
@@ -486,6 +501,8 @@ struct TuneKey {
     bool operator<(const TuneKey& o) const { return std::tie(M, N, K, flags, batch) < std::tie(o.M, o.N, o.K, o.flags, o.batch); }
 };
 static std::map<TuneKey, int> g_tuned;
+static int g_forced_cfg = -1;          // test hook (d4_gemm_force_config): run this configuration wherever it is valid
+int gemm_force_config(int id) { g_forced_cfg = id; return N_TILE_CFG; }
 
 // D4_GEMM_TUNE_CACHE=<file>: the shape -> configuration table is read at first use and every new entry is appended, so a
 // later process (a profiler pass, a restarted trainer) starts with the choices already made and never re-times.
@@ -555,6 +572,7 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
     const int nb = p.batch > 0 ? p.batch : 1;
     const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
+    if (g_forced_cfg >= 0 && g_forced_cfg < N_TILE_CFG && cfg_valid<TA, TB>(g_forced_cfg, p)) return launch_id<TA, TB>(g_forced_cfg, p, stream);
     tune_cache_load();
     auto it = g_tuned.find(key);
     if (it != g_tuned.end() && cfg_valid<TA, TB>(it->second, p)) return launch_id<TA, TB>(it->second, p, stream);

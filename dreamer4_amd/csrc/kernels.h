@@ -39,6 +39,7 @@ int gemm_profile_enable(int on);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int gemm_profile_classes();
+int gemm_force_config(int id);                             // test hook; returns the number of configurations
 const char* gemm_profile_class_name(int c);
 
 // ------------------------------------------------------------------------------------ small attention

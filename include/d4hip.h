@@ -186,6 +186,10 @@ int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int d4_profile_classes(void);
 const char* d4_profile_class_name(int c);
 
+/* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it).
+ * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
+int d4_gemm_force_config(int id);
+
 /* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr);
 

@@ -80,6 +80,28 @@ def test_gemm_is_deterministic(lib):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('M,N,K,flags', [(3584, 1552, 512, 1), (3584, 512, 1376, 0), (3584, 2752, 512, 5), (1000, 300, 72, 3), (300, 520, 256, 1)])
+def test_every_tile_configuration_gives_the_same_bits(lib, M, N, K, flags):
+    """The tuner may pick any tile configuration per shape, so all of them must agree bit for bit (same k order, same MFMA,
+    one canonical order for the folded RMSNorm's row sums)."""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g); b = torch.randn(N, device='cuda', generator=g)
+    Nout = N // 2 if flags & _lib.GEMM_SWIGLU else N
+    outs = []
+    n = lib.d4_gemm_force_config(-1)
+    try:
+        for cfg in range(n):
+            lib.d4_gemm_force_config(cfg)
+            o = torch.full((M, Nout), float('nan'), device='cuda')
+            _lib.check(lib.d4_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(o), Nout, _lib.ptr(b), None, 0, M, N, K, flags, 1e-6, stream()))
+            outs.append(o)
+    finally:
+        lib.d4_gemm_force_config(-1)
+    assert n >= 8
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_gemm_rejects_misaligned_operands(lib):
     A = torch.randn(8, 34, device='cuda')
     with pytest.raises(_lib.D4Error, match='multiples of 4'):
