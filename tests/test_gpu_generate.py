@@ -299,6 +299,28 @@ def test_env_wrapper_usage_pattern_prompt_plus_time_cache():
         lat_hist, act_hist = e.latents.cpu(), e.actions.discrete.cpu()
 
 
+def test_long_chain_of_single_frame_calls_equals_one_rollout():
+    """40 env-style calls (one new frame each, prompt = everything so far, time cache carried) against ONE 40-frame rollout
+    with the same noise: the carried KV cache survives the engine's workspace re-allocations (frame capacity grows
+    geometrically) and the per-call prompt handling adds nothing."""
+    m = small_model().cuda()
+    cfg = oracle_config(m)
+    B, T = 3, 40
+    nz = make_noise(cfg, T, B, 123)
+    whole = m.generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, noise=nz)
+    m2 = small_model().cuda()
+    lat = torch.zeros(B, 0, 6, 8, device='cuda'); act = torch.zeros(B, 0, 1, dtype=torch.long, device='cuda'); tc = None
+    for i in range(T):
+        sub = {k: (v[i:i + 1] if v is not None else None) for k, v in nz.items()}
+        kw = dict(prompt_latents=lat, prompt_discrete_actions=act) if i > 0 else {}
+        e, tc = m2.generate(i + 1, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
+                            return_log_probs_and_values=True, time_cache=tc, return_time_cache=True, noise=sub, **kw)
+        assert tc.frames == i + 1
+        lat, act = e.latents, e.actions.discrete
+    close(lat, whole.latents, atol=1e-5); assert torch.equal(act, whole.actions.discrete)
+    close(e.values[:, -1], whole.values[:, -1], atol=1e-5)
+
+
 @pytest.mark.parametrize('B,T,K', [(1, 1, 4), (1, 3, 2), (5, 2, 64), (2, 3, 8)])
 def test_edge_shapes_vs_oracle(B, T, K):
     m = small_model()
