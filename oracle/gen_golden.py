@@ -12,6 +12,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   weights.npz      reference state_dict of the fixture model
   generate.npz     generate() in four modes: cached, no time cache, 2-frame prompt, 3 chained calls
   forward.npz      one parallel forward over 4 frames (+ the same frames fed one at a time with the cache)
+  variant.npz      a second architecture (weights_variant.npz): generate cached / uncached, ppo + pmpo losses and gradients
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -43,6 +44,11 @@ CFG = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=4, time_block_every=
            num_discrete_actions=(4,), num_tasks=3, reward_num_bins=63, value_num_bins=63, multi_token_pred_len=4)
 
 
+CFG_VARIANT = dict(dim=48, dim_latent=4, num_latent_tokens=5, depth=3, time_block_every=1, attn_heads=1, attn_dim_head=64,
+                   num_spatial_tokens=2, num_register_tokens=0, num_discrete_actions=(3, 2), num_tasks=0, reward_num_bins=31,
+                   value_num_bins=31, multi_token_pred_len=1)
+
+
 def fixture_config():
     return Config(**CFG)
 
@@ -62,6 +68,20 @@ def exp_dict(prefix, e, out):
     out[prefix + 'terminals'] = npy(e.terminals)
     out[prefix + 'unembeds'] = npy(e.old_action_unembeds.discrete)
     out[prefix + 'episode_return'] = npy(e.episode_return)
+
+
+def min_margin_multi(e, noise, cfg):
+    """min_margin for several action types: the top-2 gap is taken inside each type's slice of the logits."""
+    lg = e.old_action_unembeds.discrete
+    F = lg.shape[1]
+    u = noise['gumbel_u'][:F].transpose(0, 1)
+    g = -torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+    z, o, best = lg + g, 0, float('inf')
+    for n in cfg.num_discrete_actions:
+        top = z[..., o:o + n].topk(2, dim=-1).values
+        best = min(best, float((top[..., 0] - top[..., 1]).min()))
+        o += n
+    return best
 
 
 def noise_dict(prefix, nz, out):
@@ -251,6 +271,39 @@ def main():
                 out['final_sample/' + k] = npy(p.flatten()[::97])
                 out['final_delta_norm/' + k] = npy((p - W[k]).norm())
     np.savez(os.path.join(OUT, 'trainer.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    # ------------------------------------------------------------------ a second architecture (variant.npz, weights_variant.npz)
+    # two discrete action types, no register tokens, no tasks, one attention head, a time layer in every block,
+    # two spatial tokens, single-token prediction: the options the main fixture leaves at one value
+    cfg2 = Config(**CFG_VARIANT)
+    mv = build_reference_model(cfg2, seed=3)
+    with torch.no_grad():
+        mv.action_embedder.discrete_action_unembed.mul_(0.3)
+    Wv = weights_of(mv)
+    np.savez(os.path.join(OUT, 'weights_variant.npz'), **{k: npy(v) for k, v in Wv.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in CFG_VARIANT.items()})
+    out = {}
+    Bv, Tv = 4, 5
+    nz = make_noise(cfg2, Tv, Bv, 301)
+    with injected(nz):
+        e = mv.generate(Tv, batch_size=Bv, return_for_policy_optimization=True, num_steps=8)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin_multi(e, nz, cfg2))
+    nz = make_noise(cfg2, Tv, Bv, 302)
+    with injected(nz):
+        e2 = mv.generate(Tv, batch_size=Bv, return_for_policy_optimization=True, use_time_cache=False)
+    exp_dict('nocache_', e2, out); noise_dict('nocache_', nz, out)
+    out['nocache_margin'] = np.array(min_margin_multi(e2, nz, cfg2))
+    for obj in ('ppo', 'pmpo'):
+        mv.zero_grad()
+        pl_, vl_ = mv.learn_from_experience(e, objective=obj)
+        pl_.backward(); vl_.backward()
+        out[f'{obj}_policy_loss'], out[f'{obj}_value_loss'] = npy(pl_), npy(vl_)
+        for k, p in mv.named_parameters():
+            if k.startswith(heads) and p.numel() > 0 and p.grad is not None and (p.ndim == 1 or 'unembed' in k):
+                out[f'{obj}_grad/{k}'] = npy(p.grad)
+    np.savez(os.path.join(OUT, 'variant.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('variant margins', out['cached_margin'], out['nocache_margin'], 'lens', out['cached_lens'], out['nocache_lens'])
+
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')
 

@@ -366,7 +366,7 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
     sig = W['signal_levels_embed.weight'][signal_levels]                             # b t d/2
     stp = W['step_size_embed.weight'][step_log2].expand(b, t, -1)
     flow_tok = torch.cat((sig, stp), dim=-1)[:, :, None]
-    regs = W['register_tokens'].expand(b, t, -1, -1)
+    regs = (W['register_tokens'] if cfg.num_register_tokens > 0 else latents.new_zeros(0, d)).expand(b, t, -1, -1)
     agent = W['agent_learned_embed'].expand(b, -1, -1)                               # b 1 d
     if tasks is not None:
         agent = agent + W['task_embed.weight'][tasks][:, None]

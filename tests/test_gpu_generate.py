@@ -45,6 +45,27 @@ def test_generate_cached_vs_reference_fixture(GM):
     assert e.step_size == 16 and e.is_from_world_model is True
 
 
+def test_variant_architecture_vs_reference_fixture():
+    """Second reference-pinned architecture (two action types, no register tokens, no tasks, one head, every layer a time
+    layer, two spatial tokens, single-token prediction) through the HIP engine, with and without the time cache."""
+    g = load_golden('variant.npz')
+    m = golden_model('weights_variant.npz').cuda()
+    e = m.generate(5, batch_size=4, num_steps=8, return_for_policy_optimization=True, noise=golden_noise(g, 'cached_'))
+    check_exp(e, g, 'cached_')
+    e2 = m.generate(5, batch_size=4, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(g, 'nocache_'))
+    check_exp(e2, g, 'nocache_')
+    for obj in ('ppo', 'pmpo'):
+        m.zero_grad()
+        pl, vl = m.learn_from_experience(e, objective=obj)
+        close(pl, g[f'{obj}_policy_loss'], atol=2e-5); close(vl, g[f'{obj}_value_loss'], atol=2e-5)
+        pl.backward(); vl.backward()
+        P = dict(m.named_parameters())
+        for k, v in g.items():
+            if k.startswith(f'{obj}_grad/'):
+                ref = t(v)
+                close(P[k.split('/', 1)[1]].grad, ref, atol=1e-3 * ref.abs().max().item() + 2e-6, rtol=2e-3)
+
+
 def test_generate_without_time_cache_vs_reference_fixture(GM):
     m, G = GM
     e = m.generate(5, batch_size=3, num_steps=2, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(G, 'nocache_'))

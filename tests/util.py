@@ -62,8 +62,8 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
-def golden_config_kwargs():
-    w = load_golden('weights.npz')
+def golden_config_kwargs(weights='weights.npz'):
+    w = load_golden(weights)
     kw = {}
     for k, v in w.items():
         if k.startswith('cfg_'):
@@ -72,22 +72,22 @@ def golden_config_kwargs():
     return kw
 
 
-def golden_oracle():
+def golden_oracle(weights='weights.npz'):
     """(Config, W) of the fixture model for oracle/restate.py."""
-    w = load_golden('weights.npz')
-    cfg = Config(**golden_config_kwargs())
+    w = load_golden(weights)
+    cfg = Config(**golden_config_kwargs(weights))
     W = {k: torch.from_numpy(v) for k, v in w.items() if not k.startswith(('cfg_', 'meta_'))}
     return cfg, W
 
 
-def golden_model():
+def golden_model(weights='weights.npz'):
     """Product model carrying the fixture weights (loaded by reference state_dict key)."""
     from dreamer4_amd import DynamicsWorldModel
-    kw = golden_config_kwargs()
+    kw = golden_config_kwargs(weights)
     rb, vb = kw.pop('reward_num_bins'), kw.pop('value_num_bins')
     kw['num_discrete_actions'] = tuple(kw['num_discrete_actions']) if isinstance(kw['num_discrete_actions'], (tuple, list)) else kw['num_discrete_actions']
     m = DynamicsWorldModel(**kw, reward_encoder_kwargs=dict(num_bins=rb), value_encoder_kwargs=dict(num_bins=vb))
-    _, W = golden_oracle()
+    _, W = golden_oracle(weights)
     own = dict(m.named_parameters())
     missing = [k for k, p in own.items() if p.numel() > 0 and k not in W and k != 'reward_learned_embed']
     assert not missing, f'fixture lacks keys {missing}'
