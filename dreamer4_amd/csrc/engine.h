@@ -68,6 +68,7 @@ struct d4_engine {
     d4::AttnW cross, lq_in, lq_out;
     d4::FfW sff;
     const float *vres_norm, *vres_w, *inv_freq, *lq_in_queries, *lq_out_queries, *latent_norm, *latent_w;
+    const float *lin_w = nullptr, *lin_b = nullptr;      // num_spatial_tokens == num_latent_tokens: Linear(dim_latent -> dim)
     const float *registers, *signal_embed, *step_embed, *agent_learned, *action_learned, *task_embed, *action_embed;
     const float *action_unembed; float* action_unembed_grad;
     const float *reward_norm, *reward_w, *reward_centers, *value_centers, *value_support;

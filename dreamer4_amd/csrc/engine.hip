@@ -61,7 +61,7 @@ int engine_layout(d4_engine* e, bool assign) {
     e->lout_q = fl((size_t)n * hd);
     e->lout_gate = fl((size_t)n * c.attn_heads);
     e->qtmp = fl((size_t)(n > ns ? n : ns) * D);
-    e->lout_w = fl((size_t)dl * hd);
+    e->lout_w = fl((size_t)dl * (hd > D ? hd : D));      // LQAP path: [dl][hd]; same-length path: [dl][D] (gamma folded)
     e->action_offsets = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
     e->action_sizes = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
 
@@ -221,12 +221,18 @@ int engine_resolve(d4_engine* e) {
     e->vres_norm = r.get("transformer.to_value_residual.0.weight", D);
     e->vres_w = r.get("transformer.to_value_residual.1.weight", (int64_t)e->hd * D);
     e->inv_freq = r.get("transformer.time_rotary.inv_freq", 32);
-    r.attn(e->lq_in, "latents_to_spatial_tokens.attn.", D, c.dim_latent, h, true, false);
-    e->lq_in_queries = r.get("latents_to_spatial_tokens.queries", (int64_t)c.num_spatial_tokens * D);
     e->latent_norm = r.get("to_latent_pred.0.weight", D);
-    r.attn(e->lq_out, "to_latent_pred.1.attn.", D, D, h, true, false);
-    e->lq_out_queries = r.get("to_latent_pred.1.queries", (int64_t)c.num_latent_tokens * D);
     e->latent_w = r.get("to_latent_pred.2.weight", (int64_t)c.dim_latent * D);
+    if (c.num_spatial_tokens == c.num_latent_tokens) {
+        // one spatial token per latent token: Linear in, RMSNorm -> Linear out, no learned-query pools   D4:4816-4834
+        e->lin_w = r.get("latents_to_spatial_tokens.weight", (int64_t)D * c.dim_latent);
+        e->lin_b = r.get("latents_to_spatial_tokens.bias", D);
+    } else {
+        r.attn(e->lq_in, "latents_to_spatial_tokens.attn.", D, c.dim_latent, h, true, false);
+        e->lq_in_queries = r.get("latents_to_spatial_tokens.queries", (int64_t)c.num_spatial_tokens * D);
+        r.attn(e->lq_out, "to_latent_pred.1.attn.", D, D, h, true, false);
+        e->lq_out_queries = r.get("to_latent_pred.1.queries", (int64_t)c.num_latent_tokens * D);
+    }
     e->registers = r.get("register_tokens", (int64_t)c.num_register_tokens * D);
     e->signal_embed = r.get("signal_levels_embed.weight", (int64_t)c.max_steps * (D / 2));
     e->step_embed = r.get("step_size_embed.weight", (int64_t)(int)round(log2((double)c.max_steps)) * (D / 2));
@@ -306,6 +312,9 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
 
     // learned-query pools: the query side is batch independent -> evaluate once        D4:2189, 2206
     const int dl = c.dim_latent, ns = c.num_spatial_tokens, n = c.num_latent_tokens;
+    if (ns == n) {
+        if ((rc = fold_rows(e->latent_w, e->latent_norm, e->lout_w, dl, D, D, s))) return rc;       // W_latent . diag(gamma)
+    } else {
     if ((rc = fold_rows(e->lq_in.to_k, e->lq_in.norm_ctx, e->lin_kv_w, hd, dl, dl, s))) return rc;
     if ((rc = fold_rows(e->lq_in.to_v, e->lq_in.norm_ctx, e->lin_kv_w + (size_t)hd * dl, hd, dl, dl, s))) return rc;
     if ((rc = rmsnorm_rows(e->lq_in_queries, D, e->lq_in.norm, e->qtmp, D, ns, D, RMS_EPS, s))) return rc;
@@ -320,6 +329,7 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
     // the pool's output projection and the latent Linear are back-to-back linear maps with nothing in between
     // (D4:2068, 4833): fold them, W[dl][hd] = W_latent[dl][D] . W_out[D][hd]
     if ((rc = gemm_simple(e->latent_w, D, e->lq_out.to_out, hd, e->lout_w, hd, dl, hd, D, GEMM_TRANS_B, nullptr, nullptr, 0, s))) return rc;
+    }
 
     int32_t offs[D4_MAX_ACTION_TYPES] = {0}, sizes[D4_MAX_ACTION_TYPES] = {0};
     int o = 0;
@@ -403,7 +413,11 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     const int Fr = B * Tq, M = Fr * S;
     int rc;
 
-    // ---- latents -> spatial tokens (LearnedQueriesAttentionPool, D4:7168)
+    // ---- latents -> spatial tokens (LearnedQueriesAttentionPool, D4:7168; a plain Linear when there is one per latent)
+    const bool same_len = ns == n;
+    if (same_len) {
+        if ((rc = gemm_simple(latents, dl, e->lin_w, dl, e->space, D, Fr * n, D, dl, 0, e->lin_b, nullptr, 0, s))) return rc;
+    } else {
     if ((rc = gemm_simple(latents, dl, e->lin_kv_w, dl, e->lkv, 2 * hd, Fr * n, 2 * hd, dl, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
     {
         SmallAttnArgs sa{};
@@ -417,6 +431,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         if ((rc = small_attn(sa, s))) return rc;
     }
     if ((rc = gemm_simple(e->latt, hd, e->lq_in.to_out, hd, e->space, D, Fr * ns, D, hd, 0, nullptr, nullptr, 0, s))) return rc;
+    }
 
     // ---- pack tokens (D4:7182-7222)
     float* slab0 = e->slabs;
@@ -522,6 +537,11 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     if ((rc = pool_block(e, c.depth - 1, xfc, xfc, e->nslab, Mc, s, e->cslabs))) return rc;
 
     // ---- to_latent_pred: RMSNorm -> LQAP (n queries over the ns spatial tokens) -> Linear  (D4:7251)
+    if (same_len) {
+        // RMSNorm -> Linear on the spatial rows (gamma folded into the weight, 1/rms in the GEMM)
+        if ((rc = copy_rows(xfc, nkeep * D, e->gs, ns * D, Fr, ns * D, s))) return rc;
+        return gemm_simple(e->gs, D, e->lout_w, D, e->pred, dl, Fr * n, dl, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s);
+    }
     if ((rc = gather_space_double_norm(xfc, e->gs, e->latent_norm, e->lq_out.norm_ctx, Fr, nkeep, 0, D, ns, RMS_EPS, s))) return rc;
     if ((rc = gemm_simple(e->gs, D, e->lout_kv_w, D, e->okv, 2 * hd, Fr * ns, 2 * hd, D, 0, nullptr, nullptr, 0, s))) return rc;
     {
@@ -603,7 +623,6 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     D4_REQUIRE(c.pool_dim_head == 64, "pool_dim_head=%d: only 64 is implemented", c.pool_dim_head);
     D4_REQUIRE(c.dim % 4 == 0 && c.dim_latent % 4 == 0, "dim and dim_latent must be multiples of 4");
     D4_REQUIRE(c.depth >= 1 && c.time_block_every >= 1, "bad depth/time_block_every");
-    D4_REQUIRE(c.num_spatial_tokens != c.num_latent_tokens, "num_spatial_tokens == num_latent_tokens (Linear latents_to_spatial path) is not implemented");
     D4_REQUIRE(c.num_discrete_action_types >= 0 && c.num_discrete_action_types <= D4_MAX_ACTION_TYPES, "too many action types");
     D4_REQUIRE(c.num_latent_tokens <= 64 && c.num_spatial_tokens <= 64, "at most 64 latent / spatial tokens");
     D4_REQUIRE((c.max_steps & (c.max_steps - 1)) == 0, "max_steps must be a power of two");

@@ -142,8 +142,6 @@ class DynamicsWorldModel(nn.Module):
             raise AssertionError('`num_latent_tokens` must be set')
         if attn_dim_head != 64:
             raise NotImplementedError('attn_dim_head must be 64 (one CDNA wavefront per head row)')
-        if num_spatial_tokens == num_latent_tokens:
-            raise NotImplementedError('num_spatial_tokens == num_latent_tokens (Linear latents_to_spatial) is not implemented')
         assert dim % 2 == 0
         assert log2(max_steps).is_integer(), '`max_steps` must be a power of 2'
 
@@ -229,11 +227,17 @@ class DynamicsWorldModel(nn.Module):
                 reg(f'{pre}layers.{i}.1.weight', _linear_w(b, a))
                 reg(f'{pre}layers.{i}.1.bias', _linear_b(b, a))
 
-        reg('latents_to_spatial_tokens.queries', torch.randn(self.num_spatial_tokens, D) * 1e-2)
-        attn('latents_to_spatial_tokens.attn.', D, dl, h, True, False)
-        reg('to_latent_pred.0.weight', torch.ones(D))
-        reg('to_latent_pred.1.queries', torch.randn(self.num_latent_tokens, D) * 1e-2)
-        attn('to_latent_pred.1.attn.', D, D, h, True, False)
+        if self.num_spatial_tokens == self.num_latent_tokens:
+            # one spatial token per latent token: Linear(dim_latent, dim) in, RMSNorm -> [Identity] -> Linear out   D4:4816-4834
+            reg('latents_to_spatial_tokens.weight', _linear_w(D, dl))
+            reg('latents_to_spatial_tokens.bias', _linear_b(D, dl))
+            reg('to_latent_pred.0.weight', torch.ones(D))
+        else:
+            reg('latents_to_spatial_tokens.queries', torch.randn(self.num_spatial_tokens, D) * 1e-2)
+            attn('latents_to_spatial_tokens.attn.', D, dl, h, True, False)
+            reg('to_latent_pred.0.weight', torch.ones(D))
+            reg('to_latent_pred.1.queries', torch.randn(self.num_latent_tokens, D) * 1e-2)
+            attn('to_latent_pred.1.attn.', D, D, h, True, False)
         reg('to_latent_pred.2.weight', _linear_w(dl, D))
         reg('register_tokens', torch.randn(self.num_register_tokens, D) * 1e-2)
         reg('signal_levels_embed.weight', torch.randn(self.max_steps, D // 2))

@@ -13,6 +13,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   generate.npz     generate() in four modes: cached, no time cache, 2-frame prompt, 3 chained calls
   forward.npz      one parallel forward over 4 frames (+ the same frames fed one at a time with the cache)
   variant.npz      a second architecture (weights_variant.npz): generate cached / uncached, ppo + pmpo losses and gradients
+  samelen.npz      num_spatial_tokens == num_latent_tokens (weights_samelen.npz): rollout + env-wrapper style chained calls
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -47,6 +48,10 @@ CFG = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=4, time_block_every=
 CFG_VARIANT = dict(dim=48, dim_latent=4, num_latent_tokens=5, depth=3, time_block_every=1, attn_heads=1, attn_dim_head=64,
                    num_spatial_tokens=2, num_register_tokens=0, num_discrete_actions=(3, 2), num_tasks=0, reward_num_bins=31,
                    value_num_bins=31, multi_token_pred_len=1)
+
+
+CFG_SAMELEN = dict(dim=32, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=2, time_block_every=1, attn_heads=2,
+                   attn_dim_head=64, num_discrete_actions=(4,), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=8)
 
 
 def fixture_config():
@@ -303,6 +308,38 @@ def main():
                 out[f'{obj}_grad/{k}'] = npy(p.grad)
     np.savez(os.path.join(OUT, 'variant.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('variant margins', out['cached_margin'], out['nocache_margin'], 'lens', out['cached_lens'], out['nocache_lens'])
+
+    # ------------------------------------------------------------------ one spatial token per latent token (samelen.npz)
+    # num_spatial_tokens == num_latent_tokens switches latents_to_spatial_tokens to a Linear and drops the learned-query pool
+    # of to_latent_pred (D4:4816-4834); this is BASELINE config 4's shape (4 latent tokens x 16)
+    cfg3 = Config(**CFG_SAMELEN)
+    ms = build_reference_model(cfg3, seed=5)
+    with torch.no_grad():
+        ms.action_embedder.discrete_action_unembed.mul_(0.3)
+    Ws = weights_of(ms)
+    np.savez(os.path.join(OUT, 'weights_samelen.npz'), **{k: npy(v) for k, v in Ws.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in CFG_SAMELEN.items()})
+    out = {}
+    Bs, Ts = 3, 4
+    nz = make_noise(cfg3, Ts, Bs, 401)
+    with injected(nz):
+        e = ms.generate(Ts, batch_size=Bs, return_for_policy_optimization=True)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg3))
+    # env-wrapper pattern (dreamer4/env.py:445-483): one new frame per call, prompt = history, time cache carried
+    nz = make_noise(cfg3, 3, Bs, 402)
+    noise_dict('env_', nz, out)
+    lat_hist = torch.zeros(Bs, 0, 4, 16); act_hist = torch.zeros(Bs, 0, 1, dtype=torch.long); tc = None
+    for i in range(3):
+        sub = {k: v[i:i + 1] for k, v in nz.items()}
+        kw = dict(prompt_latents=lat_hist, prompt_discrete_actions=act_hist) if i > 0 else {}
+        with injected(sub):
+            e, tc = ms.generate(i + 1, batch_size=Bs, return_rewards_per_frame=True, return_agent_actions=True,
+                                return_log_probs_and_values=True, time_cache=tc, return_time_cache=True, return_terminals=False, **kw)
+        lat_hist, act_hist = e.latents, e.actions.discrete
+        out[f'env{i}_latents'], out[f'env{i}_actions'], out[f'env{i}_values'] = npy(e.latents), npy(e.actions.discrete), npy(e.values)
+    np.savez(os.path.join(OUT, 'samelen.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('samelen margin', out['cached_margin'], 'lens', out['cached_lens'])
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

@@ -361,7 +361,11 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
         latents, signal_levels, act_tok = latents[:, -1:], signal_levels[:, -1:], act_tok[:, -1:]
         t = 1
 
-    space = lq_attn_pool(cfg, W, 'latents_to_spatial_tokens.', latents)             # b t ns d
+    same_len = cfg.num_spatial_tokens == cfg.num_latent_tokens                      # D4:4816-4834: Linear in, no pool out
+    if same_len:
+        space = latents @ W['latents_to_spatial_tokens.weight'].t() + W['latents_to_spatial_tokens.bias']
+    else:
+        space = lq_attn_pool(cfg, W, 'latents_to_spatial_tokens.', latents)         # b t ns d
     step_log2 = int(math.log2(step_size))
     sig = W['signal_levels_embed.weight'][signal_levels]                             # b t d/2
     stp = W['step_size_embed.weight'][step_log2].expand(b, t, -1)
@@ -382,7 +386,8 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
     agent_embed = tokens[:, :, -1]
 
     x = rmsnorm(space_out, W['to_latent_pred.0.weight'])
-    x = lq_attn_pool(cfg, W, 'to_latent_pred.1.', x)
+    if not same_len:
+        x = lq_attn_pool(cfg, W, 'to_latent_pred.1.', x)
     pred = x @ W['to_latent_pred.2.weight'].t()
     return pred, agent_embed, new_cache
 
