@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
     const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int lane = threadIdx.x & 63;
     const int nk = p.nk, nq = p.nq;
-    const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;   // (gamma + 1) * sqrt(64)
+    const int dh = p.dh;
+    const bool act = lane < dh;                                     // head dims below 64: the upper lanes carry zeros
+    const int hl = h * dh + (act ? lane : 0);
+    const float kscale = act ? (p.k_gamma[hl] + 1.f) * sqrtf((float)dh) : 0.f;   // (gamma + 1) * sqrt(dh)
+    const float qscale = rsqrtf((float)dh);
 
     {
         constexpr int PER = (NKM + 3) / 4;
@@ -40,10 +44,10 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
             const int j = w + 4 * t;
             kr[t] = vr[t] = rr[t] = wm[t] = 0.f;
             if (j < nk) {
-                kr[t] = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
-                vr[t] = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+                kr[t] = act ? p.k[g * p.k_group_stride + j * p.k_item_stride + hl] : 0.f;
+                vr[t] = act ? p.v[g * p.v_group_stride + j * p.v_item_stride + hl] : 0.f;
                 if (p.vres) {
-                    rr[t] = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                    rr[t] = act ? p.vres[g * p.r_group_stride + j * p.r_item_stride + hl] : 0.f;
                     wm[t] = p.mix[g * p.m_group_stride + j * p.m_item_stride + h];
                 }
             }
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
     }
 
     for (int i = w; i < nq; i += 4) {
-        const float qi = p.q[g * p.q_group_stride + i * p.q_item_stride + h * 64 + lane];
+        const float qi = act ? p.q[g * p.q_group_stride + i * p.q_item_stride + hl] : 0.f;
         float s[NKM];
         float m = -FLT_MAX;
         const bool ordinary_q = p.mask_special > 0 && i < nq - p.mask_special;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
         for (int j = 0; j < NKM; ++j) {
             s[j] = -FLT_MAX;
             if (j < nk) {
-                float sc = wave_sum(qi * K[j]) * 0.125f;
+                float sc = wave_sum(qi * K[j]) * qscale;
                 if (p.softclamp > 0.f) sc = tanhf(sc / p.softclamp) * p.softclamp;
                 if (ordinary_q && j >= nk - p.mask_special) sc = -FLT_MAX;
                 s[j] = sc;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
             o -= wave_sum(o * vn) * vn;
         }
         if (p.gate) o *= sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
-        p.out[g * p.o_group_stride + i * p.o_item_stride + h * 64 + lane] = o;
+        if (act) p.out[g * p.o_group_stride + i * p.o_item_stride + hl] = o;
     }
 }
 
@@ -130,7 +134,11 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
     const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int lane = threadIdx.x & 63;
     const int n = p.nk;                                   // == nq <= 16
-    const float kscale = (p.k_gamma[h * 64 + lane] + 1.f) * 8.f;
+    const int dh = p.dh;
+    const bool act = lane < dh;                           // head dims below 64: the upper lanes carry zeros
+    const int hl = h * dh + (act ? lane : 0);
+    const float kscale = act ? (p.k_gamma[hl] + 1.f) * sqrtf((float)dh) : 0.f;
+    const float qscale = rsqrtf((float)dh);
 
     // phase 1: all global loads of this wave's tokens before the first dependent reduction
     float V[4], Kr[4], Qr[4], Rr[4], Wm[4];
@@ -139,11 +147,11 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
         const int j = w + 4 * t;
         V[t] = Kr[t] = Qr[t] = Rr[t] = Wm[t] = 0.f;
         if (j < n) {
-            Kr[t] = p.k[g * p.k_group_stride + j * p.k_item_stride + h * 64 + lane];
-            Qr[t] = p.q[g * p.q_group_stride + j * p.q_item_stride + h * 64 + lane];
-            V[t] = p.v[g * p.v_group_stride + j * p.v_item_stride + h * 64 + lane];
+            Kr[t] = act ? p.k[g * p.k_group_stride + j * p.k_item_stride + hl] : 0.f;
+            Qr[t] = act ? p.q[g * p.q_group_stride + j * p.q_item_stride + hl] : 0.f;
+            V[t] = act ? p.v[g * p.v_group_stride + j * p.v_item_stride + hl] : 0.f;
             if (p.vres) {
-                Rr[t] = p.vres[g * p.r_group_stride + j * p.r_item_stride + h * 64 + lane];
+                Rr[t] = act ? p.vres[g * p.r_group_stride + j * p.r_item_stride + hl] : 0.f;
                 Wm[t] = p.mix[g * p.m_group_stride + j * p.m_item_stride + h];
             }
         }
@@ -177,7 +185,7 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
             const f32x4 a = qrow[c], b = krow[c];
             acc += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
         }
-        float sc = acc * 0.125f;
+        float sc = acc * qscale;
         if (p.softclamp > 0.f) sc = tanhf(sc / p.softclamp) * p.softclamp;
         const bool ordinary_q = p.mask_special > 0 && i < n - p.mask_special;
         if (ordinary_q && jl >= n - p.mask_special) sc = -FLT_MAX;
@@ -217,12 +225,13 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
             o -= wave_sum(o * vn) * vn;
         }
         if (p.gate) o *= sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
-        p.out[g * p.o_group_stride + orank * p.o_item_stride + h * 64 + lane] = o;
+        if (act) p.out[g * p.o_group_stride + orank * p.o_item_stride + hl] = o;
     }
 }
 
 int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.nk >= 1 && p.nk <= 64, "small_attn: nk=%d out of range [1,64]", p.nk);
+    D4_REQUIRE(p.dh == 16 || p.dh == 32 || p.dh == 64, "small_attn: head dim %d (16, 32 or 64)", p.dh);
     D4_REQUIRE(!p.belief || p.nq == p.nk, "small_attn: belief needs self attention");
     const int waves = p.groups * p.heads;
     if (waves == 0) return 0;
@@ -386,11 +395,12 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // time axis
 
-__device__ __forceinline__ float rotate_half_lane(float x, int lane, float pos, const float* inv_freq) {
-    // freqs = cat(f, f); rotated = x * cos + cat(-x2, x1) * sin      (D4:1624, 1653-1658)
-    const float f = pos * inv_freq[lane & 31];
-    const float partner = __shfl_xor(x, 32);
-    const float half = (lane < 32) ? -partner : partner;
+__device__ __forceinline__ float rotate_half_lane(float x, int lane, float pos, const float* inv_freq, int dh) {
+    // freqs = cat(f, f); rotated = x * cos + cat(-x2, x1) * sin      (D4:1624, 1653-1658); halves are dh / 2 lanes wide
+    const int hw = dh >> 1;
+    const float f = pos * inv_freq[lane & (hw - 1)];
+    const float partner = __shfl_xor(x, hw);
+    const float half = (lane < hw) ? -partner : partner;
     float sn, cs;
     sincosf(f, &sn, &cs);
     return x * cs + half * sn;
@@ -403,23 +413,26 @@ __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     const int row = wid / p.H, h = wid % p.H;
     const int lane = threadIdx.x & 63;
     const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
-    const int hd = p.H * 64;
+    const int dh = p.dh, hd = p.H * dh;
+    const bool act = lane < dh;
+    const int hl = h * dh + (act ? lane : 0);
     const float* pr = p.proj + (int64_t)row * p.ldp;
-    float k = pr[hd + h * 64 + lane];
-    float v = pr[2 * hd + h * 64 + lane];
-    const float vr = p.vres[(int64_t)row * p.ldv + h * 64 + lane];
+    float k = act ? pr[hd + hl] : 0.f;
+    float v = act ? pr[2 * hd + hl] : 0.f;
+    const float vr = act ? p.vres[(int64_t)row * p.ldv + hl] : 0.f;
     const float w = sigmoidf(pr[3 * hd + p.H + h]);
     v = lerp_torch(v, vr, w);
     const float nrm = sqrtf(wave_sum(k * k));
-    k = k / fmaxf(nrm, 1e-12f) * ((p.k_gamma[h * 64 + lane] + 1.f) * 8.f);
+    k = k / fmaxf(nrm, 1e-12f) * (act ? (p.k_gamma[hl] + 1.f) * sqrtf((float)dh) : 0.f);
     const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
-    k = rotate_half_lane(k, lane, (float)pos, p.inv_freq);
+    k = rotate_half_lane(k, lane, (float)pos, p.inv_freq, dh);
     const int cS = p.cache_S > 0 ? p.cache_S : p.S;
     const int64_t col = (int64_t)b * cS + s;
     const int64_t cols = (int64_t)p.cache_batch * cS;
-    const int64_t off = ((col * p.H + h) * p.Tcap + pos) * 64 + lane;
+    if (!act) return;
+    const int64_t off = ((col * p.H + h) * p.Tcap + pos) * dh + lane;
     p.cache[off] = k;
-    p.cache[cols * p.H * p.Tcap * 64 + off] = v;
+    p.cache[cols * p.H * p.Tcap * dh + off] = v;
 }
 
 __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
@@ -429,34 +442,37 @@ __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const int row = wid / p.H, h = wid % p.H;
     const int lane = threadIdx.x & 63;
     const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
-    const int hd = p.H * 64;
+    const int dh = p.dh, hd = p.H * dh;
+    const bool act = lane < dh;
+    const int hl = h * dh + (act ? lane : 0);
     const float* pr = p.proj + (int64_t)row * p.ldp;
     const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
-    float q = rotate_half_lane(pr[h * 64 + lane], lane, (float)pos, p.inv_freq);
+    float q = rotate_half_lane(act ? pr[hl] : 0.f, lane, (float)pos, p.inv_freq, dh);
     const int cS = p.cache_S > 0 ? p.cache_S : p.S;
     const int64_t col = (int64_t)b * cS + s;
     const int64_t cols = (int64_t)p.cache_batch * cS;
-    const float* ck = p.cache + ((col * p.H + h) * p.Tcap) * 64 + lane;
-    const float* cv = ck + cols * p.H * p.Tcap * 64;
+    const float* ck = p.cache + ((col * p.H + h) * p.Tcap) * dh + (act ? lane : 0);
+    const float* cv = ck + cols * p.H * p.Tcap * dh;
+    const float qscale = rsqrtf((float)dh);
 
     float m = -FLT_MAX, l = 0.f, acc = 0.f;
     for (int j = 0; j <= pos; ++j) {
-        float sc = wave_sum(q * ck[j * 64]) * 0.125f;
+        float sc = wave_sum(act ? q * ck[j * dh] : 0.f) * qscale;
         if (p.softclamp > 0.f) sc = tanhf(sc / p.softclamp) * p.softclamp;
         const float mn = fmaxf(m, sc);
         const float alpha = expf(m - mn);
         const float e = expf(sc - mn);
         l = l * alpha + e;
-        acc = acc * alpha + e * cv[j * 64];
+        acc = acc * alpha + e * (act ? cv[j * dh] : 0.f);
         m = mn;
     }
     float o = acc / l;
     // belief: orthogonalise against this step's (mixed) value            D4:2049-2054
-    const float vi = cv[pos * 64];
+    const float vi = act ? cv[pos * dh] : 0.f;
     const float vn = vi / fmaxf(sqrtf(wave_sum(vi * vi)), 1e-12f);
     o -= wave_sum(o * vn) * vn;
     o *= sigmoidf(pr[3 * hd + h]);
-    p.out[(int64_t)row * p.ldo + h * 64 + lane] = o;
+    if (act) p.out[(int64_t)row * p.ldo + hl] = o;
 }
 
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {

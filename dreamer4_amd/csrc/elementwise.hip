@@ -291,26 +291,26 @@ int set_frame_state(int* state, int t0, hipStream_t s) {
     return 0;
 }
 
-// engine cache [Lt][2][cache_batch*S][H][Tcap][64]  <->  reference layout (Lt, 2, B*S, H, frames, 64)   D4:2075, 3256
+// engine cache [Lt][2][cache_batch*S][H][Tcap][dh]  <->  reference layout (Lt, 2, B*S, H, frames, dh)   D4:2075, 3256
 __global__ void cache_transfer_kernel(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap,
-                                      int frames, int to_ext) {
-    const int64_t n = (int64_t)Lt * 2 * B * S * H * frames * 64;
+                                      int frames, int to_ext, int dh) {
+    const int64_t n = (int64_t)Lt * 2 * B * S * H * frames * dh;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
-        const int d = (int)(r % 64); r /= 64;
+        const int d = (int)(r % dh); r /= dh;
         const int t = (int)(r % frames); r /= frames;
         const int h = (int)(r % H); r /= H;
         const int col = (int)(r % ((int64_t)B * S)); r /= (int64_t)B * S;
         const int kv = (int)(r % 2); r /= 2;
         const int l = (int)r;
-        const int64_t ci = ((((int64_t)(l * 2 + kv) * cache_batch * S + col) * H + h) * Tcap + t) * 64 + d;
+        const int64_t ci = ((((int64_t)(l * 2 + kv) * cache_batch * S + col) * H + h) * Tcap + t) * dh + d;
         if (to_ext) ext[i] = cache[ci]; else cache[ci] = ext[i];
     }
 }
-int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, hipStream_t s) {
-    const int64_t n = (int64_t)Lt * 2 * B * S * H * frames * 64;
+int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, int dh, hipStream_t s) {
+    const int64_t n = (int64_t)Lt * 2 * B * S * H * frames * dh;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(cache_transfer_kernel, grid1d(n), dim3(256), 0, s, cache, ext, Lt, cache_batch, B, S, H, Tcap, frames, to_ext);
+    hipLaunchKernelGGL(cache_transfer_kernel, grid1d(n), dim3(256), 0, s, cache, ext, Lt, cache_batch, B, S, H, Tcap, frames, to_ext, dh);
     D4_LAUNCH_CHECK();
     return 0;
 }

@@ -96,7 +96,7 @@ int engine_layout(d4_engine* e, bool assign) {
     e->pact = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * Fr * (e->na > 0 ? e->na : 1)));
     e->fstate = reinterpret_cast<int*>(alloc_bytes(sizeof(int) * 16));
     e->tasks_dev = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * e->maxB));
-    e->cache = fl((size_t)(e->Lt > 0 ? e->Lt : 1) * 2 * e->maxB * S * c.attn_heads * e->Tcap * 64);
+    e->cache = fl((size_t)(e->Lt > 0 ? e->Lt : 1) * 2 * e->maxB * S * c.attn_heads * e->Tcap * c.attn_dim_head);
 
     int maxdim = 4 * D;
     if (c.reward_num_bins > maxdim) maxdim = c.reward_num_bins;
@@ -161,8 +161,8 @@ struct Resolver {
         if (grad) *grad = it->second.g;
         return it->second.p;
     }
-    void attn(AttnW& a, const std::string& pre, int dim_q, int dim_kv, int heads, bool ctx_norm, bool mix) {
-        const int inner = heads * 64;
+    void attn(AttnW& a, const std::string& pre, int dim_q, int dim_kv, int heads, bool ctx_norm, bool mix, int dh = 64) {
+        const int inner = heads * dh;
         a.norm = get((pre + "norm.weight").c_str(), dim_q);
         if (ctx_norm) a.norm_ctx = get((pre + "norm_context.weight").c_str(), dim_kv);
         a.to_q = get((pre + "to_q.weight").c_str(), (int64_t)inner * dim_q);
@@ -170,7 +170,7 @@ struct Resolver {
         a.to_v = get((pre + "to_v.weight").c_str(), (int64_t)inner * dim_kv);
         a.to_out = get((pre + "to_out.weight").c_str(), (int64_t)dim_q * inner);
         a.to_gates = get((pre + "to_gates.0.weight").c_str(), (int64_t)heads * dim_q);
-        a.k_gamma = get((pre + "k_heads_rmsnorm.gamma").c_str(), (int64_t)heads * 64);
+        a.k_gamma = get((pre + "k_heads_rmsnorm.gamma").c_str(), (int64_t)heads * dh);
         if (mix) {
             a.mix_w = get((pre + "to_learned_value_residual_mix.0.weight").c_str(), (int64_t)heads * dim_q);
             a.mix_b = get((pre + "to_learned_value_residual_mix.0.bias").c_str(), heads);
@@ -209,18 +209,18 @@ int engine_resolve(d4_engine* e) {
     e->layer_attn.assign(c.depth, AttnW{});
     e->layer_ff.assign(c.depth, FfW{});
     for (int l = 0; l < c.depth; ++l) {
-        r.attn(e->layer_attn[l], keyf("transformer.layers.%d.2.fn.", l), D, D, h, false, true);
+        r.attn(e->layer_attn[l], keyf("transformer.layers.%d.2.fn.", l), D, D, h, false, true, c.attn_dim_head);
         r.ff(e->layer_ff[l], keyf("transformer.layers.%d.3.fn.", l), D, e->inner);
     }
     e->pools.assign(c.depth, AttnW{});
     for (int p = 0; p < c.depth - 1; ++p)
         r.attn(e->pools[p], keyf("transformer.attn_pools.%d.fn.attn.", p), D, D, c.pool_heads, true, false);
     r.attn(e->pools[c.depth - 1], "transformer.final_attn_pool.fn.attn.", D, D, c.pool_heads, true, false);
-    r.attn(e->cross, "transformer.final_special_cross_attn.fn.", D, D, h, true, false);
+    r.attn(e->cross, "transformer.final_special_cross_attn.fn.", D, D, h, true, false, c.attn_dim_head);
     r.ff(e->sff, "transformer.final_special_ff.fn.", D, e->inner);
     e->vres_norm = r.get("transformer.to_value_residual.0.weight", D);
     e->vres_w = r.get("transformer.to_value_residual.1.weight", (int64_t)e->hd * D);
-    e->inv_freq = r.get("transformer.time_rotary.inv_freq", 32);
+    e->inv_freq = r.get("transformer.time_rotary.inv_freq", c.attn_dim_head / 2);
     e->latent_norm = r.get("to_latent_pred.0.weight", D);
     e->latent_w = r.get("to_latent_pred.2.weight", (int64_t)c.dim_latent * D);
     if (c.num_spatial_tokens == c.num_latent_tokens) {
@@ -228,9 +228,9 @@ int engine_resolve(d4_engine* e) {
         e->lin_w = r.get("latents_to_spatial_tokens.weight", (int64_t)D * c.dim_latent);
         e->lin_b = r.get("latents_to_spatial_tokens.bias", D);
     } else {
-        r.attn(e->lq_in, "latents_to_spatial_tokens.attn.", D, c.dim_latent, h, true, false);
+        r.attn(e->lq_in, "latents_to_spatial_tokens.attn.", D, c.dim_latent, h, true, false, c.attn_dim_head);
         e->lq_in_queries = r.get("latents_to_spatial_tokens.queries", (int64_t)c.num_spatial_tokens * D);
-        r.attn(e->lq_out, "to_latent_pred.1.attn.", D, D, h, true, false);
+        r.attn(e->lq_out, "to_latent_pred.1.attn.", D, D, h, true, false, c.attn_dim_head);
         e->lq_out_queries = r.get("to_latent_pred.1.queries", (int64_t)c.num_latent_tokens * D);
     }
     e->registers = r.get("register_tokens", (int64_t)c.num_register_tokens * D);
@@ -421,6 +421,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     if ((rc = gemm_simple(latents, dl, e->lin_kv_w, dl, e->lkv, 2 * hd, Fr * n, 2 * hd, dl, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
     {
         SmallAttnArgs sa{};
+        sa.dh = c.attn_dim_head;
         sa.q = e->lin_q; sa.q_group_stride = 0; sa.q_item_stride = hd;
         sa.k = e->lkv; sa.k_group_stride = (int64_t)n * 2 * hd; sa.k_item_stride = 2 * hd;
         sa.v = e->lkv + hd; sa.v_group_stride = (int64_t)n * 2 * hd; sa.v_item_stride = 2 * hd;
@@ -462,7 +463,8 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         if (e->is_time[l]) {
             TimeAttnArgs ta{};
             ta.proj = P; ta.ldp = ldp; ta.vres = vres; ta.ldv = e->Nproj0; ta.k_gamma = a.k_gamma; ta.inv_freq = e->inv_freq;
-            ta.cache = e->cache + (size_t)e->time_index[l] * 2 * e->maxB * e->S * h * e->Tcap * 64;
+            ta.cache = e->cache + (size_t)e->time_index[l] * 2 * e->maxB * e->S * h * e->Tcap * c.attn_dim_head;
+            ta.dh = c.attn_dim_head;
             ta.out = e->att; ta.ldo = hd; ta.B = B; ta.S = S; ta.H = h; ta.Tq = Tq; ta.t0 = t0; ta.Tcap = e->Tcap;
             ta.softclamp = c.attn_softclamp_value;
             ta.cache_batch = e->maxB; ta.cache_S = e->S;
@@ -471,6 +473,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
             if ((rc = time_attn(ta, s))) return rc;
         } else {
             SmallAttnArgs sa{};
+            sa.dh = c.attn_dim_head;
             const int64_t gs = (int64_t)S * ldp;
             sa.q = P; sa.q_group_stride = gs; sa.q_item_stride = ldp;
             sa.k = P + hd; sa.k_group_stride = gs; sa.k_item_stride = ldp;
@@ -522,6 +525,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         if ((rc = gemm_simple(agent_in, lda, e->cq_w, D, e->cq, e->ldcq, Fr, hd + h, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
         if ((rc = gemm_simple(last, D, e->ckv_w, D, e->ckv, 2 * hd, M, 2 * hd, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
         SmallAttnArgs sa{};
+        sa.dh = c.attn_dim_head;
         sa.q = e->cq; sa.q_group_stride = e->ldcq; sa.q_item_stride = 0;
         sa.k = e->ckv; sa.k_group_stride = (int64_t)S * 2 * hd; sa.k_item_stride = 2 * hd;
         sa.v = e->ckv + hd; sa.v_group_stride = (int64_t)S * 2 * hd; sa.v_item_stride = 2 * hd;
@@ -546,6 +550,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     if ((rc = gemm_simple(e->gs, D, e->lout_kv_w, D, e->okv, 2 * hd, Fr * ns, 2 * hd, D, 0, nullptr, nullptr, 0, s))) return rc;
     {
         SmallAttnArgs sa{};
+        sa.dh = c.attn_dim_head;
         sa.q = e->lout_q; sa.q_group_stride = 0; sa.q_item_stride = hd;
         sa.k = e->okv; sa.k_group_stride = (int64_t)ns * 2 * hd; sa.k_item_stride = 2 * hd;
         sa.v = e->okv + hd; sa.v_group_stride = (int64_t)ns * 2 * hd; sa.v_item_stride = 2 * hd;
@@ -619,7 +624,8 @@ int d4_version(void) { return 1; }
 int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     D4_REQUIRE(cfg && out, "null argument");
     const d4_config& c = *cfg;
-    D4_REQUIRE(c.attn_dim_head == 64, "attn_dim_head=%d: only 64 (one wavefront per head row) is implemented", c.attn_dim_head);
+    D4_REQUIRE(c.attn_dim_head == 16 || c.attn_dim_head == 32 || c.attn_dim_head == 64,
+               "attn_dim_head=%d: 16, 32 or 64 (a head row lives in one wavefront) is implemented", c.attn_dim_head);
     D4_REQUIRE(c.pool_dim_head == 64, "pool_dim_head=%d: only 64 is implemented", c.pool_dim_head);
     D4_REQUIRE(c.dim % 4 == 0 && c.dim_latent % 4 == 0, "dim and dim_latent must be multiples of 4");
     D4_REQUIRE(c.depth >= 1 && c.time_block_every >= 1, "bad depth/time_block_every");
@@ -632,7 +638,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->D = c.dim;
     e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + 1 + 1;
     D4_REQUIRE(e->S <= 64 && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
-    e->hd = c.attn_heads * 64;
+    e->hd = c.attn_heads * c.attn_dim_head;
     e->php = c.pool_heads;
     e->hp = c.pool_heads * 64;
     e->Nproj = 3 * e->hd + 2 * c.attn_heads;
@@ -712,14 +718,14 @@ int d4_engine_cache_reset(d4_engine* e, int frames) {
 
 int d4_engine_cache_export(d4_engine* e, float* dst, int batch, void* stream) {
     D4_REQUIRE(e && dst, "null argument");
-    return d4::cache_transfer(e->cache, dst, e->Lt, e->maxB, batch, e->S, e->c.attn_heads, e->Tcap, e->cache_frames, 1,
+    return d4::cache_transfer(e->cache, dst, e->Lt, e->maxB, batch, e->S, e->c.attn_heads, e->Tcap, e->cache_frames, 1, e->c.attn_dim_head,
                               static_cast<hipStream_t>(stream));
 }
 
 int d4_engine_cache_import(d4_engine* e, const float* src, int batch, int frames, void* stream) {
     D4_REQUIRE(e && src, "null argument");
     D4_REQUIRE(frames <= e->Tcap && batch <= e->maxB, "cache_import: exceeds capacity");
-    int rc = d4::cache_transfer(e->cache, const_cast<float*>(src), e->Lt, e->maxB, batch, e->S, e->c.attn_heads, e->Tcap, frames, 0,
+    int rc = d4::cache_transfer(e->cache, const_cast<float*>(src), e->Lt, e->maxB, batch, e->S, e->c.attn_heads, e->Tcap, frames, 0, e->c.attn_dim_head,
                                 static_cast<hipStream_t>(stream));
     if (!rc) e->cache_frames = frames;
     return rc;

@@ -61,6 +61,7 @@ struct SmallAttnArgs {
     // space_attn only: restrict the QUERIES to tokens [q_lo, q_hi) plus the last token; outputs are written at item
     // rank (i - q_lo, or q_hi - q_lo for the last token).  q_hi == 0 -> all queries, natural order.
     int q_lo = 0, q_hi = 0, q_last = 1;   // q_last = 0: do not add the last token to the restricted query set
+    int dh = 64;                          // head dim (16 / 32 / 64): lanes >= dh of the wavefront idle; rows are packed h * dh + lane
 };
 int small_attn(const SmallAttnArgs& p, hipStream_t stream);
 
@@ -96,6 +97,7 @@ struct TimeAttnArgs {
     int cache_S = 0;                     // tokens per frame the cache was laid out for (0: same as S)
     const int* t0_dev = nullptr;         // when set, the frame offset is read from device memory (hipGraph replay)
     float softclamp;
+    int dh = 64;                         // head dim (16 / 32 / 64); cache rows are dh wide
 };
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream);   // normalise/rotate/mix new K,V -> cache[t0 .. t0+Tq)
 int time_attn(const TimeAttnArgs& p, hipStream_t stream);        // attend over cache[0 .. t0+i], belief + gates
@@ -142,7 +144,7 @@ int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, i
                      int hist_stride, int sig_val, int ctx_sig, hipStream_t s);
 int fill_sig(int32_t* sig, int n, int value, hipStream_t s);
 int set_frame_state(int* state, int t0, hipStream_t s);
-int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, hipStream_t s);
+int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, int dh, hipStream_t s);
 
 // latents input for a parallel (multi-frame) evaluation: context frames lerp(history, ctx_noise, w), last frame = x
 int build_latent_input(float* out, const float* hist, const float* ctx_noise, const float* x,

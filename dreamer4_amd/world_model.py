@@ -60,7 +60,7 @@ def mlp_widths(dim_in, dim, dim_out, depth):
 class TimeCache:
     """Opaque handle of the engine's time KV cache (reference: DynamicsIntermediates.main.next_kv_cache,
     token_count — dreamer4.py:3255-3265).  `kv()` materialises the reference layout
-    (time_layers, 2, B*S, heads, frames, 64)."""
+    (time_layers, 2, B*S, heads, frames, attn_dim_head)."""
 
     def __init__(self, model, frames, batch, serial):
         self._model, self.frames, self.batch, self._serial = model, frames, batch, serial
@@ -140,8 +140,8 @@ class DynamicsWorldModel(nn.Module):
             raise NotImplementedError('attn_kwargs / transformer_kwargs / ff_kwargs must be empty (reference defaults)')
         if num_latent_tokens is None:
             raise AssertionError('`num_latent_tokens` must be set')
-        if attn_dim_head != 64:
-            raise NotImplementedError('attn_dim_head must be 64 (one CDNA wavefront per head row)')
+        if attn_dim_head not in (16, 32, 64):
+            raise NotImplementedError('attn_dim_head must be 16, 32 or 64 (a head row lives in one CDNA wavefront)')
         assert dim % 2 == 0
         assert log2(max_steps).is_integer(), '`max_steps` must be a power of 2'
 
@@ -196,11 +196,12 @@ class DynamicsWorldModel(nn.Module):
     # ------------------------------------------------------------------------------ parameters
     def _build_parameters(self):
         D, dl, h = self.dim, self.dim_latent, self.attn_heads
-        hd = h * 64
+        dh = self.attn_dim_head
+        hd = h * dh
         reg = lambda k, t: _register(self, k, t)
 
-        def attn(pre, dim_q, dim_kv, heads, ctx_norm, mix):
-            inner = heads * 64
+        def attn(pre, dim_q, dim_kv, heads, ctx_norm, mix, dh=dh):
+            inner = heads * dh
             reg(pre + 'norm.weight', torch.ones(dim_q))
             if ctx_norm:
                 reg(pre + 'norm_context.weight', torch.ones(dim_kv))
@@ -209,7 +210,7 @@ class DynamicsWorldModel(nn.Module):
             reg(pre + 'to_v.weight', _linear_w(inner, dim_kv))
             reg(pre + 'to_out.weight', _linear_w(dim_q, inner))
             reg(pre + 'to_gates.0.weight', _linear_w(heads, dim_q))
-            reg(pre + 'k_heads_rmsnorm.gamma', torch.zeros(heads, 64))
+            reg(pre + 'k_heads_rmsnorm.gamma', torch.zeros(heads, dh))
             if mix:
                 reg(pre + 'to_learned_value_residual_mix.0.weight', _linear_w(heads, dim_q))
                 reg(pre + 'to_learned_value_residual_mix.0.bias', _linear_b(heads, dim_q))
@@ -258,7 +259,7 @@ class DynamicsWorldModel(nn.Module):
         if self.predict_terminals:
             mlp('to_state_terminal_pred.0.', mlp_widths(dl, 4 * dl, 1, self.terminal_mlp_depth))
         mlp('value_head.', mlp_widths(D, 4 * D, self.value_num_bins, self.value_head_mlp_depth))
-        inv_freq = 1.0 / (10000. ** (torch.arange(0, 64, 2).float() / 64))
+        inv_freq = 1.0 / (10000. ** (torch.arange(0, dh, 2).float() / dh))
         _register(self, 'transformer.time_rotary.inv_freq', inv_freq, buffer=True)
         reg('transformer.to_value_residual.0.weight', torch.ones(D))
         reg('transformer.to_value_residual.1.weight', _linear_w(hd, D))
@@ -266,8 +267,8 @@ class DynamicsWorldModel(nn.Module):
             attn(f'transformer.layers.{i}.2.fn.', D, D, h, False, True)
             ff(f'transformer.layers.{i}.3.fn.')
         for i in range(self.depth - 1):
-            attn(f'transformer.attn_pools.{i}.fn.attn.', D, D, self.pool_heads, True, False)
-        attn('transformer.final_attn_pool.fn.attn.', D, D, self.pool_heads, True, False)
+            attn(f'transformer.attn_pools.{i}.fn.attn.', D, D, self.pool_heads, True, False, dh=self.pool_dim_head)
+        attn('transformer.final_attn_pool.fn.attn.', D, D, self.pool_heads, True, False, dh=self.pool_dim_head)
         attn('transformer.final_special_cross_attn.fn.', D, D, h, True, True)
         ff('transformer.final_special_ff.fn.')
         # constructor-built buffers of the HL-Gauss encoders (hl_gauss_pytorch.HLGaussLoss.support / centers)
@@ -426,7 +427,7 @@ class DynamicsWorldModel(nn.Module):
             raise _lib.D4Error('this TimeCache is stale (the engine cache has advanced past it); '
                                'call .kv() before issuing further generate() calls to keep a copy')
         lt = sum(1 for i in range(self.depth) if (i + 1) % self.time_block_every == 0)
-        out = torch.empty(lt, 2, tc.batch * self.tokens_per_frame, self.attn_heads, tc.frames, 64, device=self.device)
+        out = torch.empty(lt, 2, tc.batch * self.tokens_per_frame, self.attn_heads, tc.frames, self.attn_dim_head, device=self.device)
         _lib.check(lib.d4_engine_cache_export(self._engine, _lib.ptr(out), tc.batch, self._stream()))
         return out
 

@@ -14,6 +14,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   forward.npz      one parallel forward over 4 frames (+ the same frames fed one at a time with the cache)
   variant.npz      a second architecture (weights_variant.npz): generate cached / uncached, ppo + pmpo losses and gradients
   samelen.npz      num_spatial_tokens == num_latent_tokens (weights_samelen.npz): rollout + env-wrapper style chained calls
+  headdim16.npz    attn_dim_head = 16 (weights_headdim16.npz): rollout, and a rollout returning the time KV cache
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -52,6 +53,10 @@ CFG_VARIANT = dict(dim=48, dim_latent=4, num_latent_tokens=5, depth=3, time_bloc
 
 CFG_SAMELEN = dict(dim=32, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=2, time_block_every=1, attn_heads=2,
                    attn_dim_head=64, num_discrete_actions=(4,), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=8)
+
+
+CFG_HEADDIM16 = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=3, time_block_every=2, attn_heads=3, attn_dim_head=16,
+                     num_discrete_actions=(4,), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=2)
 
 
 def fixture_config():
@@ -340,6 +345,28 @@ def main():
         out[f'env{i}_latents'], out[f'env{i}_actions'], out[f'env{i}_values'] = npy(e.latents), npy(e.actions.discrete), npy(e.values)
     np.savez(os.path.join(OUT, 'samelen.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('samelen margin', out['cached_margin'], 'lens', out['cached_lens'])
+
+    # ------------------------------------------------------------------ head dim 16 (headdim16.npz), the reference tests' own setting
+    cfg4 = Config(**CFG_HEADDIM16)
+    mh = build_reference_model(cfg4, seed=7)
+    with torch.no_grad():
+        mh.action_embedder.discrete_action_unembed.mul_(0.3)
+    Wh = weights_of(mh)
+    np.savez(os.path.join(OUT, 'weights_headdim16.npz'), **{k: npy(v) for k, v in Wh.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in CFG_HEADDIM16.items()})
+    out = {}
+    nz = make_noise(cfg4, 5, 3, 501)
+    with injected(nz):
+        e = mh.generate(5, batch_size=3, return_for_policy_optimization=True)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg4))
+    nz = make_noise(cfg4, 4, 3, 502)
+    with injected(nz):
+        e2, tc = mh.generate(4, batch_size=3, return_for_policy_optimization=True, use_time_cache=True, return_time_cache=True, return_terminals=False)
+    exp_dict('tc_', e2, out); noise_dict('tc_', nz, out)
+    out['tc_kv'] = npy(tc.main.next_kv_cache)
+    np.savez(os.path.join(OUT, 'headdim16.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('headdim16 margin', out['cached_margin'], 'lens', out['cached_lens'], 'kv', out['tc_kv'].shape)
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

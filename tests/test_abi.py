@@ -63,7 +63,7 @@ def test_engine_create_and_workspace_size(lib):
 
 
 @pytest.mark.parametrize('over,frag', [
-    (dict(attn_dim_head=32), 'attn_dim_head'),
+    (dict(attn_dim_head=48), 'attn_dim_head'),
     (dict(num_spatial_tokens=65), 'at most 64'),
     (dict(max_steps=48), 'power of two'),
     (dict(dim=66), 'multiples of 4'),

@@ -85,6 +85,19 @@ def test_one_spatial_token_per_latent_token_vs_reference_fixture():
         assert np.array_equal(act.numpy(), g[f'env{i}_actions'])
 
 
+def test_head_dim_16_vs_reference_fixture():
+    """attn_dim_head = 16 (the reference tests' own setting), 3 heads: head rows occupy 16 of the 64 lanes; the exported time
+    KV cache has the reference layout (time layers, 2, B*S, heads, frames, 16)."""
+    g = load_golden('headdim16.npz')
+    m = golden_model('weights_headdim16.npz').cuda()
+    e = m.generate(5, batch_size=3, return_for_policy_optimization=True, noise=golden_noise(g, 'cached_'))
+    check_exp(e, g, 'cached_')
+    e, tc = m.generate(4, batch_size=3, return_for_policy_optimization=True, return_time_cache=True, noise=golden_noise(g, 'tc_'))
+    close(e.latents, g['tc_latents']); close(e.values, g['tc_values'])
+    assert tc.kv().shape == g['tc_kv'].shape
+    close(tc.kv(), g['tc_kv'], atol=1e-5)
+
+
 def test_generate_without_time_cache_vs_reference_fixture(GM):
     m, G = GM
     e = m.generate(5, batch_size=3, num_steps=2, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(G, 'nocache_'))
@@ -174,7 +187,7 @@ def _sweep_configs():
     for i in range(20):
         depth = rng.choice([1, 2, 3, 5])
         out.append(dict(
-            dim=rng.choice([32, 64, 96, 160]), attn_heads=rng.choice([1, 2, 3]), depth=depth,
+            dim=rng.choice([32, 64, 96, 160]), attn_heads=rng.choice([1, 2, 3]), attn_dim_head=rng.choice([64, 64, 32, 16]), depth=depth,
             time_block_every=rng.choice([1, 2, 4]), num_latent_tokens=rng.choice([3, 5, 9, 16]), dim_latent=rng.choice([4, 8, 12]),
             num_spatial_tokens=rng.choice([1, 2, 3, 4, 5, 6]), num_register_tokens=rng.choice([0, 1, 3, 8]),
             num_discrete_actions=rng.choice([2, 5, (2, 3), (4, 2, 3)]), num_tasks=rng.choice([0, 2]),
