@@ -142,7 +142,7 @@ int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy,
 }
 
 // ---------------------------------------------------------------------------------- token assembly
-// tokens[(b,t)][s] = [flow | space x ns | registers x nr | action | agent]          D4:7182-7222
+// tokens[(b,t)][s] = [flow | space x ns | registers x nr | action (if the model has actions) | agent]          D4:7182-7222
 __global__ void assemble_kernel(AssembleArgs p) {
     const int D = p.D;
     const int64_t n = (int64_t)p.B * p.Tq * p.S * D;
@@ -160,7 +160,7 @@ __global__ void assemble_kernel(AssembleArgs p) {
             v = p.space[(f * p.ns + (s - 1)) * D + d];
         } else if (s <= p.ns + p.nr) {
             v = p.registers[(int64_t)(s - 1 - p.ns) * D + d];
-        } else if (s == p.ns + p.nr + 1) {
+        } else if (p.na > 0 && s == p.ns + p.nr + 1) {        // (a model without an action space has no action token, D4:7124-7130)
             v = 0.f;
             if (p.prev_actions && p.prev_actions[f * p.na] >= 0) {
                 for (int a = 0; a < p.na; ++a)

@@ -636,7 +636,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     d4_engine* e = new d4_engine();
     e->c = c;
     e->D = c.dim;
-    e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + 1 + 1;
+    e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + (c.num_discrete_action_types > 0 ? 1 : 0) + 1;   // no action token without an action space
     D4_REQUIRE(e->S <= 64 && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
     e->hd = c.attn_heads * c.attn_dim_head;
     e->php = c.pool_heads;

@@ -178,7 +178,8 @@ class DynamicsWorldModel(nn.Module):
         self.use_delight_gating, self.delight_temperature = use_delight_gating, delight_temperature
         self.normalize_advantages, self.policy_entropy_weight = normalize_advantages, policy_entropy_weight
         self.pool_heads, self.pool_dim_head = 4, 64              # AttentionPool defaults, dreamer4.py:2147-2148
-        self.tokens_per_frame = 1 + num_spatial_tokens + num_register_tokens + 1 + 1
+        # [flow | spatial | registers | action (only with an action space, dreamer4.py:7124-7130) | agent]
+        self.tokens_per_frame = 1 + num_spatial_tokens + num_register_tokens + (1 if len(nda) > 0 else 0) + 1
         self.ff_inner = int(dim * 4 * 2 / 3)
 
         self._build_parameters()
@@ -545,8 +546,6 @@ class DynamicsWorldModel(nn.Module):
         assert 0 < num_steps <= self.max_steps, f'number of steps {num_steps} must be between 0 and {self.max_steps}'
         if return_agent_actions and not self.num_discrete_actions:
             raise AssertionError('the model has no actions (dreamer4.py:6626)')
-        if not self.num_discrete_actions:
-            raise NotImplementedError('action-free world models are not implemented on the engine yet')
 
         dev, B, T = self.device, batch_size, time_steps
         n, dl = self.latent_shape

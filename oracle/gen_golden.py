@@ -15,6 +15,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   variant.npz      a second architecture (weights_variant.npz): generate cached / uncached, ppo + pmpo losses and gradients
   samelen.npz      num_spatial_tokens == num_latent_tokens (weights_samelen.npz): rollout + env-wrapper style chained calls
   headdim16.npz    attn_dim_head = 16 (weights_headdim16.npz): rollout, and a rollout returning the time KV cache
+  actionfree.npz   a world model without an action space (weights_actionfree.npz): plain and rewards-only rollouts
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -57,6 +58,10 @@ CFG_SAMELEN = dict(dim=32, dim_latent=16, num_latent_tokens=4, num_spatial_token
 
 CFG_HEADDIM16 = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=3, time_block_every=2, attn_heads=3, attn_dim_head=16,
                      num_discrete_actions=(4,), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=2)
+
+
+CFG_ACTIONFREE = dict(dim=16, dim_latent=8, num_latent_tokens=6, depth=2, time_block_every=2, attn_heads=1, attn_dim_head=32,
+                      num_discrete_actions=(), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=1)
 
 
 def fixture_config():
@@ -367,6 +372,26 @@ def main():
     out['tc_kv'] = npy(tc.main.next_kv_cache)
     np.savez(os.path.join(OUT, 'headdim16.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('headdim16 margin', out['cached_margin'], 'lens', out['cached_lens'], 'kv', out['tc_kv'].shape)
+
+    # ------------------------------------------------------------------ action-free world model (actionfree.npz)
+    cfg5 = Config(**CFG_ACTIONFREE)
+    ma = build_reference_model(cfg5, seed=9)
+    Wa = weights_of(ma)
+    np.savez(os.path.join(OUT, 'weights_actionfree.npz'), **{k: npy(v) for k, v in Wa.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in CFG_ACTIONFREE.items()})
+    out = {}
+    nz = make_noise(cfg5, 4, 3, 601)
+    with injected(nz):
+        lat = ma.generate(4, batch_size=3)
+    out['plain_latents'] = npy(lat); noise_dict('plain_', nz, out)
+    nz = make_noise(cfg5, 4, 3, 602)
+    with injected(nz):
+        e = ma.generate(4, batch_size=3, return_rewards_per_frame=True, return_terminals=True)
+    out['rew_latents'], out['rew_rewards'], out['rew_agent_embed'] = npy(e.latents), npy(e.rewards), npy(e.agent_embed)
+    out['rew_lens'], out['rew_terminals'] = npy(e.lens), npy(e.terminals)
+    noise_dict('rew_', nz, out)
+    np.savez(os.path.join(OUT, 'actionfree.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('actionfree lens', out['rew_lens'])
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

@@ -75,7 +75,7 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
         depth=cfg.depth, time_block_every=cfg.time_block_every, attn_heads=cfg.attn_heads,
         attn_dim_head=cfg.attn_dim_head, num_spatial_tokens=cfg.num_spatial_tokens,
         num_register_tokens=cfg.num_register_tokens, max_steps=cfg.max_steps, num_tasks=cfg.num_tasks,
-        num_discrete_actions=cfg.num_discrete_actions if len(cfg.num_discrete_actions) > 1 else cfg.num_discrete_actions[0],
+        num_discrete_actions=cfg.num_discrete_actions if len(cfg.num_discrete_actions) > 1 else (cfg.num_discrete_actions[0] if cfg.num_discrete_actions else 0),
         multi_token_pred_len=cfg.multi_token_pred_len,
         policy_head_mlp_depth=cfg.policy_head_mlp_depth, value_head_mlp_depth=cfg.value_head_mlp_depth,
         reward_encoder_kwargs=dict(num_bins=cfg.reward_num_bins, reward_range=cfg.reward_range),

@@ -376,7 +376,10 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
         agent = agent + W['task_embed.weight'][tasks][:, None]
     agent = agent[:, None].expand(b, t, -1, -1)
 
-    tokens = torch.cat((flow_tok, space, regs, act_tok[:, :, None], agent), dim=2)
+    if len(cfg.num_discrete_actions) == 0:                                          # no action space: no action token  D4:7128-7130
+        tokens = torch.cat((flow_tok, space, regs, agent), dim=2)
+    else:
+        tokens = torch.cat((flow_tok, space, regs, act_tok[:, :, None], agent), dim=2)
     if trace is not None:
         trace['spatial_tokens'] = space
     tokens, new_cache = transformer(cfg, W, tokens, cache, trace=trace)

@@ -98,6 +98,19 @@ def test_head_dim_16_vs_reference_fixture():
     close(tc.kv(), g['tc_kv'], atol=1e-5)
 
 
+def test_action_free_world_model_vs_reference_fixture():
+    """No action space at all: plain and rewards-only rollouts; asking for actions raises as the reference does (D4:6626)."""
+    g = load_golden('actionfree.npz')
+    m = golden_model('weights_actionfree.npz').cuda()
+    lat = m.generate(4, batch_size=3, noise=golden_noise(g, 'plain_'))
+    close(lat, g['plain_latents'])
+    e = m.generate(4, batch_size=3, return_rewards_per_frame=True, return_terminals=True, noise=golden_noise(g, 'rew_'))
+    close(e.latents, g['rew_latents']); close(e.rewards, g['rew_rewards']); close(e.agent_embed, g['rew_agent_embed'])
+    assert np.array_equal(e.lens.cpu().numpy(), g['rew_lens']) and np.array_equal(e.terminals.cpu().numpy(), g['rew_terminals'])
+    with pytest.raises(AssertionError):
+        m.generate(2, batch_size=1, return_agent_actions=True)
+
+
 def test_generate_without_time_cache_vs_reference_fixture(GM):
     m, G = GM
     e = m.generate(5, batch_size=3, num_steps=2, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(G, 'nocache_'))
