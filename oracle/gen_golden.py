@@ -16,6 +16,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   samelen.npz      num_spatial_tokens == num_latent_tokens (weights_samelen.npz): rollout + env-wrapper style chained calls
   headdim16.npz    attn_dim_head = 16 (weights_headdim16.npz): rollout, and a rollout returning the time KV cache
   actionfree.npz   a world model without an action space (weights_actionfree.npz): plain and rewards-only rollouts
+  options.npz      non-default call options on the main model (context noise, temperatures, 64 denoising steps, store_* = False)
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -178,6 +179,25 @@ def main():
     out['rewonly_lens'], out['rewonly_terminals'] = npy(e.lens), npy(e.terminals)
     assert e.actions is None and e.values is None
     noise_dict('rewonly_', nz, out)
+
+    # non-default call options on the same model -> options.npz
+    opt = {}
+    nz = make_noise(cfg, 4, B, 107)
+    with injected(nz):
+        e = m.generate(4, batch_size=B, return_for_policy_optimization=True, use_time_cache=False, context_signal_noise=0.35,
+                       discrete_temperature=0.6, num_steps=8)
+    exp_dict('ctxnoise_', e, opt); noise_dict('ctxnoise_', nz, opt)
+    nz = make_noise(cfg, 3, B, 108)
+    with injected(nz):
+        e = m.generate(3, batch_size=B, return_for_policy_optimization=True, discrete_temperature=1.7, num_steps=64,
+                       store_agent_embed=False, store_old_action_unembeds=False)
+    assert e.agent_embed is None and e.old_action_unembeds is None
+    for k in ('latents', 'rewards', 'values', 'lens', 'terminals'):
+        opt['fine_' + k] = npy(getattr(e, k))
+    opt['fine_log_probs'], opt['fine_actions'] = npy(e.log_probs.discrete), npy(e.actions.discrete)
+    opt['fine_step_size'] = np.array(e.step_size)
+    noise_dict('fine_', nz, opt)
+    np.savez(os.path.join(OUT, 'options.npz'), **opt, **{'meta_' + k: np.array(v) for k, v in META.items()})
 
     np.savez(os.path.join(OUT, 'generate.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('generate margins', out['cached_margin'], out['nocache_margin'], out['prompt_margin'],

@@ -111,6 +111,21 @@ def test_action_free_world_model_vs_reference_fixture():
         m.generate(2, batch_size=1, return_agent_actions=True)
 
 
+def test_non_default_call_options_vs_reference_fixture(GM):
+    """context_signal_noise / discrete_temperature / num_steps = max_steps (step size 1) / store_* = False."""
+    m, _ = GM
+    g = load_golden('options.npz')
+    e = m.generate(4, batch_size=3, return_for_policy_optimization=True, use_time_cache=False, context_signal_noise=0.35,
+                   discrete_temperature=0.6, num_steps=8, noise=golden_noise(g, 'ctxnoise_'))
+    check_exp(e, g, 'ctxnoise_')
+    e = m.generate(3, batch_size=3, return_for_policy_optimization=True, discrete_temperature=1.7, num_steps=64,
+                   store_agent_embed=False, store_old_action_unembeds=False, noise=golden_noise(g, 'fine_'))
+    assert e.agent_embed is None and e.old_action_unembeds is None and e.step_size == 1
+    close(e.latents, g['fine_latents']); close(e.rewards, g['fine_rewards']); close(e.values, g['fine_values'])
+    close(e.log_probs.discrete, g['fine_log_probs'])
+    assert np.array_equal(e.actions.discrete.cpu().numpy(), g['fine_actions']) and np.array_equal(e.lens.cpu().numpy(), g['fine_lens'])
+
+
 def test_generate_without_time_cache_vs_reference_fixture(GM):
     m, G = GM
     e = m.generate(5, batch_size=3, num_steps=2, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(G, 'nocache_'))
