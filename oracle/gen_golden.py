@@ -260,6 +260,22 @@ def main():
                 else:       # large matrices of the other objectives: Frobenius norm + a strided sample
                     out[f'{obj}_gnorm/{k}'] = npy(p.grad.norm())
                     out[f'{obj}_gsample/{k}'] = npy(p.grad.flatten()[::97])
+    # non-default learner options (kept in options.npz next to the non-default generate options)
+    lopt = {}
+    for tag, kw in (('nogate', dict(objective='ppo', use_delight_gating=False)),
+                    ('temp', dict(objective='spo', delight_temperature=2.5)),
+                    ('rawadv', dict(objective='ppo', normalize_advantages=False)),
+                    ('pmpo_norm', dict(objective='pmpo', normalize_advantages=True, eps=1e-3))):
+        m.zero_grad()
+        pl_, vl_ = m.learn_from_experience(e, **kw)
+        pl_.backward(); vl_.backward()
+        lopt[f'learn_{tag}_policy_loss'], lopt[f'learn_{tag}_value_loss'] = npy(pl_), npy(vl_)
+        for k, p in m.named_parameters():
+            if k.startswith(heads) and p.numel() > 0 and p.grad is not None and (p.ndim == 1 or 'unembed' in k):
+                lopt[f'learn_{tag}_grad/{k}'] = npy(p.grad)
+    o_ = dict(np.load(os.path.join(OUT, 'options.npz')))
+    o_.update(lopt)
+    np.savez(os.path.join(OUT, 'options.npz'), **o_)
     # GAE with terminations / truncations
     g = torch.Generator().manual_seed(9)
     r = torch.randn(4, 7, generator=g); v = torch.randn(4, 7, generator=g)

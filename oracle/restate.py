@@ -639,10 +639,15 @@ def returns_and_advantage(cfg: Config, exp, normalize=True, eps=1e-6):
     return returns, old_values, adv, mask
 
 
-def learn_losses(cfg: Config, W, exp, objective='ppo'):
+def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, delight_temperature=None,
+                 normalize_advantages=None, eps=1e-6):
     """learn_from_experience(only_learn_policy_value_heads=True) with stored agent embeds  D4:5893-6305.
-    Returns (total_policy_loss, value_loss); differentiable w.r.t. the head tensors in W."""
-    returns, old_values, adv, mask = returns_and_advantage(cfg, exp, normalize=(objective != 'pmpo'))
+    Returns (total_policy_loss, value_loss); differentiable w.r.t. the head tensors in W.
+    The three optional arguments default as the reference's do (D4:5905-5906, 6021)."""
+    use_gate = cfg.use_delight_gating if use_delight_gating is None else use_delight_gating
+    gate_temp = cfg.delight_temperature if delight_temperature is None else delight_temperature
+    normalize = (objective != 'pmpo') if normalize_advantages is None else normalize_advantages
+    returns, old_values, adv, mask = returns_and_advantage(cfg, exp, normalize=normalize, eps=eps)
     agent_embeds = exp['agent_embed'].detach()
     actions = exp['actions']
     old_lp = exp['log_probs'].sum(dim=-1)
@@ -654,8 +659,8 @@ def learn_losses(cfg: Config, W, exp, objective='ppo'):
     fmask = mask.float()
 
     gate = 1.
-    if cfg.use_delight_gating:
-        gate = ((-lp * adv) / cfg.delight_temperature).sigmoid().detach()
+    if use_gate:
+        gate = ((-lp * adv) / gate_temp).sigmoid().detach()
 
     if objective == 'ppo':
         ratio = (lp - old_lp).exp()

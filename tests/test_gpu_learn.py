@@ -46,6 +46,25 @@ def test_learn_vs_reference_fixture(objective):
     assert all(p.grad is None for k, p in P.items() if not k.startswith(HEADS)), 'only the two heads learn (D4:5898)'
 
 
+@pytest.mark.parametrize('tag,kw', (('nogate', dict(objective='ppo', use_delight_gating=False)), ('temp', dict(objective='spo', delight_temperature=2.5)),
+                                    ('rawadv', dict(objective='ppo', normalize_advantages=False)),
+                                    ('pmpo_norm', dict(objective='pmpo', normalize_advantages=True, eps=1e-3))))
+def test_non_default_learner_options_vs_reference_fixture(tag, kw):
+    """use_delight_gating / delight_temperature / normalize_advantages / eps overrides of learn_from_experience."""
+    m = golden_model().cuda()
+    G, g = load_golden('generate.npz'), load_golden('options.npz')
+    pl, vl = m.learn_from_experience(fixture_experience(G), **kw)
+    close(pl, g[f'learn_{tag}_policy_loss'], atol=1e-5, rtol=1e-4); close(vl, g[f'learn_{tag}_value_loss'], atol=1e-5)
+    pl.backward(retain_graph=True); vl.backward()
+    P = dict(m.named_parameters())
+    n = 0
+    for k, v in g.items():
+        if k.startswith(f'learn_{tag}_grad/'):
+            ref = t(v)
+            close(P[k.split('/', 1)[1]].grad, ref, atol=2e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-3); n += 1
+    assert n >= 10
+
+
 def test_learn_vs_oracle_with_terminations_and_two_action_types():
     m = small_model(num_discrete_actions=(3, 2))
     from util import randomize_weights
