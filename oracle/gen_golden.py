@@ -17,6 +17,8 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   headdim16.npz    attn_dim_head = 16 (weights_headdim16.npz): rollout, and a rollout returning the time KV cache
   actionfree.npz   a world model without an action space (weights_actionfree.npz): plain and rewards-only rollouts
   options.npz      non-default call options on the main model (context noise, temperatures, 64 denoising steps, store_* = False)
+  hyper.npz        non-default hyper-parameters (weights_hyper.npz): head depths, value / reward ranges and bins, max_steps, softclamp,
+                   GAE / PPO / PMPO / entropy constants: rollout + ppo / spo / pmpo losses and gradients
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -63,6 +65,13 @@ CFG_HEADDIM16 = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=3, time_bl
 
 CFG_ACTIONFREE = dict(dim=16, dim_latent=8, num_latent_tokens=6, depth=2, time_block_every=2, attn_heads=1, attn_dim_head=32,
                       num_discrete_actions=(), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=1)
+
+
+CFG_HYPER = dict(dim=16, dim_latent=8, num_latent_tokens=6, depth=2, time_block_every=2, attn_heads=1, attn_dim_head=32,
+                 num_discrete_actions=(3,), num_tasks=0, max_steps=16, attn_softclamp_value=30., reward_num_bins=15, reward_range=(-5., 5.),
+                 value_num_bins=21, value_range=(-10., 10.), multi_token_pred_len=2, policy_head_mlp_depth=2, value_head_mlp_depth=1,
+                 gae_discount_factor=0.9, gae_lambda=0.8, ppo_eps_clip=0.1, policy_entropy_weight=0.05, use_delight_gating=False,
+                 pmpo_pos_to_neg_weight=0.3, pmpo_reverse_kl=False, pmpo_kl_div_loss_weight=0.5)
 
 
 def fixture_config():
@@ -428,6 +437,31 @@ def main():
     noise_dict('rew_', nz, out)
     np.savez(os.path.join(OUT, 'actionfree.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('actionfree lens', out['rew_lens'])
+
+    # ------------------------------------------------------------------ non-default hyper-parameters (hyper.npz)
+    cfg6 = Config(**CFG_HYPER)
+    mp = build_reference_model(cfg6, seed=11)
+    with torch.no_grad():
+        mp.action_embedder.discrete_action_unembed.mul_(0.3)
+    Wp = weights_of(mp)
+    np.savez(os.path.join(OUT, 'weights_hyper.npz'), **{k: npy(v) for k, v in Wp.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in CFG_HYPER.items()})
+    out = {}
+    nz = make_noise(cfg6, 6, 4, 701)
+    with injected(nz):
+        e = mp.generate(6, batch_size=4, return_for_policy_optimization=True, num_steps=2)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg6))
+    for obj in ('ppo', 'spo', 'pmpo'):
+        mp.zero_grad()
+        pl_, vl_ = mp.learn_from_experience(e, objective=obj)
+        pl_.backward(); vl_.backward()
+        out[f'{obj}_policy_loss'], out[f'{obj}_value_loss'] = npy(pl_), npy(vl_)
+        for k, p in mp.named_parameters():
+            if k.startswith(heads) and p.numel() > 0 and p.grad is not None and (p.ndim == 1 or 'unembed' in k):
+                out[f'{obj}_grad/{k}'] = npy(p.grad)
+    np.savez(os.path.join(OUT, 'hyper.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('hyper margin', out['cached_margin'], 'lens', out['cached_lens'])
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

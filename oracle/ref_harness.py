@@ -80,6 +80,10 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
         policy_head_mlp_depth=cfg.policy_head_mlp_depth, value_head_mlp_depth=cfg.value_head_mlp_depth,
         reward_encoder_kwargs=dict(num_bins=cfg.reward_num_bins, reward_range=cfg.reward_range),
         value_encoder_kwargs=dict(num_bins=cfg.value_num_bins, reward_range=cfg.value_range),
+        attn_softclamp_value=cfg.attn_softclamp_value, gae_discount_factor=cfg.gae_discount_factor, gae_lambda=cfg.gae_lambda,
+        ppo_eps_clip=cfg.ppo_eps_clip, policy_entropy_weight=cfg.policy_entropy_weight, use_delight_gating=cfg.use_delight_gating,
+        delight_temperature=cfg.delight_temperature, pmpo_pos_to_neg_weight=cfg.pmpo_pos_to_neg_weight,
+        pmpo_reverse_kl=cfg.pmpo_reverse_kl, pmpo_kl_div_loss_weight=cfg.pmpo_kl_div_loss_weight,
     ).eval()
     if head_scale:
         with torch.no_grad():

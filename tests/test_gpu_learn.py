@@ -65,6 +65,31 @@ def test_non_default_learner_options_vs_reference_fixture(tag, kw):
     assert n >= 10
 
 
+def test_non_default_hyper_parameters_vs_reference_fixture():
+    """Head MLP depths, reward / value ranges and bin counts, max_steps, softclamp value, GAE / PPO / PMPO / entropy constants,
+    delight gating off, forward KL — through the engine: rollout with early termination, then all three objectives."""
+    g = load_golden('hyper.npz')
+    m = golden_model('weights_hyper.npz').cuda()
+    nz = golden_noise(g, 'cached_')
+    e = m.generate(6, batch_size=4, return_for_policy_optimization=True, num_steps=2, noise=nz)
+    close(e.latents, g['cached_latents'], atol=1e-4); close(e.values, g['cached_values'], atol=1e-4); close(e.rewards, g['cached_rewards'], atol=1e-4)
+    assert np.array_equal(e.actions.discrete.cpu().numpy(), g['cached_actions']) and np.array_equal(e.lens.cpu().numpy(), g['cached_lens'])
+    exp = Experience(latents=t(g['cached_latents']), agent_embed=t(g['cached_agent_embed']), rewards=t(g['cached_rewards']),
+                     values=t(g['cached_values']), log_probs=Actions(t(g['cached_log_probs']), None), actions=Actions(t(g['cached_actions']), None),
+                     lens=t(g['cached_lens']), terminals=t(g['cached_terminals']), is_truncated=~t(g['cached_terminals']),
+                     old_action_unembeds=Actions(t(g['cached_unembeds']), None), step_size=8)
+    P = dict(m.named_parameters())
+    for obj in ('ppo', 'spo', 'pmpo'):
+        m.zero_grad()
+        pl, vl = m.learn_from_experience(exp, objective=obj)
+        close(pl, g[f'{obj}_policy_loss'], atol=1e-5, rtol=1e-4); close(vl, g[f'{obj}_value_loss'], atol=1e-5)
+        pl.backward(retain_graph=True); vl.backward()
+        for k, v in g.items():
+            if k.startswith(f'{obj}_grad/'):
+                ref = t(v)
+                close(P[k.split('/', 1)[1]].grad, ref, atol=2e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-3)
+
+
 def test_learn_vs_oracle_with_terminations_and_two_action_types():
     m = small_model(num_discrete_actions=(3, 2))
     from util import randomize_weights

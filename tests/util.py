@@ -84,9 +84,14 @@ def golden_model(weights='weights.npz'):
     """Product model carrying the fixture weights (loaded by reference state_dict key)."""
     from dreamer4_amd import DynamicsWorldModel
     kw = golden_config_kwargs(weights)
-    rb, vb = kw.pop('reward_num_bins'), kw.pop('value_num_bins')
+    renc, venc = dict(num_bins=kw.pop('reward_num_bins')), dict(num_bins=kw.pop('value_num_bins'))
+    if 'reward_range' in kw:
+        renc['reward_range'] = tuple(kw.pop('reward_range'))
+    if 'value_range' in kw:
+        venc['reward_range'] = tuple(kw.pop('value_range'))
     kw['num_discrete_actions'] = tuple(kw['num_discrete_actions']) if isinstance(kw['num_discrete_actions'], (tuple, list)) else kw['num_discrete_actions']
-    m = DynamicsWorldModel(**kw, reward_encoder_kwargs=dict(num_bins=rb), value_encoder_kwargs=dict(num_bins=vb))
+    kw = {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in kw.items()}
+    m = DynamicsWorldModel(**kw, reward_encoder_kwargs=renc, value_encoder_kwargs=venc)
     _, W = golden_oracle(weights)
     own = dict(m.named_parameters())
     missing = [k for k, p in own.items() if p.numel() > 0 and k not in W and k != 'reward_learned_embed']
