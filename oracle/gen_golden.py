@@ -19,6 +19,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   options.npz      non-default call options on the main model (context noise, temperatures, 64 denoising steps, store_* = False)
   hyper.npz        non-default hyper-parameters (weights_hyper.npz): head depths, value / reward ranges and bins, max_steps, softclamp,
                    GAE / PPO / PMPO / entropy constants: rollout + ppo / spo / pmpo losses and gradients
+  noterm.npz       predict_terminals = False (weights_noterm.npz): policy-optimisation rollout with tasks, ppo losses
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
@@ -72,6 +73,10 @@ CFG_HYPER = dict(dim=16, dim_latent=8, num_latent_tokens=6, depth=2, time_block_
                  value_num_bins=21, value_range=(-10., 10.), multi_token_pred_len=2, policy_head_mlp_depth=2, value_head_mlp_depth=1,
                  gae_discount_factor=0.9, gae_lambda=0.8, ppo_eps_clip=0.1, policy_entropy_weight=0.05, use_delight_gating=False,
                  pmpo_pos_to_neg_weight=0.3, pmpo_reverse_kl=False, pmpo_kl_div_loss_weight=0.5)
+
+
+CFG_NOTERM = dict(dim=16, dim_latent=4, num_latent_tokens=3, depth=1, time_block_every=1, attn_heads=2, attn_dim_head=16,
+                  num_discrete_actions=(5,), num_tasks=2, predict_terminals=False, reward_num_bins=15, value_num_bins=15, multi_token_pred_len=1)
 
 
 def fixture_config():
@@ -462,6 +467,27 @@ def main():
                 out[f'{obj}_grad/{k}'] = npy(p.grad)
     np.savez(os.path.join(OUT, 'hyper.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('hyper margin', out['cached_margin'], 'lens', out['cached_lens'])
+
+    # ------------------------------------------------------------------ a model without the terminal head (noterm.npz)
+    cfg7 = Config(**CFG_NOTERM)
+    mt = build_reference_model(cfg7, seed=13)
+    with torch.no_grad():
+        mt.action_embedder.discrete_action_unembed.mul_(0.3)
+    Wt = weights_of(mt)
+    assert not any(k.startswith('to_state_terminal_pred') for k in Wt)
+    np.savez(os.path.join(OUT, 'weights_noterm.npz'), **{k: npy(v) for k, v in Wt.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in CFG_NOTERM.items()})
+    out = {}
+    nz = make_noise(cfg7, 4, 3, 801)
+    with injected(nz):
+        e = mt.generate(4, batch_size=3, return_for_policy_optimization=True, tasks=torch.tensor([1, 0, 1]))
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg7))
+    mt.zero_grad()
+    pl_, vl_ = mt.learn_from_experience(e, objective='ppo')
+    out['ppo_policy_loss'], out['ppo_value_loss'] = npy(pl_), npy(vl_)
+    np.savez(os.path.join(OUT, 'noterm.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('noterm margin', out['cached_margin'], 'lens', out['cached_lens'], 'terminals', out['cached_terminals'])
 
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')

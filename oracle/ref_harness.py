@@ -80,7 +80,7 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
         policy_head_mlp_depth=cfg.policy_head_mlp_depth, value_head_mlp_depth=cfg.value_head_mlp_depth,
         reward_encoder_kwargs=dict(num_bins=cfg.reward_num_bins, reward_range=cfg.reward_range),
         value_encoder_kwargs=dict(num_bins=cfg.value_num_bins, reward_range=cfg.value_range),
-        attn_softclamp_value=cfg.attn_softclamp_value, gae_discount_factor=cfg.gae_discount_factor, gae_lambda=cfg.gae_lambda,
+        predict_terminals=cfg.predict_terminals, attn_softclamp_value=cfg.attn_softclamp_value, gae_discount_factor=cfg.gae_discount_factor, gae_lambda=cfg.gae_lambda,
         ppo_eps_clip=cfg.ppo_eps_clip, policy_entropy_weight=cfg.policy_entropy_weight, use_delight_gating=cfg.use_delight_gating,
         delight_temperature=cfg.delight_temperature, pmpo_pos_to_neg_weight=cfg.pmpo_pos_to_neg_weight,
         pmpo_reverse_kl=cfg.pmpo_reverse_kl, pmpo_kl_div_loss_weight=cfg.pmpo_kl_div_loss_weight,
@@ -99,8 +99,9 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
                     p.copy_(torch.randn(p.shape, generator=g) * 0.2)
                 if name.endswith('norm.weight') or name.endswith('norm_context.weight') or (name.endswith('.0.weight') and p.ndim == 1):
                     p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
-            last = m.to_state_terminal_pred[0].layers[-1][1]
-            last.bias.fill_(-2.5)
+            if cfg.predict_terminals:
+                last = m.to_state_terminal_pred[0].layers[-1][1]
+                last.bias.fill_(-2.5)
     return m
 
 

@@ -126,6 +126,17 @@ def test_non_default_call_options_vs_reference_fixture(GM):
     assert np.array_equal(e.actions.discrete.cpu().numpy(), g['fine_actions']) and np.array_equal(e.lens.cpu().numpy(), g['fine_lens'])
 
 
+def test_model_without_terminal_head_vs_reference_fixture():
+    """predict_terminals = False: the engine runs without a terminal MLP; nothing terminates, every trajectory is truncated."""
+    g = load_golden('noterm.npz')
+    m = golden_model('weights_noterm.npz').cuda()
+    assert not any(k.startswith('to_state_terminal_pred') for k in m.state_dict())
+    e = m.generate(4, batch_size=3, return_for_policy_optimization=True, tasks=torch.tensor([1, 0, 1]), noise=golden_noise(g, 'cached_'))
+    check_exp(e, g, 'cached_')
+    pl, vl = m.learn_from_experience(e, objective='ppo')
+    close(pl, g['ppo_policy_loss'], atol=2e-5); close(vl, g['ppo_value_loss'], atol=2e-5)
+
+
 def test_generate_without_time_cache_vs_reference_fixture(GM):
     m, G = GM
     e = m.generate(5, batch_size=3, num_steps=2, return_for_policy_optimization=True, use_time_cache=False, noise=golden_noise(G, 'nocache_'))
