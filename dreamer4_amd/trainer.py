@@ -18,9 +18,24 @@ from dreamer4_amd.learner import run_learner
 
 
 class DreamTrainer:
-    def __init__(self, model, batch_size=16, generate_timesteps=16, learning_rate=3e-4, max_grad_norm=0.5,
-                 num_train_steps=10_000, weight_decay=0., objective='ppo', betas=(0.9, 0.999), adam_eps=1e-8,
-                 process_group=None, stats='global', seed=None, generate_kwargs: dict | None = None):
+    def __init__(self, model, optim_klass=None, batch_size=16, generate_timesteps=16, learning_rate=3e-4, max_grad_norm=0.5,
+                 num_train_steps=10_000, weight_decay=0., objective='ppo', accelerate_kwargs: dict | None = None,
+                 optim_kwargs: dict | None = None, cpu=False, use_tensorboard=False, use_wandb=False, log_dir=None,
+                 project_name='dreamer4', *, betas=(0.9, 0.999), adam_eps=1e-8, process_group=None, stats='global', seed=None,
+                 generate_kwargs: dict | None = None):
+        """Positional / keyword order of the reference's constructor (trainers.py:1331-1349).  `optim_klass` None or
+        torch.optim.AdamW: the fused native clip + AdamW step; any other optimiser class is instantiated on the two heads'
+        parameters and stepped by PyTorch (with `clip_grad_norm_`) on the gradients the engine computed.  As in the
+        reference the optimisers get `lr` / `weight_decay` only (its `optim_kwargs` argument is overwritten, trainers.py:1371).
+        There is no CPU path and no Accelerate / tracker integration: those arguments raise instead of being ignored."""
+        if cpu:
+            raise NotImplementedError('DreamTrainer(cpu=True): this implementation has no CPU path')
+        if use_tensorboard or use_wandb or accelerate_kwargs:
+            raise NotImplementedError('experiment trackers / Accelerate options are not part of the imagination path')
+        self.torch_optims = None
+        if optim_klass is not None and optim_klass is not torch.optim.AdamW:
+            kw = dict(lr=learning_rate, weight_decay=weight_decay)
+            self.torch_optims = (optim_klass(model.policy_head_parameters(), **kw), optim_klass(model.value_head_parameters(), **kw))
         self.model, self.objective = model, objective
         self.batch_size, self.generate_timesteps = batch_size, generate_timesteps
         self.lr, self.max_grad_norm, self.weight_decay = learning_rate, max_grad_norm, weight_decay
@@ -66,11 +81,33 @@ class DreamTrainer:
     def learn(self, dreams):
         """learn_from_experience + backward + clip + AdamW for the policy head, then the value head.
         Returns the device tensor [total_policy_loss, value_loss] (no host sync)."""
+        if self.torch_optims is not None:
+            return self._learn_with_torch_optims(dreams)
         losses, _ = run_learner(self.model, dreams, self.objective, process_group=self.process_group, stats=self.stats)
         self._optim_step('policy')
         self._optim_step('value')
         self.step += 1
         return losses
+
+    def _learn_with_torch_optims(self, dreams):
+        """trainers.py:1430-1452 with user-chosen optimiser classes: engine gradients, PyTorch clip + step."""
+        m = self.model
+        pl, vl = m.learn_from_experience(dreams, objective=self.objective, process_group=self.process_group, stats=self.stats)
+        for loss, params, optim in ((pl, m.policy_head_parameters(), self.torch_optims[0]),
+                                    (vl, m.value_head_parameters(), self.torch_optims[1])):
+            loss.backward()
+            if parallel.world_size(self.process_group) > 1:
+                for p in params:
+                    if p.grad is not None:
+                        parallel.all_reduce_sum_(p.grad, self.process_group)
+                        if self.stats != 'global':
+                            p.grad.div_(parallel.world_size(self.process_group))
+            if self.max_grad_norm is not None:
+                torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+            optim.step()
+            optim.zero_grad()
+        self.step += 1
+        return torch.stack((pl.detach(), vl.detach()))
 
     def train_step(self):
         return self.learn(self.generate())

@@ -190,6 +190,28 @@ def test_three_trainer_steps_vs_reference_fixture():
             close((P[k[17:]].detach().cpu() - W0[k[17:]]).norm(), v, atol=1e-5, rtol=1e-2)
 
 
+def test_dream_trainer_constructor_follows_the_reference():
+    """Positional / keyword order of trainers.py:1331-1349; a non-default optimiser class steps both heads through PyTorch
+    on the engine's gradients; CPU / tracker options raise instead of being ignored."""
+    m = small_model().cuda()
+    with pytest.raises(NotImplementedError):
+        DreamTrainer(m, batch_size=2, num_train_steps=1, cpu=True)              # the reference test's own call (tests/test_dreamer.py:755)
+    with pytest.raises(NotImplementedError):
+        DreamTrainer(m, use_wandb=True)
+    before = {k: p.detach().clone() for k, p in m.named_parameters() if k.startswith(HEADS)}
+    tr = DreamTrainer(m, torch.optim.SGD, 3, 4, 1e-2, objective='spo', num_train_steps=2)     # positional: optim_klass, batch_size, generate_timesteps, lr
+    assert tr.batch_size == 3 and tr.generate_timesteps == 4 and tr.lr == 1e-2
+    tr()
+    assert tr.step == 2
+    moved = [k for k, p in m.named_parameters() if k.startswith(HEADS) and p.numel() > 0 and not torch.equal(p, before[k])]
+    assert any(k.startswith('policy_head') for k in moved) and any(k.startswith('value_head') for k in moved)
+    frozen = [k for k, p in m.named_parameters() if not k.startswith(HEADS) and p.numel() > 0]
+    assert frozen                                                   # the trunk is not an optimiser target
+    tr2 = DreamTrainer(m, torch.optim.AdamW, batch_size=2, generate_timesteps=3, num_train_steps=1)   # AdamW -> the fused native step
+    assert tr2.torch_optims is None
+    tr2()
+
+
 def test_optimizer_arguments_step_the_heads_like_the_reference():
     m = small_model().cuda()
     cfg = oracle_config(m)
