@@ -23,15 +23,15 @@ __device__ __forceinline__ float lerp_torch(float a, float b, float w) {
 
 // Generic form: one block (4 waves) per (group, head).  Wave w prepares keys w, w+4, ... (value-residual mix, key l2-norm)
 // into LDS, then owns queries w, w+4, ...; scores are wave reductions, so they live in SGPRs.
-template <int NKM>
+template <int NKM, int DH>
 __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnArgs p) {
     __shared__ float Ks[NKM * 64], Vs[NKM * 64];
     const int w = threadIdx.x >> 6;
     const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int lane = threadIdx.x & 63;
     const int nk = p.nk, nq = p.nq;
-    const int dh = p.dh;
-    const bool act = lane < dh;                                     // head dims below 64: the upper lanes carry zeros
+    constexpr int dh = DH;                                          // compile-time: the 64-wide case keeps no lane predicate
+    const bool act = DH == 64 || lane < dh;                         // head dims below 64: the upper lanes carry zeros
     const int hl = h * dh + (act ? lane : 0);
     const float kscale = act ? (p.k_gamma[hl] + 1.f) * sqrtf((float)dh) : 0.f;   // (gamma + 1) * sqrt(dh)
     const float qscale = rsqrtf((float)dh);
@@ -124,6 +124,7 @@ constexpr int SA_LD = 68;
 // mix, key l2-norm, 1/|v| for the belief projection) into LDS, then owns query rows 4w..4w+3: scores for the four rows in one
 // pass (lane = (row, key) pair), softmax over 16-lane rows, P.V with lane = feature.  8192 short waves instead of 2048 long
 // ones: the kernel is a chain of dependent reductions, so the win is latency hiding, not bandwidth.
+template <int DH>
 __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
     __shared__ __attribute__((aligned(16))) float Qs[16 * SA_LD];
     __shared__ __attribute__((aligned(16))) float Ks[16 * SA_LD];
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
     const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int lane = threadIdx.x & 63;
     const int n = p.nk;                                   // == nq <= 16
-    const int dh = p.dh;
-    const bool act = lane < dh;                           // head dims below 64: the upper lanes carry zeros
+    constexpr int dh = DH;                                // compile-time: the 64-wide case keeps no lane predicate
+    const bool act = DH == 64 || lane < dh;               // head dims below 64: the upper lanes carry zeros
     const int hl = h * dh + (act ? lane : 0);
     const float kscale = act ? (p.k_gamma[hl] + 1.f) * sqrtf((float)dh) : 0.f;
     const float qscale = rsqrtf((float)dh);
@@ -237,13 +238,22 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
     if (waves == 0) return 0;
     dim3 block(256);
     if (p.nq == p.nk && p.nk <= 16 && p.nq >= 8 && p.q_group_stride != 0) {
-        hipLaunchKernelGGL(space_attn_kernel, dim3(waves), block, 0, stream, p);
+        if (p.dh == 64) hipLaunchKernelGGL(space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
+        else if (p.dh == 32) hipLaunchKernelGGL(space_attn_kernel<32>, dim3(waves), block, 0, stream, p);
+        else hipLaunchKernelGGL(space_attn_kernel<16>, dim3(waves), block, 0, stream, p);
         D4_LAUNCH_CHECK();
         return 0;
     }
-    if (p.nk <= 16) hipLaunchKernelGGL(small_attn_kernel<16>, dim3(waves), block, 0, stream, p);
-    else if (p.nk <= 32) hipLaunchKernelGGL(small_attn_kernel<32>, dim3(waves), block, 0, stream, p);
-    else hipLaunchKernelGGL(small_attn_kernel<64>, dim3(waves), block, 0, stream, p);
+#define D4_SMALL_ATTN(NK)                                                                                       \
+    do {                                                                                                          \
+        if (p.dh == 64) hipLaunchKernelGGL((small_attn_kernel<NK, 64>), dim3(waves), block, 0, stream, p);        \
+        else if (p.dh == 32) hipLaunchKernelGGL((small_attn_kernel<NK, 32>), dim3(waves), block, 0, stream, p);   \
+        else hipLaunchKernelGGL((small_attn_kernel<NK, 16>), dim3(waves), block, 0, stream, p);                   \
+    } while (0)
+    if (p.nk <= 16) D4_SMALL_ATTN(16);
+    else if (p.nk <= 32) D4_SMALL_ATTN(32);
+    else D4_SMALL_ATTN(64);
+#undef D4_SMALL_ATTN
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -406,6 +416,7 @@ __device__ __forceinline__ float rotate_half_lane(float x, int lane, float pos, 
     return x * cs + half * sn;
 }
 
+template <int DH>
 __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows = p.B * p.Tq * p.S;
@@ -413,8 +424,9 @@ __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     const int row = wid / p.H, h = wid % p.H;
     const int lane = threadIdx.x & 63;
     const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
-    const int dh = p.dh, hd = p.H * dh;
-    const bool act = lane < dh;
+    constexpr int dh = DH;
+    const int hd = p.H * dh;
+    const bool act = DH == 64 || lane < dh;
     const int hl = h * dh + (act ? lane : 0);
     const float* pr = p.proj + (int64_t)row * p.ldp;
     float k = act ? pr[hd + hl] : 0.f;
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     p.cache[cols * p.H * p.Tcap * dh + off] = v;
 }
 
+template <int DH>
 __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rows = p.B * p.Tq * p.S;
@@ -442,8 +455,9 @@ __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const int row = wid / p.H, h = wid % p.H;
     const int lane = threadIdx.x & 63;
     const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
-    const int dh = p.dh, hd = p.H * dh;
-    const bool act = lane < dh;
+    constexpr int dh = DH;
+    const int hd = p.H * dh;
+    const bool act = DH == 64 || lane < dh;
     const int hl = h * dh + (act ? lane : 0);
     const float* pr = p.proj + (int64_t)row * p.ldp;
     const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
@@ -479,7 +493,9 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.t0 + p.Tq <= p.Tcap, "time attention: cache capacity %d exceeded (t0=%d, Tq=%d)", p.Tcap, p.t0, p.Tq);
     const int waves = p.B * p.Tq * p.S * p.H;
     if (waves == 0) return 0;
-    hipLaunchKernelGGL(time_kv_append_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    if (p.dh == 64) hipLaunchKernelGGL(time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    else if (p.dh == 32) hipLaunchKernelGGL(time_kv_append_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(time_kv_append_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -487,7 +503,9 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
 int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
     const int waves = p.B * p.Tq * p.S * p.H;
     if (waves == 0) return 0;
-    hipLaunchKernelGGL(time_attn_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    if (p.dh == 64) hipLaunchKernelGGL(time_attn_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    else if (p.dh == 32) hipLaunchKernelGGL(time_attn_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(time_attn_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
 }
