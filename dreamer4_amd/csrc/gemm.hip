@@ -10,10 +10,13 @@
 //     1/rms is accumulated from the A tiles as they stream through LDS and applied in the epilogue,
 //   * bias, SiLU, SiLU-GLU pairing and the residual add run in the epilogue.
 //
-// Tiling: BM x BN block tile, BK = 32, 256 threads = 4 waves (WGM x WGN), each wave owns
+// Tiling: BM x BN block tile, BK = 32 or 16, WGM x WGN waves (4, 8 or 16), each wave owns
 // TM x TN MFMA 32x32 sub-tiles.  LDS tiles are row-major [rows][BK + 4] (the +4 keeps 16-byte
-// alignment and spreads ds_read_b128 over the 64 banks), double-buffered, one barrier per k-tile;
-// the next tile's global loads are issued before the current tile's MFMAs (register staging).
+// alignment and spreads ds_read_b128 over the 64 banks), double-buffered, one barrier per k-tile.
+// Staging is global -> registers -> LDS with a 2-deep register prefetch: k-tile j+2 is in flight
+// while k-tile j+1 (loaded an iteration earlier) is written to the other LDS buffer between the
+// MFMA groups of k-tile j.  Eight tile configurations exist (enum TileCfg); the first launch of a
+// shape times the valid ones and the choice is cached (all of them produce identical bits).
 // The MFMA consumes k in the order lanes<32: {8q+e}, lanes>=32: {8q+4+e} so that each lane's
 // operand for four consecutive k-steps is one ds_read_b128 (summation order inside a k-tile is a
 // fixed permutation; results are deterministic).
