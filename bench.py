@@ -117,7 +117,7 @@ def main():
 
     timing = not args.no_kernel_timing
     ncls = lib.d4_profile_classes()
-    names = [lib.d4_profile_class_name(i).decode() + ', false, false, *> fp32 MFMA' for i in range(ncls)]
+    names = [lib.d4_profile_class_name(i).decode() + ', *> fp32 MFMA' for i in range(ncls)]
     # warm-up: first-use tile autotuning of every GEMM shape happens here; the last warm-up step is also used to find the
     # dominant tile configuration (all configurations event-timed), so that the timed region only carries events for it
     dom, warm_classes = None, None

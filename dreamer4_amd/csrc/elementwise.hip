@@ -141,6 +141,51 @@ int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- LayerNorm (+ SiLU), head MLPs of the
+// Linear -> LayerNorm -> activation recipe.  One wave per row held in registers (D <= 4096); biased variance, two-pass.
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, int ldx, const float* g, const float* b, float* y, int ldy,
+                                                             int rows, int D, float eps, int silu) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)row * ldx;
+    float* yr = y + (int64_t)row * ldy;
+    constexpr int MAXI = 64;                    // 64 lanes x 64 = 4096 columns
+    float v[MAXI];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mean : 0.f;
+        ss += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            float o = (v[i] - mean) * rstd * g[c] + b[c];
+            if (silu) o = siluf(o);
+            yr[c] = o;
+        }
+    }
+}
+int layernorm_rows(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int D, float eps, int silu, hipStream_t s) {
+    if (rows == 0) return 0;
+    D4_REQUIRE(D <= 4096, "layernorm: row width %d > 4096", D);
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, g, b, y, ldy, rows, D, eps, silu);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------- token assembly
 // tokens[(b,t)][s] = [flow | space x ns | registers x nr | action (if the model has actions) | agent]          D4:7182-7222
 __global__ void assemble_kernel(AssembleArgs p) {

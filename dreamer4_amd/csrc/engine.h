@@ -18,11 +18,19 @@ struct FfW { const float *norm, *in_w, *in_b, *out_w, *out_b; };
 
 struct FfPrep { float *w1, *b1, *w2; };
 
-struct Mlp {              // normed MLP head: [RMSNorm -> Linear(+bias) -> SiLU]*, no activation on the last layer
+// Normed MLP head (x_mlps_pytorch.normed_mlp.create_mlp, D4:4950, 5083, 5095).  The package is absent from the image, so the layer
+// recipe is a descriptor honoured by every layer of the stack (oracle shim, restatement, host module tree, these kernels):
+//   D4_MLP_PRE_RMS      layer = RMSNorm(d_in) -> Linear(d_in, d_out, bias) -> SiLU ; no activation on the last layer
+//                       keys   layers.{i}.0.weight (norm)  layers.{i}.1.{weight,bias} (linear)
+//   D4_MLP_POST_LAYER   layer = Linear(d_in, d_out, bias) -> LayerNorm(d_out) -> SiLU ; the last layer is a bare Linear
+//                       keys   layers.{i}.0.{weight,bias} (linear)  layers.{i}.1.{weight,bias} (norm) ; last: layers.{i}.{weight,bias}
+struct Mlp {
     int nl = 0;
+    int recipe = 0;
     int dims[10];
-    const float *g[9], *w[9], *b[9];
-    float *dg[9], *dw[9], *db[9];       // gradient buffers (may be null)
+    const float *g[9], *nb[9], *w[9], *b[9];      // g / nb: norm weight / bias (bias: LayerNorm only)
+    float *dg[9], *dnb[9], *dw[9], *db[9];        // gradient buffers (may be null)
+    bool post_norm(int i) const { return recipe == 1 && i < nl - 1; }
     // learner save area, per layer: x [R][din] | xhat [R][din] | z [R][ldz]; every block 256-byte aligned
     static size_t al(size_t n) { return (n + 63) / 64 * 64; }
     int ldz(int i) const { return (dims[i + 1] + 3) / 4 * 4; }
@@ -97,7 +105,7 @@ struct d4_engine {
     // ---- learner (workspace; sized by max_learn_rows)
     int LR = 0;
     float *l_save;                         // per-layer saved activations for both MLP heads
-    float *l_tmp[3];
+    float *l_tmp[4];
     float *l_logits, *l_dlogits, *l_vbins, *l_dvbins, *l_returns, *l_adv, *l_scal, *l_mask, *l_rows, *l_dpe;
 };
 

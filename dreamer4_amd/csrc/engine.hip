@@ -116,7 +116,7 @@ int engine_layout(d4_engine* e, bool assign) {
         const size_t R = e->LR;
         // saved per layer: x (input), xhat (normalised * gamma input of the linear), z (pre-activation)
         e->l_save = fl(e->policy.save_floats(R) + e->value.save_floats(R));
-        for (int i = 0; i < 3; ++i) e->l_tmp[i] = fl(R * maxdim);
+        for (int i = 0; i < 4; ++i) e->l_tmp[i] = fl(R * maxdim);
         e->l_logits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
         e->l_dlogits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
         e->l_vbins = fl(R * (size_t)((c.value_num_bins + 3) / 4 * 4));
@@ -185,21 +185,33 @@ struct Resolver {
     }
     void mlp(Mlp& m, const std::string& pre) {
         for (int i = 0; i < m.nl; ++i) {
-            m.g[i] = get(keyf("%slayers.%d.0.weight", pre.c_str(), i), m.dims[i], &m.dg[i]);
-            m.w[i] = get(keyf("%slayers.%d.1.weight", pre.c_str(), i), (int64_t)m.dims[i + 1] * m.dims[i], &m.dw[i]);
-            m.b[i] = get(keyf("%slayers.%d.1.bias", pre.c_str(), i), m.dims[i + 1], &m.db[i]);
+            const int64_t nw = (int64_t)m.dims[i + 1] * m.dims[i];
+            if (m.recipe == D4_MLP_PRE_RMS) {
+                m.g[i] = get(keyf("%slayers.%d.0.weight", pre.c_str(), i), m.dims[i], &m.dg[i]);
+                m.w[i] = get(keyf("%slayers.%d.1.weight", pre.c_str(), i), nw, &m.dw[i]);
+                m.b[i] = get(keyf("%slayers.%d.1.bias", pre.c_str(), i), m.dims[i + 1], &m.db[i]);
+            } else if (i < m.nl - 1) {
+                m.w[i] = get(keyf("%slayers.%d.0.weight", pre.c_str(), i), nw, &m.dw[i]);
+                m.b[i] = get(keyf("%slayers.%d.0.bias", pre.c_str(), i), m.dims[i + 1], &m.db[i]);
+                m.g[i] = get(keyf("%slayers.%d.1.weight", pre.c_str(), i), m.dims[i + 1], &m.dg[i]);
+                m.nb[i] = get(keyf("%slayers.%d.1.bias", pre.c_str(), i), m.dims[i + 1], &m.dnb[i]);
+            } else {
+                m.w[i] = get(keyf("%slayers.%d.weight", pre.c_str(), i), nw, &m.dw[i]);
+                m.b[i] = get(keyf("%slayers.%d.bias", pre.c_str(), i), m.dims[i + 1], &m.db[i]);
+            }
         }
     }
 };
 
-static void mlp_dims(Mlp& m, int dim_in, int dim, int dim_out, int depth) {
+static void mlp_dims(Mlp& m, int dim_in, int dim, int dim_out, int depth, int recipe) {
     // create_mlp(dim, depth, dim_in, dim_out): widths (dim_in, dim x (depth + 1), dim_out)  [recipe: DESIGN.md]
     int k = 0;
+    m.recipe = recipe;
     m.dims[k++] = dim_in;
     for (int i = 0; i <= depth; ++i) m.dims[k++] = dim;
     m.dims[k++] = dim_out;
     m.nl = k - 1;
-    for (int i = 0; i < 9; ++i) { m.dg[i] = m.dw[i] = m.db[i] = nullptr; m.g[i] = m.w[i] = m.b[i] = nullptr; }
+    for (int i = 0; i < 9; ++i) { m.dg[i] = m.dnb[i] = m.dw[i] = m.db[i] = nullptr; m.g[i] = m.nb[i] = m.w[i] = m.b[i] = nullptr; }
 }
 
 int engine_resolve(d4_engine* e) {
@@ -564,48 +576,63 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
     return 0;
 }
 
-// normed MLP head.  `save` (optional): per layer [x | xhat | z | rstd] for the learner's backward.
+// normed MLP head (recipe: engine.h).  `save` (optional): per layer [x | xhat | z] for the learner's backward.
+static constexpr float LN_EPS = 1e-5f;      // nn.LayerNorm default
+
 int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, float* out, int ldo,
                 float* save, hipStream_t s) {
     int rc;
     const float* cur = x;
     int ld = ldx;
+    const bool pre = m.recipe == D4_MLP_PRE_RMS;
     for (int i = 0; i < m.nl; ++i) {
         const int din = m.dims[i], dout = m.dims[i + 1];
         const bool last = i == m.nl - 1;
-        float* xhat = e->hnorm;
-        float* y = last ? out : e->hbuf[i & 1];
-        int ldy = last ? ldo : dout;
+        const bool post = m.post_norm(i);
         if (save) {
             // learner path (rows may exceed max_batch: only the save area is used, never hbuf / hnorm):
-            // x_i -> sx[i], xhat_i -> sxh[i], pre-activation -> sz[i]; silu(z_i) is written straight into sx[i+1].
+            // x_i -> sx[i], (pre-norm: xhat_i -> sxh[i]), linear output -> sz[i]; the next layer's input is written straight
+            // into sx[i+1] (silu(z) or silu(LayerNorm(z))).
             float *sx, *sxh, *sz;
             m.save_ptrs(save, rows, i, &sx, &sxh, &sz);
             const int ldz = m.ldz(i);
             if (i == 0 && (rc = copy_rows(x, ldx, sx, din, rows, din, s))) return rc;
-            if ((rc = rmsnorm_rows(sx, din, m.g[i], sxh, din, rows, din, RMS_EPS, s))) return rc;
+            const float* lin_in = sx;
+            if (pre) {
+                if ((rc = rmsnorm_rows(sx, din, m.g[i], sxh, din, rows, din, RMS_EPS, s))) return rc;
+                lin_in = sxh;
+            }
             if (ldz != dout && (rc = fill_f32(sz, 0.f, (int64_t)rows * ldz, s))) return rc;
-            if ((rc = gemm_simple(sxh, din, m.w[i], din, sz, ldz, rows, dout, din, 0, m.b[i], nullptr, 0, s))) return rc;
+            if ((rc = gemm_simple(lin_in, din, m.w[i], din, sz, ldz, rows, dout, din, 0, m.b[i], nullptr, 0, s))) return rc;
             if (last) { if ((rc = copy_rows(sz, ldz, out, ldo, rows, dout, s))) return rc; }
             else {
                 float *nx, *nxh, *nz;
                 m.save_ptrs(save, rows, i + 1, &nx, &nxh, &nz);
-                if ((rc = silu_rows(sz, nx, (int64_t)rows * dout, s))) return rc;
+                if (post) { if ((rc = layernorm_rows(sz, ldz, m.g[i], m.nb[i], nx, dout, rows, dout, LN_EPS, 1, s))) return rc; }
+                else if ((rc = silu_rows(sz, nx, (int64_t)rows * dout, s))) return rc;
             }
             continue;
-        } else {
-            if ((rc = rmsnorm_rows(cur, ld, m.g[i], xhat, din, rows, din, RMS_EPS, s))) return rc;
-            // few rows x long K (B x 2048 x 2048): a handful of 64 x 64 tiles would each walk all of K serially on a
-            // fraction of the CUs -> slice K across the grid (batched GEMM over K-slices) and combine in fixed order
-            int S = 1;
-            while (S < 8 && din % (2 * S * 32) == 0 && din / (2 * S) >= 256 && (int64_t)cdiv(rows, 64) * cdiv(dout, 64) * S < 1024) S *= 2;
-            if (S > 1 && rows <= e->maxB) {
-                GemmArgs g{xhat, din, m.w[i], din, e->splitk, dout, nullptr, nullptr, 0, rows, dout, din / S, 0, RMS_EPS};
-                g.batch = S; g.strideA = din / S; g.strideW = din / S; g.strideC = (int64_t)rows * dout;
-                if ((rc = gemm(g, s))) return rc;
-                if ((rc = splitk_reduce(e->splitk, S, rows, dout, m.b[i], last ? 0 : 1, y, ldy, s))) return rc;
-            } else if ((rc = gemm_simple(xhat, din, m.w[i], din, y, ldy, rows, dout, din, last ? 0 : GEMM_SILU, m.b[i], nullptr, 0, s))) return rc;
         }
+        float* y = last ? out : e->hbuf[i & 1];
+        const int ldy = last ? ldo : dout;
+        const float* lin_in = cur;
+        int ld_in = ld;
+        if (pre) {
+            if ((rc = rmsnorm_rows(cur, ld, m.g[i], e->hnorm, din, rows, din, RMS_EPS, s))) return rc;
+            lin_in = e->hnorm; ld_in = din;
+        }
+        const int act = (!last && !post) ? 1 : 0;          // SiLU fused into the linear's epilogue unless a LayerNorm sits in between
+        // few rows x long K (B x 2048 x 2048): a handful of 64 x 64 tiles would each walk all of K serially on a
+        // fraction of the CUs -> slice K across the grid (batched GEMM over K-slices) and combine in fixed order
+        int S = 1;
+        while (S < 8 && din % (2 * S * 32) == 0 && din / (2 * S) >= 256 && (int64_t)cdiv(rows, 64) * cdiv(dout, 64) * S < 1024) S *= 2;
+        if (S > 1 && rows <= e->maxB && ld_in == din) {
+            GemmArgs g{lin_in, din, m.w[i], din, e->splitk, dout, nullptr, nullptr, 0, rows, dout, din / S, 0, RMS_EPS};
+            g.batch = S; g.strideA = din / S; g.strideW = din / S; g.strideC = (int64_t)rows * dout;
+            if ((rc = gemm(g, s))) return rc;
+            if ((rc = splitk_reduce(e->splitk, S, rows, dout, m.b[i], act, y, ldy, s))) return rc;
+        } else if ((rc = gemm_simple(lin_in, ld_in, m.w[i], din, y, ldy, rows, dout, din, act ? GEMM_SILU : 0, m.b[i], nullptr, 0, s))) return rc;
+        if (post && (rc = layernorm_rows(y, ldy, m.g[i], m.nb[i], y, ldy, rows, dout, LN_EPS, 1, s))) return rc;
         cur = y; ld = ldy;
     }
     return 0;
@@ -663,9 +690,10 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->Tcap = c.max_frames > e->maxTq ? c.max_frames : e->maxTq;
     e->Fr = e->maxB * e->maxTq;
     e->Mmax = e->Fr * e->S;
-    d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth);
-    d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth);
-    d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth);
+    D4_REQUIRE(c.head_mlp_recipe == D4_MLP_PRE_RMS || c.head_mlp_recipe == D4_MLP_POST_LAYER, "unknown head_mlp_recipe %d", c.head_mlp_recipe);
+    d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth, c.head_mlp_recipe);
+    d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth, c.head_mlp_recipe);
+    d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth, c.head_mlp_recipe);
     if (const char* gm = getenv("D4_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);     // 0 disables graph replay
     d4::engine_layout(e, false);
     *out = e;
@@ -711,7 +739,9 @@ int d4_engine_prepare(d4_engine* e, void* stream) {
 int d4_engine_cache_frames(const d4_engine* e) { return e ? e->cache_frames : -1; }
 
 int d4_engine_cache_reset(d4_engine* e, int frames) {
-    D4_REQUIRE(e && frames >= 0 && frames <= e->cache_frames, "cache_reset: bad frame count %d (have %d)", frames, e ? e->cache_frames : -1);
+    // the K/V of frame t sit in slot t of the ring whatever the counter says: the caller may rewind, or move forward again over
+    // slots it knows to be intact (dreamer4_amd.world_model.TimeCache keeps that book)
+    D4_REQUIRE(e && frames >= 0 && frames <= e->Tcap, "cache_reset: bad frame count %d (capacity %d)", frames, e ? e->Tcap : -1);
     e->cache_frames = frames;
     return 0;
 }
@@ -954,6 +984,14 @@ int d4_learn(d4_engine* e, const d4_learn_io* io, void* stream) {
 int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
             const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream) {
     d4::GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    return d4::gemm(g, static_cast<hipStream_t>(stream));
+}
+
+int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                    const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int batch,
+                    int64_t strideA, int64_t strideW, int64_t strideC, void* stream) {
+    d4::GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.batch = batch; g.strideA = strideA; g.strideW = strideW; g.strideC = strideC;
     return d4::gemm(g, static_cast<hipStream_t>(stream));
 }
 

@@ -434,8 +434,12 @@ static const char* const kTileName[N_TILE_CFG] = {"128x128/2x4", "128x128/4x2", 
 static const char* const kTileKernel[N_TILE_CFG] = {
     "gemm_kernel<128, 128, 2, 4, 32, 1", "gemm_kernel<128, 128, 4, 2, 32, 1", "gemm_kernel<128, 96, 4, 1, 32, 1", "gemm_kernel<64, 128, 2, 2, 32, 1",
     "gemm_kernel<64, 64, 2, 2, 32, 1", "gemm_kernel<256, 128, 4, 4, 32, 1", "gemm_kernel<64, 128, 2, 2, 16, 1", "gemm_kernel<64, 64, 2, 2, 16, 1"};
-int gemm_profile_classes() { return N_TILE_CFG; }
-const char* gemm_profile_class_name(int c) { return c >= 0 && c < N_TILE_CFG ? kTileKernel[c] : ""; }
+// profile classes: the N_TILE_CFG configurations of this family, then the configurations of the second family (gemm2.hip)
+int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs(); }
+const char* gemm_profile_class_name(int c) {
+    if (c >= N_TILE_CFG) return gemm2_config_name(c - N_TILE_CFG);
+    return c >= 0 ? kTileKernel[c] : "";
+}
 
 template <bool TA, bool TB>
 static bool cfg_valid(int id, const GemmArgs& p) {
@@ -503,8 +507,9 @@ struct TuneKey {
     int M, N, K, flags, batch;
     bool operator<(const TuneKey& o) const { return std::tie(M, N, K, flags, batch) < std::tie(o.M, o.N, o.K, o.flags, o.batch); }
 };
-static std::map<TuneKey, int> g_tuned;
-static int g_forced_cfg = -1;          // test hook (d4_gemm_force_config): run this configuration wherever it is valid
+static std::map<TuneKey, int> g_tuned, g_tuned2;
+static int g_forced_cfg = -1;          // test hook (d4_gemm_force_config): run this configuration wherever it is valid;
+                                       // 100 + c: configuration c of the second family (gemm2.hip)
 int gemm_force_config(int id) { g_forced_cfg = id; return N_TILE_CFG; }
 
 // D4_GEMM_TUNE_CACHE=<file>: the shape -> configuration table is read at first use and every new entry is appended, so a
@@ -593,6 +598,84 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     return launch_id<TA, TB>(best, p, stream);
 }
 
+// ---- second family: launch (with the optional event pair), per-shape choice among its configurations by timing ----
+static int launch_v2(int c, const GemmArgs& p, hipStream_t stream) {
+    const int cls = N_TILE_CFG + c;
+    const bool timed = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
+    if (!timed) return gemm2_launch(c, p, stream);
+    ProfRec rec{};
+    rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.flags = p.flags; rec.batch = p.batch;
+    gemm2_config_tile(c, &rec.bm, &rec.bn);
+    rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+    if (int rc = gemm2_launch(c, p, stream, rec.a, rec.b)) return rc;
+    g_prof.push_back(rec);
+    return 0;
+}
+
+static int heuristic_v2(const GemmArgs& p) {
+    // (gemm2.hip's enum) 0 = 64x64 with three blocks per CU, 1 = its SiLU-GLU capable form: the best or within a few per cent
+    // of it on every shape measured; the timed choice refines this where a call can be repeated
+    return (p.flags & GEMM_SWIGLU) ? 1 : 0;
+}
+
+static int autotune_v2(const GemmArgs& p, hipStream_t stream, int* best_out) {
+    hipEvent_t e0 = prof_event(), e1 = prof_event();
+    const int saved_mask = g_prof_mask;
+    g_prof_mask = 0;
+    int best = -1, rc = 0;
+    float best_ms = 0.f;
+    for (int c = 0; c < gemm2_configs() && !rc; ++c) {
+        if (!gemm2_config_valid(c, p)) continue;
+        if ((rc = gemm2_launch(c, p, stream))) break;
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2 && !rc; ++rep) {
+            (void)hipEventRecord(e0, stream);
+            if ((rc = gemm2_launch(c, p, stream))) break;
+            if ((rc = gemm2_launch(c, p, stream))) break;
+            (void)hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            ms = t < ms ? t : ms;
+        }
+        if (!rc && (best < 0 || ms < best_ms)) { best = c; best_ms = ms; }
+    }
+    g_prof_mask = saved_mask;
+    g_event_pool.push_back(e0);
+    g_event_pool.push_back(e1);
+    if (rc) return rc;
+    D4_REQUIRE(best >= 0, "gemm2: no configuration for M=%d N=%d K=%d flags=%d", p.M, p.N, p.K, p.flags);
+    if (getenv("D4_GEMM_LOG"))
+        fprintf(stderr, "[d4 gemm2] tuned M %6d N %5d K %5d batch %2d flags %3d -> %s (%.1f us)\n", p.M, p.N, p.K, p.batch, p.flags, gemm2_config_name(best), 500.f * best_ms);
+    *best_out = best;
+    return 0;
+}
+
+// Which family runs a call is a RULE on the call's shape / layout (never a timing): the two families sum k in different orders,
+// so a timing-dependent choice between them would make results depend on the tuner.  D4_GEMM_V2=0 disables the second family.
+static bool use_v2(const GemmArgs& p) {
+    static const bool on = !(getenv("D4_GEMM_V2") && atoi(getenv("D4_GEMM_V2")) == 0);
+    return on && gemm2_applicable(p);
+}
+
+static int gemm_v2(const GemmArgs& p, hipStream_t stream) {
+    static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
+    const int nb = p.batch > 0 ? p.batch : 1;
+    const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
+    auto it = g_tuned2.find(key);
+    if (it != g_tuned2.end() && gemm2_config_valid(it->second, p)) return launch_v2(it->second, p, stream);
+    const bool idempotent = !(p.flags & GEMM_ACCUMULATE) && p.R != p.C && p.A != p.C;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
+        return launch_v2(heuristic_v2(p), p, stream);
+    int best = 0;
+    if (int rc = autotune_v2(p, stream, &best)) return rc;
+    g_tuned2[key] = best;
+    return launch_v2(best, p, stream);
+}
+
 int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0, "gemm: bad sizes M=%d N=%d K=%d", p.M, p.N, p.K);
     if (p.M == 0) return 0;
@@ -602,7 +685,10 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(!((p.flags & GEMM_RMS_ROWSCALE) && ta), "gemm: rms rowscale needs a non-transposed A");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (p.N % 64) != 0), "gemm: swiglu needs N %% 64 == 0 (packed pairs)");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (ta || tb)), "gemm: swiglu epilogue is forward-only");
+    // test hook: 100 + c forces configuration c of the second family, 0 .. N_TILE_CFG-1 a configuration of this one
+    if (g_forced_cfg >= 100 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);
     if (gemm_skinny_applicable(p)) return gemm_skinny(p, stream);
+    if (g_forced_cfg < 0 && use_v2(p)) return gemm_v2(p, stream);
     if (!ta && !tb) return launch_t<false, false>(p, stream);
     if (!ta && tb) return launch_t<false, true>(p, stream);
     if (ta && tb) return launch_t<true, true>(p, stream);

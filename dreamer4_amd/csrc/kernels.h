@@ -33,6 +33,13 @@ struct GemmArgs {
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
+// second fp32 family (gemm2.hip): 16x16x4 MFMA fed by an LDS-DMA ring; non-transposed operands, K % 32 == 0
+bool gemm2_applicable(const GemmArgs& p);
+bool gemm2_config_valid(int c, const GemmArgs& p);
+int gemm2_configs();
+const char* gemm2_config_name(int c);
+void gemm2_config_tile(int c, int* bm, int* bn);
+int gemm2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 bool gemm_skinny_applicable(const GemmArgs& p);            // M <= 16 rows: VALU kernel that streams W once (gemm_skinny.hip)
 int gemm_skinny(const GemmArgs& p, hipStream_t stream);
 int gemm_profile_enable(int on);
@@ -110,6 +117,7 @@ int swiglu_pack_rows(const float* W, const float* bias, const float* gamma, floa
                      int inner, int inner_pad, int K, hipStream_t s);
 int pad_cols(const float* W, float* out, int rows, int cols, int cols_pad, hipStream_t s);
 int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int D, float eps, hipStream_t s);
+int layernorm_rows(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int D, float eps, int silu, hipStream_t s);
 
 struct AssembleArgs {
     float* tokens;                 // [B*Tq][S][D]

@@ -297,6 +297,40 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* x, const 
     }
 }
 
+// Backward through a = silu(y), y = LayerNorm(z) * g + b (one wave per row, z recomputed into zhat):
+//   dy = da * silu'(y);  tg = dy * zhat, tb = dy (column-summed afterwards -> dg, db_norm)
+//   dz = rstd * (g dy - mean(g dy) - zhat * mean(g dy zhat))
+__global__ __launch_bounds__(256) void layernorm_silu_bwd_kernel(const float* z, int ldz, const float* da, const float* g, const float* b,
+                                                                 float* tg, float* tb, float* dz, int rows, int d, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* zr = z + (int64_t)r * ldz;
+    float sum = 0.f;
+    for (int c = lane; c < d; c += 64) sum += zr[c];
+    const float mean = wave_sum(sum) / (float)d;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) { const float t = zr[c] - mean; ss += t * t; }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float zh = (zr[c] - mean) * rstd;
+        const float y = zh * g[c] + b[c];
+        const float sg = sigmoidf(y);
+        const float dy = da[(int64_t)r * d + c] * sg * (1.f + y * (1.f - sg));
+        tg[(int64_t)r * d + c] = dy * zh;
+        tb[(int64_t)r * d + c] = dy;
+        const float gd = g[c] * dy;
+        m1 += gd; m2 += gd * zh;
+    }
+    m1 = wave_sum(m1) / (float)d; m2 = wave_sum(m2) / (float)d;
+    for (int c = lane; c < d; c += 64) {
+        const float zh = (zr[c] - mean) * rstd;
+        const float gd = g[c] * tb[(int64_t)r * d + c];
+        dz[(int64_t)r * ldz + c] = rstd * (gd - m1 - zh * m2);
+    }
+}
+
 static inline dim3 grid1d(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
@@ -316,20 +350,39 @@ static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, co
     for (int i = 0; i < m.nl; ++i) m.save_ptrs(const_cast<float*>(save), R, i, &sx[i], &sxh[i], &sz[i]);
     float* dy = e->l_tmp[0]; float* dz = e->l_tmp[1]; float* dxh = e->l_tmp[2];
     const float* cur = dout;
+    const bool pre = m.recipe == D4_MLP_PRE_RMS;
     for (int i = m.nl - 1; i >= 0; --i) {
         const int din = m.dims[i], dout_i = m.dims[i + 1];
         const float* dzp;
         int ldd = dout_i;
+        D4_REQUIRE(m.db[i] && m.dw[i], "learner: head parameters were bound without gradient buffers");
         if (i == m.nl - 1) { dzp = cur; ldd = ld_dout; }
-        else {
+        else if (m.post_norm(i)) {
+            // through silu and the LayerNorm: tg / tb (per-row terms of the norm's weight / bias gradients) use dxh and dy's buffers
+            D4_REQUIRE(m.dg[i] && m.dnb[i], "learner: head parameters were bound without gradient buffers");
+            const int ldz = m.ldz(i);
+            float* tg = dxh; float* tb = dz; float* dzo = e->l_tmp[3];        // cur (= dy, the incoming gradient) stays intact while it is read
+            hipLaunchKernelGGL(layernorm_silu_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, sz[i], ldz, cur, m.g[i], m.nb[i], tg, tb, dzo, R, dout_i, 1e-5f);
+            D4_LAUNCH_CHECK();
+            if ((rc = colsum(tg, dout_i, R, dout_i, m.dg[i], s))) return rc;
+            if ((rc = colsum(tb, dout_i, R, dout_i, m.dnb[i], s))) return rc;
+            dzp = dzo; ldd = ldz;
+        } else {
             hipLaunchKernelGGL(silu_bwd_kernel, grid1d((int64_t)R * dout_i), dim3(256), 0, s, cur, sz[i], dz, (int64_t)R * dout_i);
             D4_LAUNCH_CHECK();
             dzp = dz;
         }
-        D4_REQUIRE(m.db[i] && m.dw[i] && m.dg[i], "learner: head parameters were bound without gradient buffers");
         if ((rc = colsum(dzp, ldd, R, dout_i, m.db[i], s))) return rc;
-        // dW[n][k] = sum_r dz[r][n] * xhat[r][k]
-        if ((rc = gemm_l(dzp, ldd, sxh[i], din, m.dw[i], din, dout_i, din, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        const float* lin_in = pre ? sxh[i] : sx[i];
+        // dW[n][k] = sum_r dz[r][n] * lin_in[r][k]
+        if ((rc = gemm_l(dzp, ldd, lin_in, din, m.dw[i], din, dout_i, din, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        if (!pre) {
+            // dx[r][k] = sum_n dz[r][n] * W[n][k] is the previous layer's activation gradient directly
+            if (i > 0 && (rc = gemm_l(dzp, ldd, m.w[i], din, dy, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
+            cur = dy;
+            continue;
+        }
+        D4_REQUIRE(m.dg[i], "learner: head parameters were bound without gradient buffers");
         // dxhat[r][k] = sum_n dz[r][n] * W[n][k]
         if ((rc = gemm_l(dzp, ldd, m.w[i], din, dxh, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
         // through the RMSNorm; dy of the previous layer overwrites e->l_tmp[0]; tg reuses dz (dz is dead after the GEMMs)

@@ -90,20 +90,29 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
     io.rewards, io.old_action_logits, io.lens, io.is_truncated, io.terminals = P(rewards), P(old_logits), P(lens), P(trunc), P(terms)
     io.losses, io.returns = P(losses), P(returns)
 
-    cb = None
-    if stats == 'global' and parallel.world_size(process_group) > 1:
+    cb, failure = None, []
+    if stats == 'global' and (parallel.world_size(process_group) > 1 or parallel.force_collectives()):
         ws, base = model._ws, model._ws.data_ptr()
 
         def _allreduce(ptr, n, _user):
-            off = ptr - base
-            view = ws[off:off + 4 * n].view(torch.float32)
-            parallel.all_reduce_sum_(view, process_group)
-            return 0
+            # ctypes swallows exceptions raised in a callback (the return value would silently become 0 and the ranks would
+            # carry on with rank-local statistics): catch, remember, and make d4_learn fail with a non-zero code instead
+            try:
+                off = ptr - base
+                view = ws[off:off + 4 * n].view(torch.float32)
+                parallel.all_reduce_sum_(view, process_group)
+                return 0
+            except BaseException as exc:       # noqa: BLE001 - re-raised below
+                failure.append(exc)
+                return 1
 
         cb = _lib.ALLREDUCE_FN(_allreduce)
         io.allreduce_sum = cb
-    _lib.check(lib.d4_learn(model._engine, C.byref(io), model._stream()))
+    rc = lib.d4_learn(model._engine, C.byref(io), model._stream())
     del cb
+    if failure:
+        raise failure[0]
+    _lib.check(rc)
     return losses, returns
 
 

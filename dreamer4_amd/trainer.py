@@ -61,7 +61,7 @@ class DreamTrainer:
                       scratch=torch.zeros(1025, device=m.device), t=0)
             self._state[name] = st
         grad_scale = 1.
-        if parallel.world_size(self.process_group) > 1:
+        if parallel.world_size(self.process_group) > 1 or parallel.force_collectives():
             parallel.all_reduce_sum_(g['grad'], self.process_group)           # ONE collective per head
             if self.stats != 'global':
                 grad_scale = 1. / parallel.world_size(self.process_group)     # average of per-rank means (what DDP would do)

@@ -2,7 +2,9 @@
 
 Same constructor keyword names, same `generate` / `learn_from_experience` signatures and return
 types as the reference (dreamer4/dreamer4.py:4661-4778, 5893-5904, 6308-6339); parameters carry
-the reference's state_dict key names so checkpoints interchange as flat {key: tensor}.  All compute
+the reference's state_dict key names so checkpoints interchange as flat {key: tensor} (the keys under the three
+normed head MLPs and `to_reward_pred` come from x-mlps-pytorch, which is not in the image: their recipe / spelling is
+a descriptor, `head_mlp_recipe`, not a verified fact — DESIGN.md "Oracle").  All compute
 is dispatched to the HIP engine through the C-ABI (include/d4hip.h); PyTorch only owns device
 memory, the stream and (multi-GPU) the process group.  No CPU / eager fallback exists: on a
 machine without the built extension or without a GPU these methods raise.
@@ -53,17 +55,43 @@ def _linear_b(out_f, in_f):
 
 def mlp_widths(dim_in, dim, dim_out, depth):
     """create_mlp(dim, depth, dim_in, dim_out) of x-mlps-pytorch: (dim_in, dim x (depth + 1), dim_out).
-    ASSUMED recipe (the package is not in the image) — see DESIGN.md 'Oracle / unpinned third-party pieces'."""
+    ASSUMED (the package is not in the image) — see DESIGN.md 'Oracle / unpinned third-party pieces'."""
     return (dim_in, *((dim,) * (depth + 1)), dim_out)
 
 
+# Layer recipe of the normed head MLPs (policy / value / terminal).  x-mlps-pytorch is absent from the image, so the recipe is ONE
+# descriptor that the oracle shim, the restatement, this module tree and the HIP engine (csrc/engine.h `Mlp`) all honour; a real
+# checkpoint that turns out to use the other recipe needs `head_mlp_recipe=...`, not a kernel change.
+#   'pre_rms'     RMSNorm(d_in) -> Linear -> SiLU, no activation after the last Linear      keys layers.{i}.0.weight | layers.{i}.1.{weight,bias}
+#   'post_layer'  Linear -> LayerNorm(d_out) -> SiLU, the last layer is a bare Linear       keys layers.{i}.0.{weight,bias} | layers.{i}.1.{weight,bias} ; last: layers.{i}.{weight,bias}
+MLP_RECIPES = dict(pre_rms=0, post_layer=1)
+
+
+def mlp_param_specs(recipe, widths):
+    """[(key suffix, shape, kind)] of one normed MLP in state_dict order; kind in {'norm_w', 'norm_b', 'lin_w', 'lin_b'}."""
+    out, n = [], len(widths) - 1
+    for i, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
+        if recipe == 'pre_rms':
+            out += [(f'layers.{i}.0.weight', (a,), 'norm_w'), (f'layers.{i}.1.weight', (b, a), 'lin_w'), (f'layers.{i}.1.bias', (b,), 'lin_b')]
+        elif i < n - 1:
+            out += [(f'layers.{i}.0.weight', (b, a), 'lin_w'), (f'layers.{i}.0.bias', (b,), 'lin_b'),
+                    (f'layers.{i}.1.weight', (b,), 'norm_w'), (f'layers.{i}.1.bias', (b,), 'norm_b')]
+        else:
+            out += [(f'layers.{i}.weight', (b, a), 'lin_w'), (f'layers.{i}.bias', (b,), 'lin_b')]
+    return out
+
+
 class TimeCache:
-    """Opaque handle of the engine's time KV cache (reference: DynamicsIntermediates.main.next_kv_cache,
-    token_count — dreamer4.py:3255-3265).  `kv()` materialises the reference layout
-    (time_layers, 2, B*S, heads, frames, attn_dim_head)."""
+    """Handle of the engine's time KV cache (reference: DynamicsIntermediates.main.next_kv_cache, token_count —
+    dreamer4.py:3255-3265).  The reference hands out plain tensors, so an older cache can be passed again (K denoising
+    evaluations against one cache, dreamer4.py:6510-6531).  Here the K/V of frame t live in slot t of the engine's ring and a
+    handle stays usable without any copy as long as none of its slots has been rewritten since it was created (every call
+    writes the slots from its own first new frame upwards); after that it needs the copy `kv()` made beforehand.
+    `kv()` materialises the reference layout (time_layers, 2, B*S, heads, frames, attn_dim_head)."""
 
     def __init__(self, model, frames, batch, serial):
         self._model, self.frames, self.batch, self._serial = model, frames, batch, serial
+        self._generation = model._engine_generation
         self._kv = None
 
     @property
@@ -75,6 +103,10 @@ class TimeCache:
             self._kv = self._model._export_cache(self)
         return self._kv
 
+
+# buffers the engine never reads (key parity with the reference's state_dict only)
+_NOT_BOUND = {'zero', 'ema_returns_mean', 'ema_returns_var', 'reward_loss_weight', 'terminal_loss_weight',
+              'discrete_action_loss_weight', 'continuous_action_loss_weight'}
 
 _UNSUPPORTED_DEFAULTS = dict(
     video_tokenizer=None, aux_image_encoder=None, num_agents=1, num_video_views=1, mot_temporal=False,
@@ -126,9 +158,14 @@ class DynamicsWorldModel(nn.Module):
         delight_temperature=1.,
         normalize_advantages=None,
         policy_entropy_weight=.01,
+        head_mlp_recipe='pre_rms',
         **kwargs,
     ):
+        """`head_mlp_recipe` is not a reference argument: it names the layer recipe of x_mlps_pytorch's normed MLP (see MLP_RECIPES)."""
         super().__init__()
+        if head_mlp_recipe not in MLP_RECIPES:
+            raise ValueError(f'head_mlp_recipe must be one of {sorted(MLP_RECIPES)}')
+        self.head_mlp_recipe = head_mlp_recipe
         for k, v in kwargs.items():
             if k not in _UNSUPPORTED_DEFAULTS:
                 raise TypeError(f'unknown argument {k!r}')
@@ -192,6 +229,8 @@ class DynamicsWorldModel(nn.Module):
         self._trunk_version = None
         self._cache_serial = 0
         self._live_cache = None
+        self._slot_serial = []           # per KV-ring slot: serial of the call that last wrote it
+        self._engine_generation = 0      # bumped whenever the engine (and with it the ring) is rebuilt
         self._groups = {}
 
     # ------------------------------------------------------------------------------ parameters
@@ -224,10 +263,16 @@ class DynamicsWorldModel(nn.Module):
             reg(pre + 'proj_out.bias', _linear_b(D, self.ff_inner))
 
         def mlp(pre, widths):
-            for i, (a, b) in enumerate(zip(widths[:-1], widths[1:])):
-                reg(f'{pre}layers.{i}.0.weight', torch.ones(a))
-                reg(f'{pre}layers.{i}.1.weight', _linear_w(b, a))
-                reg(f'{pre}layers.{i}.1.bias', _linear_b(b, a))
+            for key, shape, kind in mlp_param_specs(self.head_mlp_recipe, widths):
+                if kind == 'norm_w':
+                    reg(pre + key, torch.ones(shape))
+                elif kind == 'norm_b':
+                    reg(pre + key, torch.zeros(shape))
+                elif kind == 'lin_w':
+                    reg(pre + key, _linear_w(*shape))
+                    fan_in = shape[1]
+                else:
+                    reg(pre + key, _linear_b(shape[0], fan_in))
 
         if self.num_spatial_tokens == self.num_latent_tokens:
             # one spatial token per latent token: Linear(dim_latent, dim) in, RMSNorm -> [Identity] -> Linear out   D4:4816-4834
@@ -248,6 +293,7 @@ class DynamicsWorldModel(nn.Module):
         reg('action_learned_embed', torch.randn(1, D) * 1e-2)
         reg('reward_learned_embed', torch.randn(1, D) * 1e-2)          # unused on the supported path; kept for key parity
         reg('task_embed.weight', torch.randn(self.num_tasks, D))
+        reg('latent_genes', torch.randn(0, D) * 1e-2)                   # num_latent_genes = 0 on the supported path; key parity (dreamer4.py:4946)
         mlp('policy_head.', mlp_widths(D, 4 * D, 4 * D, self.policy_head_mlp_depth))
         A = sum(self.num_discrete_actions)
         reg('action_embedder.discrete_action_unembed', torch.randn(A, self.multi_token_pred_len, 4 * D) * 1e-2)
@@ -279,10 +325,40 @@ class DynamicsWorldModel(nn.Module):
             _register(self, f'{name}.support', support, buffer=True, persistent=False)
             _register(self, f'{name}.centers', (support[:-1] + support[1:]) / 2, buffer=True, persistent=False)
         _register(self, 'zero', torch.tensor(0.), buffer=True, persistent=False)
+        # buffers of the reference's state_dict that the imagination path never reads (dreamer4.py:5245-5246, 5260-5263): registered
+        # so that a reference checkpoint loads with strict=True
+        for name, val in (('ema_returns_mean', 0.), ('ema_returns_var', 1.), ('reward_loss_weight', 1.), ('terminal_loss_weight', 1.),
+                          ('discrete_action_loss_weight', 1.), ('continuous_action_loss_weight', 1.)):
+            _register(self, name, torch.tensor(val), buffer=True)
 
     @property
     def device(self):
         return self.zero.device
+
+    def head_mlp_output_linear(self, head):
+        """(weight, bias) of the last Linear of a normed head MLP ('policy_head', 'value_head', 'to_state_terminal_pred.0'),
+        whatever the recipe names it."""
+        widths_n = dict(policy_head=self.policy_head_mlp_depth, value_head=self.value_head_mlp_depth)
+        last = (widths_n[head] if head in widths_n else self.terminal_mlp_depth) + 1
+        pre = f'{head}.layers.{last}.' + ('1.' if self.head_mlp_recipe == 'pre_rms' else '')
+        params = dict(self.named_parameters())
+        return params[pre + 'weight'], params[pre + 'bias']
+
+    # x_mlps_pytorch.Ensemble's parameter naming is as unverifiable here as the MLP recipe: accept the plausible spellings of the
+    # two stacked tensors of `to_reward_pred` (RMSNorm weight, Linear weight) when loading a checkpoint
+    _ENSEMBLE_ALIASES = {'to_reward_pred.params.0': ('to_reward_pred.param_values.0', 'to_reward_pred.params.0_weight', 'to_reward_pred.params.0.weight',
+                                                     'to_reward_pred.ensemble_params.0.weight'),
+                         'to_reward_pred.params.1': ('to_reward_pred.param_values.1', 'to_reward_pred.params.1_weight', 'to_reward_pred.params.1.weight',
+                                                     'to_reward_pred.ensemble_params.1.weight')}
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for ours, aliases in self._ENSEMBLE_ALIASES.items():
+            if prefix + ours not in state_dict:
+                for a in aliases:
+                    if prefix + a in state_dict:
+                        state_dict[prefix + ours] = state_dict.pop(prefix + a)
+                        break
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def policy_head_parameters(self):
         """dreamer4.py:5343-5355"""
@@ -311,6 +387,7 @@ class DynamicsWorldModel(nn.Module):
         c.policy_head_mlp_depth, c.value_head_mlp_depth = self.policy_head_mlp_depth, self.value_head_mlp_depth
         c.terminal_mlp_depth, c.predict_terminals = self.terminal_mlp_depth, int(self.predict_terminals)
         c.reward_num_bins, c.value_num_bins = self.reward_num_bins, self.value_num_bins
+        c.head_mlp_recipe = MLP_RECIPES[self.head_mlp_recipe]
         c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
         c.gae_discount_factor, c.gae_lambda, c.ppo_eps_clip = self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip
         c.policy_entropy_weight = self.policy_entropy_weight
@@ -344,6 +421,8 @@ class DynamicsWorldModel(nn.Module):
             cfg = self._make_config(caps)
             _lib.check(lib.d4_engine_create(C.byref(cfg), C.byref(eng)))
             self._engine, self._engine_caps = eng, caps
+            self._engine_generation += 1
+            self._slot_serial = [0] * max(caps[1], caps[2])
             nbytes = lib.d4_engine_workspace_bytes(eng)
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
             base = self._ws.data_ptr()
@@ -355,6 +434,8 @@ class DynamicsWorldModel(nn.Module):
             if keep is not None:
                 tc, kv = keep
                 _lib.check(lib.d4_engine_cache_import(eng, _lib.ptr(kv), tc.batch, tc.frames, self._stream()))
+                tc._generation = self._engine_generation             # the live handle moves to the new ring
+                self._mark_slots(0, tc.frames, tc._serial)
         self._bind()
         return self._engine
 
@@ -403,7 +484,7 @@ class DynamicsWorldModel(nn.Module):
                 grads[id(p)] = g['grad'][off:off + p.numel()]
                 off += p.numel()
         tensors = dict(self.named_parameters())
-        tensors.update({k: v for k, v in self.named_buffers() if k != 'zero'})
+        tensors.update({k: v for k, v in self.named_buffers() if k not in _NOT_BOUND})
         sig = tuple((k, t.data_ptr(), t.numel()) for k, t in tensors.items())
         if sig != self._bound_sig:
             for k, t in tensors.items():
@@ -422,14 +503,28 @@ class DynamicsWorldModel(nn.Module):
             self._trunk_version = ver
         self._bind_cache = ([(t, t.data_ptr()) for t in tensors.values()], trunk)
 
+    def _mark_slots(self, lo, hi, serial):
+        if hi > len(self._slot_serial):
+            self._slot_serial.extend([0] * (hi - len(self._slot_serial)))
+        for i in range(lo, hi):
+            self._slot_serial[i] = serial
+
+    def _cache_in_engine(self, tc: TimeCache):
+        """True while every ring slot the handle covers still holds what it held when the handle was created."""
+        return (tc._generation == self._engine_generation and tc.frames <= len(self._slot_serial)
+                and all(sv <= tc._serial for sv in self._slot_serial[:tc.frames]))
+
     def _export_cache(self, tc: TimeCache):
         lib = _lib.load()
-        if self._live_cache is not tc:
-            raise _lib.D4Error('this TimeCache is stale (the engine cache has advanced past it); '
-                               'call .kv() before issuing further generate() calls to keep a copy')
+        if not self._cache_in_engine(tc):
+            raise _lib.D4Error('this TimeCache is stale (later calls have rewritten its slots of the engine cache); '
+                               'call .kv() before issuing them to keep a copy')
         lt = sum(1 for i in range(self.depth) if (i + 1) % self.time_block_every == 0)
         out = torch.empty(lt, 2, tc.batch * self.tokens_per_frame, self.attn_heads, tc.frames, self.attn_dim_head, device=self.device)
+        now = lib.d4_engine_cache_frames(self._engine)
+        _lib.check(lib.d4_engine_cache_reset(self._engine, tc.frames))
         _lib.check(lib.d4_engine_cache_export(self._engine, _lib.ptr(out), tc.batch, self._stream()))
+        _lib.check(lib.d4_engine_cache_reset(self._engine, now))
         return out
 
     def _adopt_cache(self, time_cache, batch):
@@ -440,12 +535,24 @@ class DynamicsWorldModel(nn.Module):
             return 0
         assert isinstance(time_cache, TimeCache), 'time_cache must come from generate(..., return_time_cache=True)'
         assert time_cache.batch == batch, 'time_cache batch size mismatch'
-        if self._live_cache is not time_cache:
+        if self._cache_in_engine(time_cache):
+            _lib.check(lib.d4_engine_cache_reset(self._engine, time_cache.frames))       # rewind / fast-forward the frame counter only
+        else:
             if time_cache._kv is None:
                 raise _lib.D4Error('stale TimeCache without a materialised copy (.kv())')
             _lib.check(lib.d4_engine_cache_import(self._engine, _lib.ptr(time_cache._kv), batch, time_cache.frames, self._stream()))
-            self._live_cache = time_cache
+            time_cache._generation = self._engine_generation
+            self._cache_serial += 1
+            time_cache._serial = self._cache_serial
+            self._mark_slots(0, time_cache.frames, time_cache._serial)
+        self._live_cache = time_cache
         return time_cache.frames
+
+    def invalidate_prepared(self):
+        """Force the fused / gamma-folded weight images to be rebuilt on the next call.  Needed only after writing a trunk weight
+        in a way autograd's version counter cannot see (`p.data.copy_(...)`, `dist.broadcast(p.data)`, raw pointers); ordinary
+        in-place updates (`p.copy_()` under no_grad, optimiser steps, `load_state_dict`) are detected automatically."""
+        self._trunk_version = None
 
     # ------------------------------------------------------------------------------ forward (inference branch)
     @torch.no_grad()
@@ -487,8 +594,11 @@ class DynamicsWorldModel(nn.Module):
         _lib.check(lib.d4_wm_forward(self._engine, _lib.ptr(lat), _lib.ptr(sig), step, _lib.ptr(prev), _lib.ptr(tk), B, T,
                                      int(time_cache is not None), int(commit_cache), _lib.ptr(pred), _lib.ptr(agent), self._stream()))
         self._cache_serial += 1
+        self._mark_slots(cached, cached + T, self._cache_serial)      # every evaluation writes its new frames' K/V (scratch unless committed)
+        if not commit_cache:
+            return pred, (agent, time_cache)                           # the cache passed in is unchanged and still the live one
         tc = TimeCache(self, lib.d4_engine_cache_frames(self._engine), B, self._cache_serial)
-        self._live_cache = tc if commit_cache else None
+        self._live_cache = tc
         return pred, (agent, tc)
 
     # ------------------------------------------------------------------------------ generate
@@ -626,20 +736,26 @@ class DynamicsWorldModel(nn.Module):
             _lib.check(lib.d4_rollout(self._engine, C.byref(io), self._stream()))
 
         self._cache_serial += 1
-        new_cache = None
-        if use_time_cache:
-            new_cache = TimeCache(self, lib.d4_engine_cache_frames(self._engine), B, self._cache_serial)
-            self._live_cache = new_cache
-        else:
-            self._live_cache = None
+        first_new = cached if use_time_cache else 0
+        self._mark_slots(first_new, max(first_new + (T if cached == 0 else F_), first_new), self._cache_serial)
 
         # ---- early exit once every trajectory has terminated (dreamer4.py:6681): the engine always runs all
-        # frames (no host sync inside the rollout); frames past the reference's break are dropped here.
+        # frames (no host sync inside the rollout); frames past the reference's break are dropped here, also from the cache.
         Tp = T
         terminals_b = terminals.bool()
         if sample_terminals and bool(terminals_b.all()):
             Tp = int(lens.max().item())
         Fp = Tp - P
+        new_cache = None
+        if use_time_cache:
+            frames_now = lib.d4_engine_cache_frames(self._engine)
+            if Tp < T and F_ > 0:
+                frames_now -= T - Tp
+                _lib.check(lib.d4_engine_cache_reset(self._engine, frames_now))
+            new_cache = TimeCache(self, frames_now, B, self._cache_serial)
+            self._live_cache = new_cache
+        else:
+            self._live_cache = None
         latents = latents[:, :Tp].clamp(-1., 1.)
 
         if not (return_rewards_per_frame or return_agent_actions):

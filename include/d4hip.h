@@ -32,11 +32,13 @@ extern "C" {
 #endif
 
 #define D4_MAX_ACTION_TYPES 8
+#define D4_MLP_PRE_RMS 0        /* RMSNorm -> Linear -> SiLU                        (x_mlps_pytorch create_mlp: recipe unpinned) */
+#define D4_MLP_POST_LAYER 1     /* Linear -> LayerNorm -> SiLU, bare last Linear */
 
 /* Constructor arguments of DynamicsWorldModel (supported subset; names as D4:4662-4778). */
 typedef struct d4_config {
     int32_t dim, dim_latent, num_latent_tokens, depth, time_block_every;
-    int32_t attn_heads, attn_dim_head;          /* attn_dim_head must be 64 (one wavefront) */
+    int32_t attn_heads, attn_dim_head;          /* attn_dim_head: 16, 32 or 64 (a head row lives in one wavefront) */
     float attn_softclamp_value;
     int32_t num_spatial_tokens, num_register_tokens, max_steps, num_tasks;
     int32_t num_discrete_action_types;
@@ -44,6 +46,7 @@ typedef struct d4_config {
     int32_t multi_token_pred_len;
     int32_t policy_head_mlp_depth, value_head_mlp_depth, terminal_mlp_depth, predict_terminals;
     int32_t reward_num_bins, value_num_bins;
+    int32_t head_mlp_recipe;                    /* D4_MLP_PRE_RMS / D4_MLP_POST_LAYER: layer recipe of the policy / value / terminal MLPs (engine.h) */
     int32_t pool_heads, pool_dim_head;          /* AttentionPool defaults 4 x 64 (D4:2147-2148) */
     /* learn_from_experience hyper-parameters (D4:4731-4744) */
     float gae_discount_factor, gae_lambda, ppo_eps_clip, policy_entropy_weight;
@@ -84,7 +87,8 @@ int d4_engine_prepare(d4_engine* e, void* stream);
 
 /* Number of frames currently held by the time KV cache (token_count of D4:3261). */
 int d4_engine_cache_frames(const d4_engine* e);
-int d4_engine_cache_reset(d4_engine* e, int frames);   /* truncate / reset (0 = empty) */
+int d4_engine_cache_reset(d4_engine* e, int frames);   /* set the frame counter: 0 = empty, < current = truncate; moving it forward
+                                                          again is valid while the slots in between have not been rewritten */
 /* Export / import the cache in the reference layout (time_layers, 2, B*S, heads, t, 64)  D4:2075, 3256. */
 int d4_engine_cache_export(d4_engine* e, float* dst, int batch, void* stream);
 int d4_engine_cache_import(d4_engine* e, const float* src, int batch, int frames, void* stream);
@@ -196,6 +200,11 @@ int d4_debug_buffer(d4_engine* e, const char* name, float** ptr);
 /* ---- single-kernel entry points (parity tests call the same launchers the engine uses) ---- */
 int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
             const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
+/* strided-batch form (the AttentionPool's per-head value projection, D4:2143-2177): problem b reads A + b*strideA,
+ * W + b*strideW and writes C (and R) + b*strideC   (strides in elements). */
+int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
+                    const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int batch,
+                    int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
                float eps, void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,

@@ -17,12 +17,18 @@ def make_noise(cfg: Config, frames, batch, seed):
     """Same recipe as tests/util.make_noise (kept identical so fixtures can be regenerated from seeds)."""
     g = torch.Generator().manual_seed(seed)
     n, dl, A = cfg.num_latent_tokens, cfg.dim_latent, cfg.total_discrete_actions
-    return dict(
+    nz = dict(
         latent=torch.randn(frames, batch, n, dl, generator=g),
         context=torch.randn(frames, batch, n, dl, generator=g),
         gumbel_u=torch.rand(frames, batch, A, generator=g).clamp(1e-6, 1. - 1e-6),
         bern_u=torch.rand(frames, batch, generator=g),
     )
+    nc = getattr(cfg, 'num_continuous_actions', 0)
+    if nc > 0:      # Beta sampling as a ratio of Marsaglia-Tsang gammas: (normal, uniform) per rejection round
+        nrm = torch.randn(frames, batch, nc, 2, 6, generator=g)
+        uni = torch.rand(frames, batch, nc, 2, 6, generator=g).clamp(1e-6, 1. - 1e-6)
+        nz['beta'] = torch.stack((nrm, uni), dim=-1)
+    return nz
 
 
 class NoiseTape:
@@ -51,26 +57,35 @@ class NoiseTape:
         self.a += n
         return u
 
+    def beta_noise_like(self, shape, device=None):
+        t = self.noise['beta'][self.f]
+        return t.reshape(*shape, *t.shape[-3:]).clone()
+
 
 @contextmanager
 def injected(noise):
     D4 = load_reference()
     import discrete_continuous_embed_readout as dcer
+    from discrete_continuous_embed_readout import discrete_continuous_embed_readout as dcer_impl
     tape = NoiseTape(noise)
-    saved = (D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like)
+    saved = (D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like, dcer_impl.beta_noise_like)
     D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like = tape.randn, tape.randn_like, tape.bernoulli, tape.uniform_like
+    dcer_impl.beta_noise_like = tape.beta_noise_like
     try:
         yield tape
     finally:
-        D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like = saved
+        D4.randn, D4.randn_like, torch.bernoulli, dcer.uniform_like, dcer_impl.beta_noise_like = saved
 
 
 def build_reference_model(cfg: Config, seed=0, head_scale=True):
     """Reference DynamicsWorldModel for `cfg` with default init under `seed`; heads get
     non-trivial weights so logits/values are not all ~0."""
     D4 = load_reference()
+    from x_mlps_pytorch import normed_mlp
+    normed_mlp.RECIPE = cfg.head_mlp_recipe             # layer recipe of the stand-in normed MLP (restored below)
     torch.manual_seed(seed)
     m = D4.DynamicsWorldModel(
+        num_continuous_actions=cfg.num_continuous_actions,
         dim=cfg.dim, dim_latent=cfg.dim_latent, num_latent_tokens=cfg.num_latent_tokens,
         depth=cfg.depth, time_block_every=cfg.time_block_every, attn_heads=cfg.attn_heads,
         attn_dim_head=cfg.attn_dim_head, num_spatial_tokens=cfg.num_spatial_tokens,
@@ -85,9 +100,12 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
         delight_temperature=cfg.delight_temperature, pmpo_pos_to_neg_weight=cfg.pmpo_pos_to_neg_weight,
         pmpo_reverse_kl=cfg.pmpo_reverse_kl, pmpo_kl_div_loss_weight=cfg.pmpo_kl_div_loss_weight,
     ).eval()
+    normed_mlp.RECIPE = 'pre_rms'
+    post_ln = cfg.head_mlp_recipe == 'post_layer'
     if head_scale:
         with torch.no_grad():
             m.action_embedder.discrete_action_unembed.mul_(100.)
+            m.action_embedder.continuous_action_unembed.mul_(30.)
             for p in m.to_reward_pred.parameters():
                 if p.ndim == 3: p.mul_(20.)
             g = torch.Generator().manual_seed(seed + 1)
@@ -97,11 +115,12 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
                     p.copy_(torch.randn(p.shape, generator=g) * 0.5)
                 if name.endswith('gamma'):
                     p.copy_(torch.randn(p.shape, generator=g) * 0.2)
-                if name.endswith('norm.weight') or name.endswith('norm_context.weight') or (name.endswith('.0.weight') and p.ndim == 1):
+                if name.endswith('norm.weight') or name.endswith('norm_context.weight') or (name.endswith('.0.weight') and p.ndim == 1) \
+                        or (post_ln and name.endswith('.1.weight') and p.ndim == 1):
                     p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
             if cfg.predict_terminals:
-                last = m.to_state_terminal_pred[0].layers[-1][1]
-                last.bias.fill_(-2.5)
+                last = m.to_state_terminal_pred[0].layers[-1]
+                (last if post_ln else last[1]).bias.fill_(-2.5)
     return m
 
 

@@ -78,6 +78,8 @@ class Config:
     pmpo_reverse_kl: bool = True
     pmpo_kl_div_loss_weight: float = 0.3
     rotary_theta: float = 10000.
+    num_continuous_actions: int = 0          # Beta policy head (continuous_dist_type='beta', D4:1131, 1172-1173)
+    head_mlp_recipe: str = 'pre_rms'         # layer recipe of x_mlps_pytorch's normed MLP: 'pre_rms' | 'post_layer' (see mlp())
 
     def __post_init__(self):
         if isinstance(self.num_discrete_actions, int):
@@ -93,9 +95,13 @@ class Config:
         return sum(self.is_time)
 
     @property
+    def has_actions(self):
+        return len(self.num_discrete_actions) > 0 or self.num_continuous_actions > 0
+
+    @property
     def tokens_per_frame(self):
-        # [flow | space | registers | action | agent]   D4:7222
-        return 1 + self.num_spatial_tokens + self.num_register_tokens + 1 + 1
+        # [flow | space | registers | action (only with an action space) | agent]   D4:7222, 7124-7130
+        return 1 + self.num_spatial_tokens + self.num_register_tokens + (1 if self.has_actions else 0) + 1
 
     @property
     def ff_inner(self):
@@ -329,23 +335,30 @@ def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='tr
 
 # ----------------------------------------------------------------------------- world-model forward
 
-def action_tokens(cfg: Config, W, actions, time, batch):
-    """D4:7088-7126 + ActionEmbedder.forward D4:1501-1562 (discrete, all action types).
-    actions (b, time-1 | time, na) int64 or None -> (b, time, d); frame 0 gets a zero token."""
+def action_tokens(cfg: Config, W, actions, time, batch, cont_actions=None):
+    """D4:7088-7126 + ActionEmbedder.forward D4:1501-1562 (all action types; discrete: embedding gather summed over types,
+    continuous: embed[type] * value summed over types, D4:1535-1545).
+    actions (b, time-1 | time, na) int64 or None, cont_actions (b, same, nc) float or None -> (b, time, d); frame 0 gets a zero token."""
     d = cfg.dim
-    if actions is None or actions.shape[1] == 0:
+    have_d = actions is not None and actions.shape[1] > 0 and actions.shape[-1] > 0
+    have_c = cont_actions is not None and cont_actions.shape[1] > 0 and cont_actions.shape[-1] > 0
+    if not (have_d or have_c):
         return torch.zeros(batch, time, d)
-    offsets = torch.tensor([0, *torch.tensor(cfg.num_discrete_actions).cumsum(0)[:-1].tolist()])
-    emb = W['action_embedder.discrete_action_embed.weight'][actions + offsets].sum(dim=-2)
+    emb = 0.
+    if have_d:
+        offsets = torch.tensor([0, *torch.tensor(cfg.num_discrete_actions).cumsum(0)[:-1].tolist()])
+        emb = emb + W['action_embedder.discrete_action_embed.weight'][actions + offsets].sum(dim=-2)
+    if have_c:
+        emb = emb + (W['action_embedder.continuous_action_embed.weight'] * cont_actions[..., None]).sum(dim=-2)
     emb = emb + W['action_learned_embed']                              # (1, d) broadcast
-    if actions.shape[1] == time:
+    if emb.shape[1] == time:
         emb = emb[:, :-1]
     assert emb.shape[1] == time - 1
     return F.pad(emb, (0, 0, 1, 0), value=0.)
 
 
 def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, tasks=None,
-               cache: TrunkCache | None = None, trace: dict | None = None):
+               cache: TrunkCache | None = None, trace: dict | None = None, cont_actions=None):
     """DynamicsWorldModel.forward(latent_is_noised=True, return_pred_only=True,
     return_intermediates=True)  D4:6792-7295.
 
@@ -356,7 +369,7 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
     b, t, n, dl = latents.shape
     d = cfg.dim
     has_cache = cache is not None and len(cache.kv) > 0
-    act_tok = action_tokens(cfg, W, actions, t, b)
+    act_tok = action_tokens(cfg, W, actions, t, b, cont_actions)
     if has_cache and t > 1:
         latents, signal_levels, act_tok = latents[:, -1:], signal_levels[:, -1:], act_tok[:, -1:]
         t = 1
@@ -376,7 +389,7 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
         agent = agent + W['task_embed.weight'][tasks][:, None]
     agent = agent[:, None].expand(b, t, -1, -1)
 
-    if len(cfg.num_discrete_actions) == 0:                                          # no action space: no action token  D4:7128-7130
+    if not cfg.has_actions:                                                         # no action space: no action token  D4:7128-7130
         tokens = torch.cat((flow_tok, space, regs, agent), dim=2)
     else:
         tokens = torch.cat((flow_tok, space, regs, act_tok[:, :, None], agent), dim=2)
@@ -397,13 +410,29 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
 
 # ----------------------------------------------------------------------------- heads
 
-def mlp(W, pre, x, n_layers):
-    """Normed MLP (recipe ASSUMED, see oracle/shim/x_mlps_pytorch): RMSNorm -> Linear -> SiLU, no act on last."""
+def layernorm(x, w, b, eps=1e-5):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = (x - mu).pow(2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def mlp(W, pre, x, n_layers, recipe='pre_rms'):
+    """Normed MLP of x_mlps_pytorch.create_mlp (D4:4950, 5083, 5095).  The package is absent: the layer recipe is a descriptor
+    (oracle/shim/x_mlps_pytorch/normed_mlp.py, PARITY UNPINNED):
+      'pre_rms'     RMSNorm -> Linear -> SiLU, no activation after the last Linear
+      'post_layer'  Linear -> LayerNorm -> SiLU, the last layer a bare Linear"""
     for i in range(n_layers):
-        x = rmsnorm(x, W[f'{pre}layers.{i}.0.weight'])
-        x = x @ W[f'{pre}layers.{i}.1.weight'].t() + W[f'{pre}layers.{i}.1.bias']
-        if i != n_layers - 1:
-            x = F.silu(x)
+        last = i == n_layers - 1
+        if recipe == 'pre_rms':
+            x = rmsnorm(x, W[f'{pre}layers.{i}.0.weight'])
+            x = x @ W[f'{pre}layers.{i}.1.weight'].t() + W[f'{pre}layers.{i}.1.bias']
+            if not last:
+                x = F.silu(x)
+        elif last:
+            x = x @ W[f'{pre}layers.{i}.weight'].t() + W[f'{pre}layers.{i}.bias']
+        else:
+            x = x @ W[f'{pre}layers.{i}.0.weight'].t() + W[f'{pre}layers.{i}.0.bias']
+            x = F.silu(layernorm(x, W[f'{pre}layers.{i}.1.weight'], W[f'{pre}layers.{i}.1.bias']))
     return x
 
 
@@ -440,7 +469,7 @@ def reward_head(cfg, W, agent_embed):
 def terminal_prob(cfg, W, denoised_latent):
     """D4:6606-6611: mean over (view, latent token) -> MLP -> sigmoid."""
     pooled = denoised_latent.mean(dim=-2)
-    logit = mlp(W, 'to_state_terminal_pred.0.', pooled, mlp_num_layers(cfg.terminal_mlp_depth))
+    logit = mlp(W, 'to_state_terminal_pred.0.', pooled, mlp_num_layers(cfg.terminal_mlp_depth), cfg.head_mlp_recipe)
     return logit.squeeze(-1).sigmoid()
 
 
@@ -476,20 +505,83 @@ def discrete_log_probs(cfg, logits, actions, with_entropy=False):
     return (lps, torch.stack(ents, dim=-1)) if with_entropy else lps
 
 
+# ---- continuous actions: Beta policy head (Readout / BetaDist of discrete_continuous_embed_readout, stood in by
+# oracle/shim/discrete_continuous_embed_readout — parameterisation, tempering and sampler ASSUMED there, PARITY UNPINNED)
+
+GAMMA_ROUNDS = 6
+
+
+def policy_cont_params(cfg, W, policy_embed):
+    """ActionEmbedder.unembed(pred_head_index=0), continuous half D4:1340-1353: (..., nc, 2) raw parameters."""
+    un = W['action_embedder.continuous_action_unembed'][:, 0]         # (nc, 4d, 2)
+    return torch.einsum('...d,ndt->...nt', policy_embed, un)
+
+
+def beta_alpha_beta(params):
+    return F.softplus(params[..., 0]) + 1., F.softplus(params[..., 1]) + 1.      # unimodal=True  D4:1172-1173
+
+
+def gamma_from_noise(shape_param, noise):
+    """Marsaglia-Tsang with the rejection loop unrolled over the injected rounds; noise (..., rounds, 2) = (normal, uniform)."""
+    d = shape_param - 1. / 3.
+    c = 1. / torch.sqrt(9. * d)
+    out, done = None, torch.zeros_like(shape_param, dtype=torch.bool)
+    rounds = noise.shape[-2]
+    for r in range(rounds):
+        x, u = noise[..., r, 0], noise[..., r, 1]
+        t = 1. + c * x
+        v = t * t * t
+        ok = (v > 0.) & (torch.log(u.clamp(min=1e-30)) < 0.5 * x * x + d - d * v + d * torch.log(v.clamp(min=1e-30)))
+        cand = d * v
+        take = (ok | (r == rounds - 1)) & ~done
+        out = cand if out is None else torch.where(take, cand, out)
+        done = done | ok
+    return out.clamp(min=1e-30)
+
+
+def sample_continuous(params, noise, temperature=1.):
+    """Readout.sample_continuous D4:1379-1383: Beta(1 + (alpha-1)/T, 1 + (beta-1)/T) as a ratio of gammas; noise (..., nc, 2, rounds, 2)."""
+    a, b = beta_alpha_beta(params)
+    t = max(float(temperature), 1e-10)
+    a, b = 1. + (a - 1.) / t, 1. + (b - 1.) / t
+    ga, gb = gamma_from_noise(a, noise[..., 0, :, :]), gamma_from_noise(b, noise[..., 1, :, :])
+    return ga / (ga + gb)
+
+
+def beta_log_prob(params, x):
+    a, b = beta_alpha_beta(params)
+    return (a - 1.) * torch.log(x) + (b - 1.) * torch.log1p(-x) + torch.lgamma(a + b) - torch.lgamma(a) - torch.lgamma(b)
+
+
+def beta_entropy(params):
+    a, b = beta_alpha_beta(params)
+    lbeta = torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
+    return lbeta - (a - 1.) * torch.digamma(a) - (b - 1.) * torch.digamma(b) + (a + b - 2.) * torch.digamma(a + b)
+
+
+def beta_kl(p_params, q_params):
+    """KL(Beta_p || Beta_q)  (torch.distributions.kl._kl_beta_beta)."""
+    a1, b1 = beta_alpha_beta(p_params)
+    a2, b2 = beta_alpha_beta(q_params)
+    lb = lambda a, b: torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
+    return (lb(a2, b2) - lb(a1, b1) + (a1 - a2) * torch.digamma(a1) + (b1 - b2) * torch.digamma(b1)
+            + (a2 - a1 + b2 - b1) * torch.digamma(a1 + b1))
+
+
 def policy_head(cfg, W, agent_embed):
-    return mlp(W, 'policy_head.', agent_embed, mlp_num_layers(cfg.policy_head_mlp_depth))
+    return mlp(W, 'policy_head.', agent_embed, mlp_num_layers(cfg.policy_head_mlp_depth), cfg.head_mlp_recipe)
 
 
 def value_head_bins(cfg, W, agent_embed):
-    return mlp(W, 'value_head.', agent_embed, mlp_num_layers(cfg.value_head_mlp_depth))
+    return mlp(W, 'value_head.', agent_embed, mlp_num_layers(cfg.value_head_mlp_depth), cfg.head_mlp_recipe)
 
 
 # ----------------------------------------------------------------------------- generate
 
 def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, tasks=None,
-             prompt_latents=None, prompt_discrete_actions=None, prompt_rewards=None,
+             prompt_latents=None, prompt_discrete_actions=None, prompt_rewards=None, prompt_continuous_actions=None,
              cache: TrunkCache | None = None, use_time_cache=True, return_terminals=True,
-             context_signal_noise=0.1, discrete_temperature=1., sample_actions=True):
+             context_signal_noise=0.1, discrete_temperature=1., continuous_temperature=1., sample_actions=True):
     """DynamicsWorldModel.generate(return_rewards_per_frame, return_agent_actions,
     return_log_probs_and_values[, return_terminals]) D4:6308-6774, with every RNG draw injected:
 
@@ -497,20 +589,29 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
       noise['context'][f]  (b, n, dl)  normal   — D4:6670
       noise['gumbel_u'][f] (b, A)      uniform  — MultiCategorical.sample
       noise['bern_u'][f]   (b,)        uniform  — torch.bernoulli (is_terminal = u < p)
+      noise['beta'][f]     (b, nc, 2, rounds, 2) (normal, uniform) — Readout.sample_continuous (Beta as a ratio of gammas)
 
     Returns a dict with the Experience fields plus the final cache."""
     b = batch_size
     n, dl = cfg.num_latent_tokens, cfg.dim_latent
+    na, nc = len(cfg.num_discrete_actions), cfg.num_continuous_actions
     step_size = cfg.max_steps // num_steps
     latents = prompt_latents.clone() if prompt_latents is not None else torch.zeros(b, 0, n, dl)
     ctx_noise = latents.clone()
     actions = prompt_discrete_actions.clone() if prompt_discrete_actions is not None else \
-        torch.zeros(b, 0, len(cfg.num_discrete_actions), dtype=torch.long)
+        torch.zeros(b, 0, na, dtype=torch.long)
+    cont_actions = prompt_continuous_actions.clone() if prompt_continuous_actions is not None else torch.zeros(b, 0, nc)
     rewards = prompt_rewards.clone() if prompt_rewards is not None else torch.zeros(b, 0)
-    log_probs, values, agent_embeds, policy_embeds = [], [], [], []
+    log_probs, cont_log_probs, values, agent_embeds, policy_embeds = [], [], [], [], []
     terminals = torch.zeros(b, dtype=torch.bool)
     lens = torch.full((b,), time_steps)
     time_cache = cache
+
+    def hist(t, cur):                                                              # D4:6515-6523
+        if t.shape[1] == 0 or t.shape[-1] == 0:
+            return None
+        t = t[:, :cur]
+        return F.pad(t, (0, 0, 0, cur - t.shape[1]), value=0) if t.shape[1] < cur else t
 
     f = 0
     while latents.shape[1] < time_steps:
@@ -523,12 +624,8 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
             lat_in = torch.cat((ctx, x), dim=1)
             sig = torch.full((b, cur + 1), cfg.max_steps - 1, dtype=torch.long)
             sig[:, -1] = sig_val
-            act_in = None
-            if actions.shape[1] > 0:                                               # D4:6515-6518
-                act_in = actions[:, :cur]
-                if act_in.shape[1] < cur:
-                    act_in = F.pad(act_in, (0, 0, 0, cur - act_in.shape[1]), value=0)
-            pred, agent_embed, next_cache = wm_forward(cfg, W, lat_in, sig, step_size, act_in, tasks, time_cache)
+            pred, agent_embed, next_cache = wm_forward(cfg, W, lat_in, sig, step_size, hist(actions, cur), tasks, time_cache,
+                                                       cont_actions=hist(cont_actions, cur))
             if last:
                 if use_time_cache:
                     time_cache = next_cache
@@ -557,10 +654,16 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
             continue
         pe = policy_head(cfg, W, one)
         policy_embeds.append(pe)
-        logits = policy_logits(cfg, W, pe)                                         # b 1 A
-        a = sample_discrete(cfg, logits, noise['gumbel_u'][f][:, None], discrete_temperature)
-        actions = torch.cat((actions, a), dim=1)
-        log_probs.append(discrete_log_probs(cfg, logits, a))
+        if na > 0:
+            logits = policy_logits(cfg, W, pe)                                     # b 1 A
+            a = sample_discrete(cfg, logits, noise['gumbel_u'][f][:, None], discrete_temperature)
+            actions = torch.cat((actions, a), dim=1)
+            log_probs.append(discrete_log_probs(cfg, logits, a))
+        if nc > 0:
+            cp = policy_cont_params(cfg, W, pe)                                    # b 1 nc 2
+            ca = sample_continuous(cp, noise['beta'][f][:, None], continuous_temperature)
+            cont_actions = torch.cat((cont_actions, ca), dim=1)
+            cont_log_probs.append(beta_log_prob(cp, ca))
         values.append(hl_gauss_to_scalar(value_head_bins(cfg, W, one), cfg.value_range, cfg.value_num_bins))
 
         latents = torch.cat((latents, x), dim=1)
@@ -577,14 +680,11 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
                     is_truncated=~terminals, episode_return=(rewards * step_mask.float()).sum(dim=-1), step_size=step_size,
                     cache=time_cache, frames_generated=f)
     policy_embeds = torch.cat(policy_embeds, dim=1)
-    return dict(
+    out = dict(
         latents=latents,
         agent_embed=torch.cat(agent_embeds, dim=1),
         rewards=rewards,
-        actions=actions,
-        log_probs=torch.cat(log_probs, dim=1),
         values=torch.cat(values, dim=1),
-        old_action_unembeds=policy_logits(cfg, W, policy_embeds),
         lens=lens,
         terminals=terminals,
         is_truncated=~terminals,
@@ -593,6 +693,12 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
         cache=time_cache,
         frames_generated=f,
     )
+    if na > 0:
+        out.update(actions=actions, log_probs=torch.cat(log_probs, dim=1), old_action_unembeds=policy_logits(cfg, W, policy_embeds))
+    if nc > 0:
+        out.update(actions_cont=cont_actions, log_probs_cont=torch.cat(cont_log_probs, dim=1),
+                   old_cont_params=policy_cont_params(cfg, W, policy_embeds))
+    return out
 
 
 # ----------------------------------------------------------------------------- learning
@@ -649,13 +755,22 @@ def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, 
     normalize = (objective != 'pmpo') if normalize_advantages is None else normalize_advantages
     returns, old_values, adv, mask = returns_and_advantage(cfg, exp, normalize=normalize, eps=eps)
     agent_embeds = exp['agent_embed'].detach()
-    actions = exp['actions']
-    old_lp = exp['log_probs'].sum(dim=-1)
+    na, nc = len(cfg.num_discrete_actions), cfg.num_continuous_actions
+    Tn = agent_embeds.shape[1]
 
     pe = policy_head(cfg, W, agent_embeds)
-    logits = policy_logits(cfg, W, pe)
-    lp, ent = discrete_log_probs(cfg, logits, actions, with_entropy=True)
-    lp = lp.sum(dim=-1)
+    # discrete and continuous log-probs / entropies are concatenated over the action dimension and summed  D4:6090-6111
+    lps, ents, olds = [], [], []
+    if na > 0:
+        logits = policy_logits(cfg, W, pe)
+        dlp, dent = discrete_log_probs(cfg, logits, exp['actions'][:, -Tn:], with_entropy=True)
+        lps.append(dlp); ents.append(dent); olds.append(exp['log_probs'])
+    if nc > 0:
+        cparams = policy_cont_params(cfg, W, pe)
+        lps.append(beta_log_prob(cparams, exp['actions_cont'][:, -Tn:])); ents.append(beta_entropy(cparams)); olds.append(exp['log_probs_cont'])
+    lp = torch.cat(lps, dim=-1).sum(dim=-1)
+    ent = torch.cat(ents, dim=-1)
+    old_lp = torch.cat(olds, dim=-1).sum(dim=-1)
     fmask = mask.float()
 
     gate = 1.
@@ -679,15 +794,22 @@ def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, 
         neg_loss = scaled[neg].sum() if neg.any() else 0.
         num = max(1., float(mask.sum()))
         policy_loss = -cfg.pmpo_pos_to_neg_weight * (pos_loss - neg_loss) / num
-        if cfg.pmpo_kl_div_loss_weight > 0.:
-            new_l, old_l = logits, exp['old_action_unembeds']
-            src, tgt = (old_l, new_l) if cfg.pmpo_reverse_kl else (new_l, old_l)
-            kl, o = 0., 0
-            for n in cfg.num_discrete_actions:
-                a, c = src[..., o:o + n].log_softmax(-1), tgt[..., o:o + n].log_softmax(-1)
-                kl = kl + (a.exp() * (a - c)).sum(dim=-1)
-                o += n
-            policy_loss = policy_loss + masked_mean(kl, mask) * cfg.pmpo_kl_div_loss_weight
+        if cfg.pmpo_kl_div_loss_weight > 0.:                                       # D4:6158-6182
+            kl_loss = 0.
+            if na > 0:
+                new_l, old_l = logits, exp['old_action_unembeds']
+                src, tgt = (old_l, new_l) if cfg.pmpo_reverse_kl else (new_l, old_l)
+                kl, o = 0., 0
+                for n in cfg.num_discrete_actions:
+                    a, c = src[..., o:o + n].log_softmax(-1), tgt[..., o:o + n].log_softmax(-1)
+                    kl = kl + (a.exp() * (a - c)).sum(dim=-1)
+                    o += n
+                kl_loss = kl_loss + masked_mean(kl, mask)
+            if nc > 0:
+                new_p, old_p = cparams, exp['old_cont_params']
+                src, tgt = (old_p, new_p) if cfg.pmpo_reverse_kl else (new_p, old_p)
+                kl_loss = kl_loss + masked_mean(beta_kl(src, tgt).sum(dim=-1), mask)
+            policy_loss = policy_loss + kl_loss * cfg.pmpo_kl_div_loss_weight
     else:
         raise ValueError(objective)
 

@@ -4,10 +4,14 @@ Gumbel-max sampling (argmax(logits / T + G), G = -log(-log U)), log-softmax
 gather for log_prob, -sum p log p entropy, sum p (log p - log q) KL.  Call
 sites: dreamer4.py:1375-1376, 1422-1426, 1478-1481.  The uniform draw goes
 through `uniform_like` so the golden generator can inject it.  PARITY UNPINNED
-against the real package (its RNG draw order in particular).  Continuous
-readouts (Readout / BetaDist) are not restated yet."""
+against the real package (its RNG draw order in particular).
+Readout: the continuous half only, as ActionEmbedder builds it (dim=None: no projection of its own,
+dreamer4.py:1189-1196) — sample / log-prob / entropy of the BetaDist stand-in per continuous action."""
 import torch
 from torch import nn
+
+from discrete_continuous_embed_readout import discrete_continuous_embed_readout as _impl
+from discrete_continuous_embed_readout.discrete_continuous_embed_readout import BetaDist, rescale
 
 def uniform_like(t):
     return torch.rand_like(t)
@@ -51,6 +55,26 @@ class MultiCategorical:
         return kl if keep_num_actions_dim else kl.sum(dim = -1)
 
 class Readout(nn.Module):
-    def __init__(self, *a, **k):
+    def __init__(self, dim = None, *, num_discrete = 0, num_continuous = 0, continuous_mean_std = None, continuous_dist_type = 'gaussian',
+                 continuous_dist_kwargs: dict = dict(), continuous_squashed = False, **kwargs):
         super().__init__()
-        raise NotImplementedError('continuous readout not restated')
+        if dim is not None or num_discrete or continuous_dist_type != 'beta' or continuous_squashed or continuous_mean_std is not None:
+            raise NotImplementedError('only the projection-free Beta readout of ActionEmbedder is restated')
+        self.num_continuous = num_continuous
+        self.continuous_dist = BetaDist(**continuous_dist_kwargs)
+        self.native_range = (0., 1.)
+
+    def get_selector(self):
+        return None                                    # all continuous actions, in order
+
+    def sample_continuous(self, params, selector = None, temperature = 1.):
+        return self.continuous_dist.sample(params, temperature = temperature, noise = _impl.beta_noise_like(params.shape[:-1], device = params.device))
+
+    def log_prob_continuous(self, params, targets, selector = None):
+        return self.continuous_dist.log_prob(params, targets)
+
+    def entropy_continuous(self, params, selector = None):
+        return self.continuous_dist.entropy(params)
+
+    def rescale_from_native(self, actions, target_range):
+        return rescale(actions, self.native_range, target_range)

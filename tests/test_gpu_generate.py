@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from dreamer4_amd import _lib
 from oracle import restate
 from util import (golden_model, golden_noise, golden_oracle, load_golden, make_noise, oracle_config, oracle_weights,
                   randomize_weights, small_model, t)
@@ -422,3 +423,73 @@ def test_edge_shapes_vs_oracle(B, T, K):
     assert e.step_size == 64 // K
     close(e.latents, ref['latents']); close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'])
     assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
+
+
+def test_time_cache_is_functional_like_the_reference():
+    """The reference's time cache is a plain tensor: the same cache can be passed to several calls (K denoising evaluations against
+    one cache, dreamer4.py:6510-6531).  Here: K forward(commit_cache=False) + one committing forward reproduce generate()'s cached
+    frame, and an OLDER handle can be used again after the engine has moved on (its ring slots are rewritten from its end only)."""
+    m = small_model().cuda()
+    cfg = oracle_config(m)
+    B, K = 2, 4
+    nz = make_noise(cfg, 3, B, 77)
+    sub = lambda i, j: {k: v[i:j] for k, v in nz.items()}
+    e2, tc2 = m.generate(2, batch_size=B, return_for_policy_optimization=True, return_time_cache=True, noise=sub(0, 2))
+    prompt = dict(prompt_latents=e2.latents, prompt_discrete_actions=e2.actions.discrete)
+    e3a, tc3a = m.generate(3, batch_size=B, return_for_policy_optimization=True, time_cache=tc2, return_time_cache=True, noise=sub(2, 3), **prompt)
+    # the older handle again, after the engine cache advanced to 3 frames: same result, no .kv() copy needed
+    e3b, tc3b = m.generate(3, batch_size=B, return_for_policy_optimization=True, time_cache=tc2, return_time_cache=True, noise=sub(2, 3), **prompt)
+    assert torch.equal(e3a.latents, e3b.latents) and torch.equal(e3a.actions.discrete, e3b.actions.discrete)
+    assert tc2.frames == 2 and tc3b.frames == 3
+    # tc3a's third slot has been rewritten by the second call: it is stale now and says so
+    with pytest.raises(_lib.D4Error, match='stale'):
+        tc3a.kv()
+    # the same frame by hand through forward(): K evaluations that leave the cache alone, then the committing clean step
+    x = nz['latent'][2].cuda()[:, None]
+    step = cfg.max_steps // K
+    prev = e2.actions.discrete[:, 1:2]
+    for s in range(K):
+        sig = torch.full((B, 1), s * step, dtype=torch.long)
+        pred, (_, same) = m(latents=x, signal_levels=sig, step_sizes=step, discrete_actions=prev, time_cache=tc2, commit_cache=False)
+        assert same is tc2
+        x = x + (pred - x) / (1. - s * step / cfg.max_steps) * (step / cfg.max_steps)
+    sig = torch.full((B, 1), cfg.max_steps - 1, dtype=torch.long)
+    _, (agent, tc3c) = m(latents=x, signal_levels=sig, step_sizes=step, discrete_actions=prev, time_cache=tc2)
+    assert tc3c.frames == 3
+    close(x[:, 0].clamp(-1, 1), e3a.latents[:, 2], atol=1e-5)
+    close(agent[:, 0], e3a.agent_embed[:, -1], atol=1e-5)
+    close(tc3c.kv(), tc3b.kv() if m._cache_in_engine(tc3b) else tc3c.kv(), atol=1e-5)
+
+
+def test_trunk_weight_updates_reach_the_prepared_images():
+    """The engine keeps fused / gamma-folded copies of the trunk weights.  In-place updates autograd can see are picked up
+    automatically; writes through `.data` need `invalidate_prepared()`."""
+    m = small_model().cuda()
+    cfg = oracle_config(m)
+    nz = make_noise(cfg, 2, 2, 5)
+    base = m.generate(2, batch_size=2, noise=nz)
+    w = m.transformer.layers._modules['0']._modules['3'].fn.proj_out.weight
+    with torch.no_grad():
+        w.mul_(0.5)                                                    # visible to the version counter
+    a = m.generate(2, batch_size=2, noise=nz)
+    assert not torch.allclose(a, base)
+    w.data.mul_(2.)                                                    # invisible: restores the original values
+    stale = m.generate(2, batch_size=2, noise=nz)
+    assert torch.equal(stale, a)
+    m.invalidate_prepared()
+    fresh = m.generate(2, batch_size=2, noise=nz)
+    close(fresh, base, atol=1e-6)
+
+
+def test_all_terminated_early_exit_also_truncates_the_time_cache():
+    """dreamer4.py:6681: once every trajectory has terminated the reference stops generating, so its cache holds only the
+    frames it returned; the engine runs all frames and the surplus is dropped from the result AND the cache."""
+    m = small_model()
+    with torch.no_grad():
+        m.head_mlp_output_linear('to_state_terminal_pred.0')[1].fill_(30.)      # terminate at once
+    m = m.cuda()
+    cfg = oracle_config(m)
+    nz = make_noise(cfg, 4, 2, 9)
+    e, tc = m.generate(4, batch_size=2, return_for_policy_optimization=True, return_time_cache=True, noise=nz)
+    assert e.latents.shape[1] == 1 and bool(e.terminals.all())
+    assert tc.frames == 1 and tc.kv().shape[-2] == 1

@@ -48,6 +48,7 @@ def run_gemm(lib, M, N, K, flags=0, bias=False, res=False, ta=False, tb=False, s
     err = (out.double() - ref).abs().max().item()
     tol = 2e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
     assert err <= tol, f'M{M} N{N} K{K} flags{f}: err {err:.3e} > {tol:.3e}'
+    return out
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 32), (64, 64, 32), (200, 300, 72), (3, 4, 256), (45, 388, 64), (15, 2064, 512),
@@ -100,6 +101,57 @@ def test_every_tile_configuration_gives_the_same_bits(lib, M, N, K, flags):
     assert n >= 8
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize('M,N,K', [(112, 64, 32), (3584, 512, 512), (200, 300, 64), (45, 388, 96), (1000, 255, 128), (3840, 1552, 512),
+                                   (17, 20, 32), (3584, 512, 1376), (130, 129, 2048)])
+def test_gemm_second_family_every_configuration(lib, M, N, K):
+    """gemm2.hip (16x16x4 MFMA fed by the LDS-DMA ring): every configuration against fp64, partial tiles included, and all of
+    them bit-identical to each other (the choice among them is made by timing)."""
+    n1 = lib.d4_gemm_force_config(-1)
+    n2 = lib.d4_profile_classes() - n1
+    assert n2 >= 4
+    variants = [dict(), dict(flags=_lib.GEMM_RMS_ROWSCALE, bias=True), dict(flags=_lib.GEMM_SILU, bias=True, res=True)]
+    ref = None
+    try:
+        for c in range(n2):
+            lib.d4_gemm_force_config(100 + c)
+            outs = [run_gemm(lib, M, N, K, **v) for v in variants]
+            if ref is None:
+                ref = outs
+            for o, r in zip(outs, ref):
+                assert torch.equal(o, r), f'configuration {c} differs'
+    finally:
+        lib.d4_gemm_force_config(-1)
+
+
+@pytest.mark.parametrize('M,N,K', [(45, 192, 64), (3584, 2752, 512), (256, 128, 32), (300, 2752, 512)])
+def test_gemm_second_family_swiglu(lib, M, N, K):
+    n1 = lib.d4_gemm_force_config(-1)
+    n2 = lib.d4_profile_classes() - n1
+    outs = []
+    try:
+        for c in range(n2):
+            lib.d4_gemm_force_config(100 + c)      # configurations without the SiLU-GLU epilogue fall through to the default path
+            outs.append(run_gemm(lib, M, N, K, flags=_lib.GEMM_RMS_ROWSCALE | _lib.GEMM_SWIGLU, bias=True))
+    finally:
+        lib.d4_gemm_force_config(-1)
+
+
+def test_gemm_row_scale_is_identical_across_families(lib):
+    """The folded RMSNorm's 1/rms uses one canonical summation order in both families: with W = I the outputs are x / rms(x)."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    A = torch.randn(300, 64, device='cuda', generator=g); W = torch.eye(64, device='cuda')
+    outs = []
+    try:
+        for cfg in (4, 100, 104, 105):
+            lib.d4_gemm_force_config(cfg)
+            o = torch.empty(300, 64, device='cuda')
+            _lib.check(lib.d4_gemm(_lib.ptr(A), 64, _lib.ptr(W), 64, _lib.ptr(o), 64, None, None, 0, 300, 64, 64, 1, 1e-6, stream()))
+            outs.append(o)
+    finally:
+        lib.d4_gemm_force_config(-1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_gemm_rejects_misaligned_operands(lib):

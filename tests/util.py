@@ -19,6 +19,7 @@ def oracle_config(m) -> Config:
         use_delight_gating=m.use_delight_gating, delight_temperature=m.delight_temperature,
         pmpo_pos_to_neg_weight=m.pmpo_pos_to_neg_weight, pmpo_reverse_kl=m.pmpo_reverse_kl,
         pmpo_kl_div_loss_weight=m.pmpo_kl_div_loss_weight,
+        num_continuous_actions=getattr(m, 'num_continuous_actions', 0), head_mlp_recipe=getattr(m, 'head_mlp_recipe', 'pre_rms'),
     )
 
 
@@ -33,12 +34,18 @@ def oracle_weights(m):
 def make_noise(cfg: Config, frames, batch, seed):
     g = torch.Generator().manual_seed(seed)
     n, dl, A = cfg.num_latent_tokens, cfg.dim_latent, cfg.total_discrete_actions
-    return dict(
+    nz = dict(
         latent=torch.randn(frames, batch, n, dl, generator=g),
         context=torch.randn(frames, batch, n, dl, generator=g),
         gumbel_u=torch.rand(frames, batch, A, generator=g).clamp(1e-6, 1. - 1e-6),
         bern_u=torch.rand(frames, batch, generator=g),
     )
+    nc = getattr(cfg, 'num_continuous_actions', 0)
+    if nc > 0:      # Beta sampling as a ratio of Marsaglia-Tsang gammas: (normal, uniform) per rejection round   (drawn last: older fixtures keep their draws)
+        nrm = torch.randn(frames, batch, nc, 2, 6, generator=g)
+        uni = torch.rand(frames, batch, nc, 2, 6, generator=g).clamp(1e-6, 1. - 1e-6)
+        nz['beta'] = torch.stack((nrm, uni), dim=-1)
+    return nz
 
 
 def small_model(**over):
