@@ -23,7 +23,7 @@ class Config(C.Structure):
         ('attn_softclamp_value', C.c_float),
         ('num_spatial_tokens', C.c_int32), ('num_register_tokens', C.c_int32), ('max_steps', C.c_int32),
         ('num_tasks', C.c_int32), ('num_discrete_action_types', C.c_int32),
-        ('num_discrete_actions', C.c_int32 * D4_MAX_ACTION_TYPES),
+        ('num_discrete_actions', C.c_int32 * D4_MAX_ACTION_TYPES), ('num_continuous_actions', C.c_int32),
         ('multi_token_pred_len', C.c_int32),
         ('policy_head_mlp_depth', C.c_int32), ('value_head_mlp_depth', C.c_int32),
         ('terminal_mlp_depth', C.c_int32), ('predict_terminals', C.c_int32),
@@ -44,11 +44,12 @@ class RolloutIO(C.Structure):
     _fields_ = [
         ('batch', C.c_int32), ('time_steps', C.c_int32), ('prompt_frames', C.c_int32), ('num_steps', C.c_int32),
         ('use_time_cache', C.c_int32), ('sample_terminals', C.c_int32), ('sample_actions', C.c_int32),
-        ('context_signal_noise', C.c_float), ('discrete_temperature', C.c_float),
+        ('context_signal_noise', C.c_float), ('discrete_temperature', C.c_float), ('continuous_temperature', C.c_float),
         ('noise_latent', C.c_void_p), ('noise_context', C.c_void_p), ('gumbel_u', C.c_void_p), ('bern_u', C.c_void_p),
-        ('tasks', C.c_void_p),
-        ('latents', C.c_void_p), ('actions', C.c_void_p), ('rewards', C.c_void_p), ('ctx_hist', C.c_void_p),
-        ('agent_embed', C.c_void_p), ('log_probs', C.c_void_p), ('values', C.c_void_p), ('action_logits', C.c_void_p),
+        ('beta_noise', C.c_void_p), ('tasks', C.c_void_p),
+        ('latents', C.c_void_p), ('actions', C.c_void_p), ('actions_cont', C.c_void_p), ('rewards', C.c_void_p), ('ctx_hist', C.c_void_p),
+        ('agent_embed', C.c_void_p), ('log_probs', C.c_void_p), ('log_probs_cont', C.c_void_p), ('cont_params', C.c_void_p),
+        ('values', C.c_void_p), ('action_logits', C.c_void_p),
         ('lens', C.c_void_p), ('terminals', C.c_void_p),
     ]
 
@@ -60,7 +61,8 @@ class LearnIO(C.Structure):
     _fields_ = [
         ('batch', C.c_int32), ('time', C.c_int32), ('objective', C.c_int32), ('normalize_advantages', C.c_int32),
         ('eps', C.c_float), ('use_delight_gating', C.c_int32), ('delight_temperature', C.c_float),
-        ('agent_embed', C.c_void_p), ('actions', C.c_void_p), ('old_log_probs', C.c_void_p), ('old_values', C.c_void_p),
+        ('agent_embed', C.c_void_p), ('actions', C.c_void_p), ('old_log_probs', C.c_void_p),
+        ('actions_cont', C.c_void_p), ('old_log_probs_cont', C.c_void_p), ('old_cont_params', C.c_void_p), ('old_values', C.c_void_p),
         ('rewards', C.c_void_p), ('old_action_logits', C.c_void_p), ('lens', C.c_void_p), ('is_truncated', C.c_void_p),
         ('terminals', C.c_void_p),
         ('allreduce_sum', ALLREDUCE_FN), ('allreduce_user', C.c_void_p),
@@ -83,7 +85,7 @@ SYMBOLS = {
     'd4_engine_cache_reset': (_I, [_P, _I]),
     'd4_engine_cache_export': (_I, [_P, _P, _I, _P]),
     'd4_engine_cache_import': (_I, [_P, _P, _I, _I, _P]),
-    'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),
     'd4_learn': (_I, [_P, C.POINTER(LearnIO), _P]),
     'd4_adamw_clip': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),

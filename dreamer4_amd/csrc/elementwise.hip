@@ -4,6 +4,7 @@
 // (float4 where the layout allows), grid-stride.
 #include "common.h"
 #include "kernels.h"
+#include "beta.h"
 #include <float.h>
 
 namespace d4 {
@@ -205,11 +206,14 @@ __global__ void assemble_kernel(AssembleArgs p) {
             v = p.space[(f * p.ns + (s - 1)) * D + d];
         } else if (s <= p.ns + p.nr) {
             v = p.registers[(int64_t)(s - 1 - p.ns) * D + d];
-        } else if (p.na > 0 && s == p.ns + p.nr + 1) {        // (a model without an action space has no action token, D4:7124-7130)
+        } else if ((p.na > 0 || p.nc > 0) && s == p.ns + p.nr + 1) {        // (a model without an action space has no action token, D4:7124-7130)
             v = 0.f;
-            if (p.prev_actions && p.prev_actions[f * p.na] >= 0) {
+            const bool have = p.na > 0 ? (p.prev_actions && p.prev_actions[f * p.na] >= 0) : (p.prev_cont && p.prev_cont[f * p.nc] == p.prev_cont[f * p.nc]);
+            if (have) {
                 for (int a = 0; a < p.na; ++a)
                     v += p.action_embed[(p.prev_actions[f * p.na + a] + p.action_offsets[a]) * D + d];
+                if (p.prev_cont)                                  // embed[type] * value, summed over the types  D4:1535-1545
+                    for (int c = 0; c < p.nc; ++c) v += p.cont_embed[(int64_t)c * D + d] * p.prev_cont[f * p.nc + c];
                 v += p.action_learned[d];
             }
         } else {
@@ -303,7 +307,7 @@ int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int
 
 // per-evaluation integer inputs: signal level of every frame and the action token source   D4:6492-6523
 __global__ void prep_inputs_kernel(int32_t* sig, int64_t* pact, const int64_t* hist, int B, int Tq, int na, int frame_base,
-                                   int hist_stride, int sig_val, int ctx_sig) {
+                                   int hist_stride, int sig_val, int ctx_sig, float* pcont, const float* chist, int nc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * Tq) return;
     const int b = i / Tq, t = i % Tq;
@@ -311,11 +315,13 @@ __global__ void prep_inputs_kernel(int32_t* sig, int64_t* pact, const int64_t* h
     const int g = frame_base + t;
     for (int a = 0; a < na; ++a)
         pact[(int64_t)i * na + a] = (g == 0 || !hist) ? -1 : hist[((int64_t)b * hist_stride + (g - 1)) * na + a];
+    for (int c = 0; c < nc; ++c)
+        pcont[(int64_t)i * nc + c] = (g == 0 || !chist) ? __builtin_nanf("") : chist[((int64_t)b * hist_stride + (g - 1)) * nc + c];
 }
 int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
-                     int hist_stride, int sig_val, int ctx_sig, hipStream_t s) {
+                     int hist_stride, int sig_val, int ctx_sig, hipStream_t s, float* pcont, const float* cont_hist, int nc) {
     hipLaunchKernelGGL(prep_inputs_kernel, dim3(cdiv(B * Tq, 128)), dim3(128), 0, s, sig, pact, actions_hist, B, Tq, na, frame_base,
-                       hist_stride, sig_val, ctx_sig);
+                       hist_stride, sig_val, ctx_sig, pcont, cont_hist, pcont ? nc : 0);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -433,6 +439,36 @@ int mean_tokens(const float* x, float* out, int B, int n, int d, hipStream_t s) 
     return 0;
 }
 
+// continuous_action_unembed [nc][mtp][d][2] (D4:1244): prediction head 0 as a K-contiguous GEMM weight [2 nc][d] (row 2 n + t), and back
+__global__ void cunembed_gather_kernel(const float* U, float* w, int nc, int mtp, int d) {
+    const int64_t n = (int64_t)2 * nc * d;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % d), row = (int)(i / d);
+        w[i] = U[(((int64_t)(row >> 1) * mtp) * d + k) * 2 + (row & 1)];
+    }
+}
+__global__ void cunembed_scatter_kernel(const float* g, float* dU, int nc, int mtp, int d) {
+    const int64_t n = (int64_t)nc * mtp * d * 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i & 1);
+        const int64_t r = i >> 1;
+        const int k = (int)(r % d), h = (int)((r / d) % mtp), c = (int)(r / ((int64_t)d * mtp));
+        dU[i] = h == 0 ? g[((int64_t)(2 * c + t)) * d + k] : 0.f;        // only prediction head 0 is read (pred_head_index = 0)
+    }
+}
+int cunembed_gather(const float* U, float* w, int nc, int mtp, int d, hipStream_t s) {
+    if (nc == 0) return 0;
+    hipLaunchKernelGGL(cunembed_gather_kernel, grid1d((int64_t)2 * nc * d), dim3(256), 0, s, U, w, nc, mtp, d);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+int cunembed_scatter_grad(const float* g, float* dU, int nc, int mtp, int d, hipStream_t s) {
+    if (nc == 0) return 0;
+    hipLaunchKernelGGL(cunembed_scatter_kernel, grid1d((int64_t)nc * mtp * d * 2), dim3(256), 0, s, g, dU, nc, mtp, d);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 __device__ __forceinline__ float log_eps(float t) { return logf(fmaxf(t, 1e-20f)); }
 
 // Gumbel-max sampling per action type + log-prob of the sample (D4:485-497, 1374-1376, 1422-1423);
@@ -440,8 +476,8 @@ __device__ __forceinline__ float log_eps(float t) { return logf(fmaxf(t, 1e-20f)
 __global__ void sample_kernel(SampleArgs p) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= p.B) return;
-    const float* lg = p.logits + (int64_t)b * p.ld;
-    const float* u = p.gumbel_u + (int64_t)b * p.ld_u;
+    const float* lg = p.na > 0 ? p.logits + (int64_t)b * p.ld : nullptr;
+    const float* u = p.na > 0 ? p.gumbel_u + (int64_t)b * p.ld_u : nullptr;
     const float temp = fmaxf(p.temperature, 1e-10f);
     int o = 0;
     for (int a = 0; a < p.na; ++a) {
@@ -460,6 +496,14 @@ __global__ void sample_kernel(SampleArgs p) {
         p.actions[(int64_t)b * p.act_stride + a] = arg;
         p.log_probs[(int64_t)b * p.lp_stride + a] = (lg[o + arg] - mx) - logf(se);
         o += n;
+    }
+    // continuous actions: Beta(alpha, beta) sample (tempered) from injected gamma noise + log-prob under the untempered head
+    for (int c = 0; c < p.nc; ++c) {
+        const float* raw = p.cont_params + (int64_t)b * p.ld_c + 2 * c;
+        const BetaAB ab = beta_ab(raw[0], raw[1]);
+        const float x = beta_sample(ab.a, ab.b, p.cont_temperature, p.beta_noise + ((int64_t)b * p.nc + c) * (4 * BETA_ROUNDS));
+        p.actions_cont[(int64_t)b * p.actc_stride + c] = x;
+        p.log_probs_cont[(int64_t)b * p.lpc_stride + c] = beta_log_prob(ab.a, ab.b, x);
     }
     if (p.term_logit) {
         const float pr = sigmoidf(p.term_logit[b]);

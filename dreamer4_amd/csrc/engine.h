@@ -53,7 +53,7 @@ struct d4_engine {
     std::unordered_map<std::string, d4::Bound> bound;
 
     // derived sizes
-    int S, hd, hp, php, D, Nproj, Nproj0, inner, inner_pad, Lt, A, na, ldpq, ldcq, nslab;
+    int S, hd, hp, php, D, Nproj, Nproj0, inner, inner_pad, Lt, A, na, nc, ldpq, ldcq, nslab;
     std::vector<int> is_time, time_index;
     int maxB, maxTq, Tcap, Mmax, Fr;
 
@@ -79,6 +79,7 @@ struct d4_engine {
     const float *lin_w = nullptr, *lin_b = nullptr;      // num_spatial_tokens == num_latent_tokens: Linear(dim_latent -> dim)
     const float *registers, *signal_embed, *step_embed, *agent_learned, *action_learned, *task_embed, *action_embed;
     const float *action_unembed; float* action_unembed_grad;
+    const float *cont_embed = nullptr, *cont_unembed = nullptr; float* cont_unembed_grad = nullptr;      // continuous actions (Beta head)
     const float *reward_norm, *reward_w, *reward_centers, *value_centers, *value_support;
     d4::Mlp policy, value, terminal;
 
@@ -97,6 +98,7 @@ struct d4_engine {
     float *lat_in, *lkv, *latt, *space, *gs, *okv, *oatt, *oproj, *pred, *x_lat;
     int32_t* sig;
     int64_t* pact;
+    float *pcont, *cu_w, *cparams;          // previous continuous actions per frame, head-0 unembed as a GEMM weight [2 nc][4 D], raw Beta parameters
     int* fstate;                           // device frame state {t0} read by the time-attention kernels under graph replay
     int64_t* tasks_dev;                    // engine-owned copy of the task ids (stable address for captured graphs)
     float* cache;
@@ -106,6 +108,7 @@ struct d4_engine {
     int LR = 0;
     float *l_save;                         // per-layer saved activations for both MLP heads
     float *l_tmp[4];
+    float *l_cparams, *l_dcparams, *l_cu_g;
     float *l_logits, *l_dlogits, *l_vbins, *l_dvbins, *l_returns, *l_adv, *l_scal, *l_mask, *l_rows, *l_dpe;
 };
 

@@ -94,6 +94,9 @@ int engine_layout(d4_engine* e, bool assign) {
     e->x_lat = fl((size_t)e->maxB * n * dl);
     e->sig = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * Fr));
     e->pact = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * Fr * (e->na > 0 ? e->na : 1)));
+    e->pcont = fl(Fr * (size_t)(e->nc > 0 ? e->nc : 1));
+    e->cu_w = fl((size_t)2 * (e->nc > 0 ? e->nc : 1) * 4 * D);
+    e->cparams = fl((size_t)e->maxB * (2 * e->nc + 4));
     e->fstate = reinterpret_cast<int*>(alloc_bytes(sizeof(int) * 16));
     e->tasks_dev = reinterpret_cast<int64_t*>(alloc_bytes(sizeof(int64_t) * e->maxB));
     e->cache = fl((size_t)(e->Lt > 0 ? e->Lt : 1) * 2 * e->maxB * S * c.attn_heads * e->Tcap * c.attn_dim_head);
@@ -117,6 +120,7 @@ int engine_layout(d4_engine* e, bool assign) {
         // saved per layer: x (input), xhat (normalised * gamma input of the linear), z (pre-activation)
         e->l_save = fl(e->policy.save_floats(R) + e->value.save_floats(R));
         for (int i = 0; i < 4; ++i) e->l_tmp[i] = fl(R * maxdim);
+        e->l_cparams = fl(R * (size_t)(2 * e->nc + 4)); e->l_dcparams = fl(R * (size_t)(2 * e->nc + 4)); e->l_cu_g = fl((size_t)(2 * e->nc + 4) * 4 * D);
         e->l_logits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
         e->l_dlogits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
         e->l_vbins = fl(R * (size_t)((c.value_num_bins + 3) / 4 * 4));
@@ -254,6 +258,10 @@ int engine_resolve(d4_engine* e) {
     e->action_embed = e->A > 0 ? r.get("action_embedder.discrete_action_embed.weight", (int64_t)e->A * D) : nullptr;
     e->action_unembed = e->A > 0 ? r.get("action_embedder.discrete_action_unembed",
                                          (int64_t)e->A * c.multi_token_pred_len * 4 * D, &e->action_unembed_grad) : nullptr;
+    if (e->nc > 0) {
+        e->cont_embed = r.get("action_embedder.continuous_action_embed.weight", (int64_t)e->nc * D);
+        e->cont_unembed = r.get("action_embedder.continuous_action_unembed", (int64_t)e->nc * c.multi_token_pred_len * 4 * D * 2, &e->cont_unembed_grad);
+    }
     e->reward_norm = r.get("to_reward_pred.params.0", (int64_t)c.multi_token_pred_len * D);
     e->reward_w = r.get("to_reward_pred.params.1", (int64_t)c.multi_token_pred_len * c.reward_num_bins * D);
     e->reward_centers = r.get("reward_encoder.centers", c.reward_num_bins);
@@ -457,6 +465,7 @@ int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, in
         a.registers = e->registers; a.agent_embed = e->agent_learned; a.task_embed = e->task_embed;
         a.action_embed = e->action_embed; a.action_learned = e->action_learned;
         a.signal_levels = e->sig; a.prev_actions = e->na > 0 ? e->pact : nullptr; a.tasks = tasks;
+        a.prev_cont = e->nc > 0 ? e->pcont : nullptr; a.cont_embed = e->cont_embed; a.nc = e->nc;
         a.action_offsets = e->action_offsets;
         a.B = B; a.Tq = Tq; a.S = S; a.D = D; a.ns = ns; a.nr = c.num_register_tokens; a.na = e->na; a.step_log2 = step_log2;
         a.compact = e->cslabs; a.has_agent = has_agent;
@@ -646,7 +655,7 @@ int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, f
 extern "C" {
 
 const char* d4_last_error(void) { return d4::last_error(); }
-int d4_version(void) { return 1; }
+int d4_version(void) { return 2; }
 
 int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     D4_REQUIRE(cfg && out, "null argument");
@@ -663,7 +672,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     d4_engine* e = new d4_engine();
     e->c = c;
     e->D = c.dim;
-    e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + (c.num_discrete_action_types > 0 ? 1 : 0) + 1;   // no action token without an action space
+    e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + ((c.num_discrete_action_types > 0 || c.num_continuous_actions > 0) ? 1 : 0) + 1;   // no action token without an action space
     D4_REQUIRE(e->S <= 64 && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
     e->hd = c.attn_heads * c.attn_dim_head;
     e->php = c.pool_heads;
@@ -678,6 +687,8 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->ldcq = (e->hd + c.attn_heads + 3) / 4 * 4;
     e->nslab = 2 * c.depth + 1;
     e->na = c.num_discrete_action_types;
+    e->nc = c.num_continuous_actions;
+    D4_REQUIRE(e->nc >= 0 && e->nc <= 64, "num_continuous_actions out of range");
     e->A = 0;
     for (int a = 0; a < e->na; ++a) e->A += c.num_discrete_actions[a];
     e->is_time.assign(c.depth, 0);
@@ -778,7 +789,7 @@ static int check_step_log2(const d4_engine* e, int sl) {
 }
 
 int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_levels, int step_size,
-                  const int64_t* prev_actions, const int64_t* tasks, int batch, int frames,
+                  const int64_t* prev_actions, const float* prev_cont, const int64_t* tasks, int batch, int frames,
                   int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream) {
     D4_REQUIRE(e && latents && signal_levels, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -791,6 +802,11 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
     if (e->na > 0) {
         if (prev_actions) D4_HIP(hipMemcpyAsync(e->pact, prev_actions, sizeof(int64_t) * Fr * e->na, hipMemcpyDeviceToDevice, s));
         else D4_HIP(hipMemsetAsync(e->pact, 0xFF, sizeof(int64_t) * Fr * e->na, s));     // -1 => zero token
+    }
+    if (e->nc > 0) {
+        if (prev_cont) D4_HIP(hipMemcpyAsync(e->pcont, prev_cont, sizeof(float) * Fr * e->nc, hipMemcpyDeviceToDevice, s));
+        else if (e->na > 0) D4_HIP(hipMemsetAsync(e->pcont, 0, sizeof(float) * Fr * e->nc, s));      // validity comes from the discrete side
+        else D4_HIP(hipMemsetAsync(e->pcont, 0xFF, sizeof(float) * Fr * e->nc, s));                    // NaN => zero token
     }
     const int t0 = use_cache ? e->cache_frames : 0;
     if ((rc = d4::engine_forward(e, latents, batch, frames, t0, sl, tasks, true, s))) return rc;
@@ -810,8 +826,10 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
     D4_REQUIRE(K >= 1 && (K & (K - 1)) == 0 && K <= c.max_steps, "number of steps %d must be a power of 2 in (0, %d]  [D4:6357-6358]", K, c.max_steps);
     D4_REQUIRE(P >= 0 && P <= T, "bad prompt_frames");
-    D4_REQUIRE(!io->sample_actions || e->na > 0, "the model has no actions to sample  [D4:6626]");
-    D4_REQUIRE(!io->sample_actions || (io->actions && io->gumbel_u && io->log_probs && io->values && io->action_logits), "sample_actions needs the action outputs and gumbel_u");
+    D4_REQUIRE(!io->sample_actions || e->na > 0 || e->nc > 0, "the model has no actions to sample  [D4:6626]");
+    D4_REQUIRE(!io->sample_actions || e->na == 0 || (io->actions && io->gumbel_u && io->log_probs && io->action_logits), "sample_actions needs the action outputs and gumbel_u");
+    D4_REQUIRE(!io->sample_actions || e->nc == 0 || (io->actions_cont && io->beta_noise && io->log_probs_cont && io->cont_params), "sample_actions needs the continuous action outputs and beta_noise");
+    D4_REQUIRE(!io->sample_actions || io->values, "sample_actions needs the values output");
     D4_REQUIRE(!io->sample_terminals || (c.predict_terminals && io->bern_u), "sample_terminals needs predict_terminals and bern_u");
     D4_REQUIRE(io->use_time_cache || io->noise_context || T - P <= 1, "noise_context is required without the time cache");
     const int F = T - P;
@@ -820,7 +838,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     if ((rc = step_log2_of(step_size, &sl))) return rc;
     if ((rc = check_step_log2(e, sl))) return rc;
     const int n_el = c.num_latent_tokens * c.dim_latent;
-    const int D = e->D, S = e->S, A = e->A, na = e->na;
+    const int D = e->D, S = e->S, A = e->A, na = e->na, nc = e->nc;
     if (!io->use_time_cache) e->cache_frames = 0;
 
     for (int f = 0; f < F; ++f) {
@@ -839,7 +857,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
         if (graphable) {
             D4_REQUIRE(t0 + 1 <= e->Tcap || e->Lt == 0, "KV cache capacity %d exceeded (%d + 1 frames)", e->Tcap, t0);
             if ((rc = d4::set_frame_state(e->fstate, t0, s))) return rc;
-            if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, 1, na, cur, T, 0, c.max_steps - 1, s))) return rc;
+            if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, 1, na, cur, T, 0, c.max_steps - 1, s, nc > 0 ? e->pcont : nullptr, io->actions_cont, nc))) return rc;
             const int64_t* tasks = nullptr;
             if (io->tasks) {
                 D4_HIP(hipMemcpyAsync(e->tasks_dev, io->tasks, sizeof(int64_t) * B, hipMemcpyDeviceToDevice, s));
@@ -898,7 +916,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                 if ((rc = d4::build_latent_input(e->lat_in, io->latents, io->ctx_hist, e->x_lat, B, Tq, n_el, T, io->context_signal_noise, s))) return rc;
                 lat = e->lat_in;
             }
-            if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, Tq, na, cur + 1 - Tq, T, sig_val, c.max_steps - 1, s))) return rc;
+            if ((rc = d4::prep_eval_inputs(e->sig, e->pact, io->actions, B, Tq, na, cur + 1 - Tq, T, sig_val, c.max_steps - 1, s, nc > 0 ? e->pcont : nullptr, io->actions_cont, nc))) return rc;
             if ((rc = d4::engine_forward(e, lat, B, Tq, t0, sl, io->tasks, last, s))) return rc;
             if (last) { if (commit) e->cache_frames = t0 + Tq; break; }
             const float tt = (float)sig_val / (float)c.max_steps;
@@ -926,8 +944,15 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
             // policy embed -> logits of prediction head 0                            D4:6628-6643
             float* pe = e->hbuf[(e->policy.nl - 1) & 1];   // the buffer mlp_forward's last hidden does not occupy
             if ((rc = d4::mlp_forward(e, e->policy, e->agent_c, D, B, pe, 4 * D, nullptr, s))) return rc;
-            float* logits = io->action_logits + (size_t)f * A;
-            if ((rc = d4::gemm_simple(pe, 4 * D, e->action_unembed, c.multi_token_pred_len * 4 * D, logits, F * A, B, A, 4 * D, 0, nullptr, nullptr, 0, s))) return rc;
+            float* logits = na > 0 ? io->action_logits + (size_t)f * A : nullptr;
+            if (na > 0 && (rc = d4::gemm_simple(pe, 4 * D, e->action_unembed, c.multi_token_pred_len * 4 * D, logits, F * A, B, A, 4 * D, 0, nullptr, nullptr, 0, s))) return rc;
+            float* cparams = nc > 0 ? io->cont_params + (size_t)f * nc * 2 : nullptr;
+            if (nc > 0) {
+                // raw Beta parameters of prediction head 0: the [nc][mtp][4D][2] parameter is read through a K-contiguous copy of
+                // its head-0 slice (a trained head changes every optimiser step, so the copy is refreshed per frame: 2 nc x 4D floats)
+                if ((rc = d4::cunembed_gather(e->cont_unembed, e->cu_w, nc, c.multi_token_pred_len, 4 * D, s))) return rc;
+                if ((rc = d4::gemm_simple(pe, 4 * D, e->cu_w, 4 * D, cparams, F * nc * 2, B, 2 * nc, 4 * D, 0, nullptr, nullptr, 0, s))) return rc;
+            }
             // value                                                                    D4:6659-6662
             float* vb = e->hbuf[(e->value.nl - 1) & 1];
             if ((rc = d4::mlp_forward(e, e->value, e->agent_c, D, B, vb, c.value_num_bins, nullptr, s))) return rc;
@@ -935,12 +960,19 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
             // sample action, log-prob, terminal                                        D4:6611-6616, 6637-6657
             d4::SampleArgs sa{};
             sa.logits = logits; sa.ld = F * A;
-            sa.gumbel_u = io->gumbel_u + (size_t)f * B * A; sa.ld_u = A;
+            sa.gumbel_u = na > 0 ? io->gumbel_u + (size_t)f * B * A : nullptr; sa.ld_u = A;
             sa.term_logit = term_logit; sa.bern_u = io->sample_terminals ? io->bern_u + (size_t)f * B : nullptr;
-            sa.actions = io->actions + (size_t)cur * na; sa.act_stride = T * na;
-            sa.log_probs = io->log_probs + (size_t)f * na; sa.lp_stride = F * na;
+            sa.actions = na > 0 ? io->actions + (size_t)cur * na : nullptr; sa.act_stride = T * na;
+            sa.log_probs = na > 0 ? io->log_probs + (size_t)f * na : nullptr; sa.lp_stride = F * na;
             sa.terminals = io->terminals; sa.lens = io->lens; sa.action_sizes = e->action_sizes;
             sa.B = B; sa.na = na; sa.frame_index = cur; sa.temperature = io->discrete_temperature;
+            if (nc > 0) {
+                sa.nc = nc; sa.cont_params = cparams; sa.ld_c = F * nc * 2;
+                sa.beta_noise = io->beta_noise + (size_t)f * B * nc * 4 * 6;
+                sa.actions_cont = io->actions_cont + (size_t)cur * nc; sa.actc_stride = T * nc;
+                sa.log_probs_cont = io->log_probs_cont + (size_t)f * nc; sa.lpc_stride = F * nc;
+                sa.cont_temperature = io->continuous_temperature;
+            }
             if ((rc = d4::sample_actions_terminals(sa, s))) return rc;
         } else if (term_logit) {
             d4::SampleArgs sa{};

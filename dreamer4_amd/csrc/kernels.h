@@ -131,9 +131,11 @@ struct AssembleArgs {
     const float* action_learned;   // [D]
     const int32_t* signal_levels;  // [B*Tq]
     const int64_t* prev_actions;   // [B*Tq][na] (-1 in slot 0 => zero token) or null (=> zero token)
+    const float* prev_cont;        // [B*Tq][nc] continuous actions (NaN in slot 0 => zero token when na == 0) or null
+    const float* cont_embed;       // [nc][D]  action_embedder.continuous_action_embed.weight
     const int64_t* tasks;          // [B] or null
     const int32_t* action_offsets; // [na] (device)
-    int B, Tq, S, D, ns, nr, na, step_log2;
+    int B, Tq, S, D, ns, nr, na, nc, step_log2;
     float* compact;                // optional [B*Tq][ns (+ 1)][D]: spatial (+ agent) rows only
     int has_agent;                 // 0: the frame is packed without its trailing agent token (S = tokens actually present)
 };
@@ -149,7 +151,7 @@ int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
 // y[m][n] = act(sum_s part[s][m][n] + bias[n])   (split-K combine, fixed order)
 int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy, hipStream_t s);
 int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
-                     int hist_stride, int sig_val, int ctx_sig, hipStream_t s);
+                     int hist_stride, int sig_val, int ctx_sig, hipStream_t s, float* pcont = nullptr, const float* cont_hist = nullptr, int nc = 0);
 int fill_sig(int32_t* sig, int n, int value, hipStream_t s);
 int set_frame_state(int* state, int t0, hipStream_t s);
 int cache_transfer(float* cache, float* ext, int Lt, int cache_batch, int B, int S, int H, int Tcap, int frames, int to_ext, int dh, hipStream_t s);
@@ -173,7 +175,16 @@ struct SampleArgs {
     const int32_t* action_sizes;            // [na] device
     int B, na, frame_index;
     float temperature;
+    // continuous actions (Beta head): raw parameters [B][nc][2] at stride ld_c, injected gamma noise [B][nc][2][6][2]
+    const float* cont_params = nullptr; int ld_c = 0;
+    const float* beta_noise = nullptr;
+    float* actions_cont = nullptr; int actc_stride = 0;     // out [B][nc]
+    float* log_probs_cont = nullptr; int lpc_stride = 0;    // out [B][nc]
+    int nc = 0;
+    float cont_temperature = 1.f;
 };
 int sample_actions_terminals(const SampleArgs& p, hipStream_t s);
+int cunembed_gather(const float* U, float* w, int nc, int mtp, int d, hipStream_t s);
+int cunembed_scatter_grad(const float* g, float* dU, int nc, int mtp, int d, hipStream_t s);
 
 }  // namespace d4

@@ -13,6 +13,7 @@
 // Every reduction has a fixed order: results are bitwise reproducible run to run.
 #include "common.h"
 #include "engine.h"
+#include "beta.h"
 #include <float.h>
 #include <math.h>
 
@@ -119,6 +120,11 @@ struct PolicyLossArgs {
     const int32_t* action_sizes;
     float* dlogits;                     // [R][Apad]
     float* row_pl; float* row_ent; float* row_aux;   // per-row masked terms
+    // continuous actions (Beta head): raw parameters [R][ldc] (2 per action), targets, old log-probs, old parameters (pmpo KL)
+    const float* cparams; int ldc;
+    const float* actions_cont; const float* old_lp_cont; const float* old_cparams;
+    float* dcparams;                    // [R][ldc]
+    int nc;
     int R, na, A, objective, normalize, use_gate, reverse_kl;
     float eps, clip, ent_w, gate_temp, pmpo_alpha, kl_w;
 };
@@ -153,6 +159,14 @@ __global__ void policy_loss_kernel(PolicyLossArgs p) {
         for (int j = 0; j < n; ++j) { const float l = lg[o + j] - lse; h -= expf(l) * l; }
         ent += h;
         o += n;
+    }
+    // continuous actions: log-prob of the stored action and entropy of each Beta join the same sums  D4:6090-6111
+    for (int c = 0; c < p.nc; ++c) {
+        const float* raw = p.cparams + (int64_t)r * p.ldc + 2 * c;
+        const BetaAB ab = beta_ab(raw[0], raw[1]);
+        lp += beta_log_prob(ab.a, ab.b, p.actions_cont[(int64_t)r * p.nc + c]);
+        old += p.old_lp_cont[(int64_t)r * p.nc + c];
+        ent += lbetaf(ab.a, ab.b) - (ab.a - 1.f) * digammaf(ab.a) - (ab.b - 1.f) * digammaf(ab.b) + (ab.a + ab.b - 2.f) * digammaf(ab.a + ab.b);
     }
     const float gate = p.use_gate ? sigmoidf(-lp * adv / p.gate_temp) : 1.f;
     float pl = 0.f, dpl_dlp = 0.f, aux = 0.f;
@@ -216,6 +230,43 @@ __global__ void policy_loss_kernel(PolicyLossArgs p) {
         o += n;
     }
     for (int j = p.A; j < p.ld; ++j) dl[j] = 0.f;
+    // gradients wrt the raw Beta parameters: d lp, d(-H) and (pmpo) the KL against the behaviour parameters
+    for (int c = 0; c < p.nc; ++c) {
+        const float* raw = p.cparams + (int64_t)r * p.ldc + 2 * c;
+        const BetaAB ab = beta_ab(raw[0], raw[1]);
+        const float a = ab.a, b = ab.b, x = p.actions_cont[(int64_t)r * p.nc + c];
+        const float psi_a = digammaf(a), psi_b = digammaf(b), psi_ab = digammaf(a + b);
+        const float tri_ab = trigammaf(a + b);
+        float ga = dpl_dlp * (logf(x) - psi_a + psi_ab);                              // d lp / d alpha
+        float gb = dpl_dlp * (log1pf(-x) - psi_b + psi_ab);
+        // H = lbeta - (a-1) psi(a) - (b-1) psi(b) + (a+b-2) psi(a+b);  dH/da = -(a-1) psi'(a) + (a+b-2) psi'(a+b)
+        ga += p.ent_w * ((a - 1.f) * trigammaf(a) - (a + b - 2.f) * tri_ab);          // d(-H) / d alpha
+        gb += p.ent_w * ((b - 1.f) * trigammaf(b) - (a + b - 2.f) * tri_ab);
+        if (p.objective == 2 && p.kl_w > 0.f && p.old_cparams) {
+            const float* oraw = p.old_cparams + ((int64_t)r * p.nc + c) * 2;
+            const BetaAB ob = beta_ab(oraw[0], oraw[1]);
+            const float a2 = ob.a, b2 = ob.b;
+            float kl, ka, kb;
+            if (p.reverse_kl) {
+                // KL(old || new): lbeta(a,b) - lbeta(a2,b2) + (a2-a) psi(a2) + (b2-b) psi(b2) + (a-a2+b-b2) psi(a2+b2)
+                const float q_a = digammaf(a2), q_b = digammaf(b2), q_ab = digammaf(a2 + b2);
+                kl = lbetaf(a, b) - lbetaf(a2, b2) + (a2 - a) * q_a + (b2 - b) * q_b + (a - a2 + b - b2) * q_ab;
+                ka = (psi_a - psi_ab) - q_a + q_ab;
+                kb = (psi_b - psi_ab) - q_b + q_ab;
+            } else {
+                // KL(new || old): lbeta(a2,b2) - lbeta(a,b) + (a-a2) psi(a) + (b-b2) psi(b) + (a2-a+b2-b) psi(a+b)
+                kl = lbetaf(a2, b2) - lbetaf(a, b) + (a - a2) * psi_a + (b - b2) * psi_b + (a2 - a + b2 - b) * psi_ab;
+                ka = -(psi_a - psi_ab) + psi_a + (a - a2) * trigammaf(a) - psi_ab + (a2 - a + b2 - b) * tri_ab;
+                kb = -(psi_b - psi_ab) + psi_b + (b - b2) * trigammaf(b) - psi_ab + (a2 - a + b2 - b) * tri_ab;
+            }
+            aux += kl;
+            ga += p.kl_w * ka; gb += p.kl_w * kb;
+        }
+        float* dc = p.dcparams + (int64_t)r * p.ldc + 2 * c;
+        dc[0] = ga * ab.da * scale;
+        dc[1] = gb * ab.db * scale;
+    }
+    for (int j = 2 * p.nc; j < p.ldc; ++j) p.dcparams[(int64_t)r * p.ldc + j] = 0.f;
     p.row_pl[r] = pl * mk;
     p.row_ent[r] = -ent * mk;
     p.row_aux[r] = aux * mk;
@@ -400,10 +451,11 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
     D4_REQUIRE(e->prepared, "engine not prepared");
     const int B = io->batch, T = io->time, R = B * T;
     D4_REQUIRE(R > 0 && R <= e->LR, "learn: %d rows exceed max_learn_rows %d", R, e->LR);
-    D4_REQUIRE(io->agent_embed && io->actions && io->old_log_probs && io->old_values && io->rewards && io->losses,
+    D4_REQUIRE(io->agent_embed && io->old_values && io->rewards && io->losses && (e->na == 0 || (io->actions && io->old_log_probs)) &&
+               (e->nc == 0 || (io->actions_cont && io->old_log_probs_cont)),
                "the generations need to contain the log probs, values, and rewards for policy optimization  [D4:5935]");
     D4_REQUIRE(io->objective >= 0 && io->objective <= 2, "unknown objective %d  [D4:6215]", io->objective);
-    const int D = e->D, A = e->A, Apad = (A + 3) / 4 * 4, na = e->na;
+    const int D = e->D, A = e->A, Apad = (A + 3) / 4 * 4 + (A == 0 ? 4 : 0), na = e->na, nc = e->nc, Cpad = (2 * nc + 3) / 4 * 4 + (nc == 0 ? 4 : 0);
     int rc;
     float* scal = e->l_scal;
     D4_HIP(hipMemsetAsync(scal, 0, 64 * sizeof(float), s));
@@ -432,8 +484,14 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
     float* pe = e->l_tmp[0];
     if ((rc = mlp_forward(e, e->policy, io->agent_embed, D, R, pe, 4 * D, save_p, s))) return rc;
     if ((rc = fill_f32(e->l_logits, 0.f, (int64_t)R * Apad, s))) return rc;
-    {
+    if (na > 0) {
         GemmArgs g{pe, 4 * D, e->action_unembed, c.multi_token_pred_len * 4 * D, e->l_logits, Apad, nullptr, nullptr, 0, R, A, 4 * D, 0, 0.f};
+        if ((rc = gemm(g, s))) return rc;
+    }
+    if (nc > 0) {      // raw Beta parameters of prediction head 0 (head-0 slice of the [nc][mtp][4D][2] parameter as a GEMM weight)
+        if ((rc = cunembed_gather(e->cont_unembed, e->cu_w, nc, c.multi_token_pred_len, 4 * D, s))) return rc;
+        if ((rc = fill_f32(e->l_cparams, 0.f, (int64_t)R * Cpad, s))) return rc;
+        GemmArgs g{pe, 4 * D, e->cu_w, 4 * D, e->l_cparams, Cpad, nullptr, nullptr, 0, R, 2 * nc, 4 * D, 0, 0.f};
         if ((rc = gemm(g, s))) return rc;
     }
     float* row_pl = e->l_rows, *row_ent = e->l_rows + R, *row_aux = e->l_rows + 2 * R, *row_vl = e->l_rows + 3 * R;
@@ -442,6 +500,8 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
         p.logits = e->l_logits; p.ld = Apad; p.actions = io->actions; p.old_lp = io->old_log_probs;
         p.old_logits = io->old_action_logits; p.ldo = A; p.adv_raw = row_a; p.mask = mask_keep; p.scal = scal;
         p.action_sizes = e->action_sizes; p.dlogits = e->l_dlogits; p.row_pl = row_pl; p.row_ent = row_ent; p.row_aux = row_aux;
+        p.cparams = e->l_cparams; p.ldc = Cpad; p.actions_cont = io->actions_cont; p.old_lp_cont = io->old_log_probs_cont;
+        p.old_cparams = io->old_cont_params; p.dcparams = e->l_dcparams; p.nc = nc;
         p.R = R; p.na = na; p.A = A; p.objective = io->objective; p.normalize = normalize;
         p.use_gate = io->use_delight_gating < 0 ? c.use_delight_gating : io->use_delight_gating;
         p.reverse_kl = c.pmpo_reverse_kl;
@@ -449,7 +509,7 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
         p.gate_temp = io->delight_temperature > 0.f ? io->delight_temperature : c.delight_temperature;
         p.pmpo_alpha = c.pmpo_pos_to_neg_weight;
         p.kl_w = io->objective == 2 ? c.pmpo_kl_div_loss_weight : 0.f;
-        D4_REQUIRE(!(p.kl_w > 0.f) || io->old_action_logits, "pmpo with a KL weight needs old_action_unembeds  [D4:6160-6170]");
+        D4_REQUIRE(!(p.kl_w > 0.f) || ((na == 0 || io->old_action_logits) && (nc == 0 || io->old_cont_params)), "pmpo with a KL weight needs old_action_unembeds  [D4:6160-6170]");
         hipLaunchKernelGGL(policy_loss_kernel, dim3(cdiv(R, 128)), dim3(128), 0, s, p);
         D4_LAUNCH_CHECK();
     }
@@ -474,17 +534,27 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
     D4_LAUNCH_CHECK();
 
     // ---- backward: unembed head 0, policy MLP, value MLP
-    D4_REQUIRE(e->action_unembed_grad, "learner: discrete_action_unembed was bound without a gradient buffer");
     const int mtp4d = c.multi_token_pred_len * 4 * D;
-    if ((rc = fill_f32(e->action_unembed_grad, 0.f, (int64_t)A * mtp4d, s))) return rc;
     // pe (policy MLP output) was saved as the last layer's z
     float *pe_x, *pe_xh, *pe_saved;
     e->policy.save_ptrs(save_p, R, e->policy.nl - 1, &pe_x, &pe_xh, &pe_saved);
-    // dU0[a][k] = sum_r dlogits[r][a] * pe[r][k]
-    if ((rc = gemm_l(e->l_dlogits, Apad, pe_saved, 4 * D, e->action_unembed_grad, mtp4d, A, 4 * D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
-    // dpe[r][k] = sum_a dlogits[r][a] * U0[a][k]      (K = Apad; pad rows of U0 are never read: mask K to A)
     float* dpe = e->l_dpe;
-    if ((rc = gemm_l(e->l_dlogits, Apad, e->action_unembed, mtp4d, dpe, 4 * D, R, 4 * D, A, GEMM_TRANS_B, s))) return rc;
+    if (na > 0) {
+        D4_REQUIRE(e->action_unembed_grad, "learner: discrete_action_unembed was bound without a gradient buffer");
+        if ((rc = fill_f32(e->action_unembed_grad, 0.f, (int64_t)A * mtp4d, s))) return rc;
+        // dU0[a][k] = sum_r dlogits[r][a] * pe[r][k]
+        if ((rc = gemm_l(e->l_dlogits, Apad, pe_saved, 4 * D, e->action_unembed_grad, mtp4d, A, 4 * D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        // dpe[r][k] = sum_a dlogits[r][a] * U0[a][k]      (K = Apad; pad rows of U0 are never read: mask K to A)
+        if ((rc = gemm_l(e->l_dlogits, Apad, e->action_unembed, mtp4d, dpe, 4 * D, R, 4 * D, A, GEMM_TRANS_B, s))) return rc;
+    }
+    if (nc > 0) {
+        D4_REQUIRE(e->cont_unembed_grad, "learner: continuous_action_unembed was bound without a gradient buffer");
+        // d cu_w[j][k] = sum_r dcparams[r][j] * pe[r][k], scattered back into the [nc][mtp][4D][2] layout (other heads: zero)
+        if ((rc = gemm_l(e->l_dcparams, Cpad, pe_saved, 4 * D, e->l_cu_g, 4 * D, 2 * nc, 4 * D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        if ((rc = cunembed_scatter_grad(e->l_cu_g, e->cont_unembed_grad, nc, c.multi_token_pred_len, 4 * D, s))) return rc;
+        // dpe (+)= dcparams . cu_w
+        if ((rc = gemm_l(e->l_dcparams, Cpad, e->cu_w, 4 * D, dpe, 4 * D, R, 4 * D, 2 * nc, GEMM_TRANS_B | (na > 0 ? GEMM_ACCUMULATE : 0), s))) return rc;
+    }
     if ((rc = mlp_backward(e, e->policy, save_p, R, dpe, 4 * D, s))) return rc;
     if ((rc = mlp_backward(e, e->value, save_v, R, e->l_dvbins, vld, s))) return rc;
     return 0;

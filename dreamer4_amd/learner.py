@@ -57,15 +57,25 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
         assert t.shape[:2] == (B, T), f'experience field of shape {tuple(t.shape)} does not match agent_embed {(B, T)}'
         return t.contiguous()
 
-    actions = exp.actions.discrete
-    actions = actions[..., None] if actions.ndim == 2 else actions
-    actions = bt(actions).long()
-    old_lp = bt(exp.log_probs.discrete.float().reshape(B, -1, na))
+    nc = model.num_continuous_actions
+    actions = old_lp = actions_c = old_lp_c = None
+    if na > 0:
+        actions = exp.actions.discrete
+        actions = actions[..., None] if actions.ndim == 2 else actions
+        actions = bt(actions).long()
+        old_lp = bt(exp.log_probs.discrete.float().reshape(B, -1, na))
+    if nc > 0:
+        actions_c = exp.actions.continuous
+        actions_c = actions_c[..., None] if actions_c.ndim == 2 else actions_c
+        actions_c = bt(actions_c.float())
+        old_lp_c = bt(exp.log_probs.continuous.float().reshape(B, -1, nc))
     old_values = bt(exp.values.float())
     rewards = bt(exp.rewards.float())
-    old_logits = None
-    if exp.old_action_unembeds is not None and exp.old_action_unembeds.discrete is not None:
+    old_logits = old_cparams = None
+    if exp.old_action_unembeds is not None and exp.old_action_unembeds.discrete is not None and na > 0:
         old_logits = bt(exp.old_action_unembeds.discrete.float())
+    if exp.old_action_unembeds is not None and exp.old_action_unembeds.continuous is not None and nc > 0:
+        old_cparams = bt(exp.old_action_unembeds.continuous.float())
     prompt_off = exp.latents.shape[1] - T if exp.latents is not None else 0
     lens = exp.lens.long() - prompt_off if exp.lens is not None else torch.full((B,), T, device=dev)
     lens = lens.contiguous()
@@ -87,6 +97,7 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
     io.delight_temperature = -1. if delight_temperature is None else float(delight_temperature)
     P = _lib.ptr
     io.agent_embed, io.actions, io.old_log_probs, io.old_values = P(agent), P(actions), P(old_lp), P(old_values)
+    io.actions_cont, io.old_log_probs_cont, io.old_cont_params = P(actions_c), P(old_lp_c), P(old_cparams)
     io.rewards, io.old_action_logits, io.lens, io.is_truncated, io.terminals = P(rewards), P(old_logits), P(lens), P(trunc), P(terms)
     io.losses, io.returns = P(losses), P(returns)
 

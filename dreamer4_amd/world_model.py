@@ -113,7 +113,8 @@ _UNSUPPORTED_DEFAULTS = dict(
     dim_proprio=None, dim_state=None, dim_critic_state=None, critic_state_embedder=None,
     spatial_pre_encoder_depth=0, action_pre_encoder_depth=0, actor_depth=0, critic_depth=0,
     pred_orig_latent=True, use_time_rnn=False, add_reward_embed_to_agent_token=False,
-    add_state_pred_head=False, agent_predicts_state=False, num_continuous_actions=0,
+    add_state_pred_head=False, agent_predicts_state=False, continuous_norm_stats=None, continuous_dist_type='beta',
+    continuous_dist_kwargs={}, continuous_target_action_range=None,
     num_latent_genes=0, keep_reward_ema_stats=False, clip_values=False, time_attention_use_pope=False,
     latent_ar=False, identity_latents_to_spatial=False, has_aug_conditioning=False, ssl_lapo=False,
     ssl_tem=False, actor_spr=False, agent_policy_gradient_frac=1., agent_value_gradient_frac=1.,
@@ -143,6 +144,7 @@ class DynamicsWorldModel(nn.Module):
         attn_softclamp_value=50.,
         ff_kwargs: dict = dict(),
         num_discrete_actions: int | tuple = 0,
+        num_continuous_actions=0,
         multi_token_pred_len=8,
         value_head_mlp_depth=3,
         policy_head_mlp_depth=3,
@@ -205,6 +207,7 @@ class DynamicsWorldModel(nn.Module):
         self.num_tasks, self.time_block_every = num_tasks, time_block_every
         self.attn_heads, self.attn_dim_head, self.attn_softclamp_value = attn_heads, attn_dim_head, attn_softclamp_value
         self.num_discrete_actions = nda
+        self.num_continuous_actions = int(num_continuous_actions)      # Beta policy head (the reference's default continuous_dist_type)
         self.multi_token_pred_len = multi_token_pred_len
         self.policy_head_mlp_depth, self.value_head_mlp_depth = policy_head_mlp_depth, value_head_mlp_depth
         self.terminal_mlp_depth = dict(predict_terminal_mlp_kwargs).get('depth', 1)
@@ -216,7 +219,7 @@ class DynamicsWorldModel(nn.Module):
         self.normalize_advantages, self.policy_entropy_weight = normalize_advantages, policy_entropy_weight
         self.pool_heads, self.pool_dim_head = 4, 64              # AttentionPool defaults, dreamer4.py:2147-2148
         # [flow | spatial | registers | action (only with an action space, dreamer4.py:7124-7130) | agent]
-        self.tokens_per_frame = 1 + num_spatial_tokens + num_register_tokens + (1 if len(nda) > 0 else 0) + 1
+        self.tokens_per_frame = 1 + num_spatial_tokens + num_register_tokens + (1 if (len(nda) > 0 or self.num_continuous_actions > 0) else 0) + 1
         self.ff_inner = int(dim * 4 * 2 / 3)
 
         self._build_parameters()
@@ -297,9 +300,10 @@ class DynamicsWorldModel(nn.Module):
         mlp('policy_head.', mlp_widths(D, 4 * D, 4 * D, self.policy_head_mlp_depth))
         A = sum(self.num_discrete_actions)
         reg('action_embedder.discrete_action_unembed', torch.randn(A, self.multi_token_pred_len, 4 * D) * 1e-2)
-        reg('action_embedder.continuous_action_unembed', torch.randn(0, self.multi_token_pred_len, 4 * D, 2) * 1e-2)
+        nc = self.num_continuous_actions
+        reg('action_embedder.continuous_action_unembed', torch.randn(nc, self.multi_token_pred_len, 4 * D, 2) * 1e-2)
         reg('action_embedder.discrete_action_embed.weight', torch.randn(A, D))
-        reg('action_embedder.continuous_action_embed.weight', torch.randn(0, D))
+        reg('action_embedder.continuous_action_embed.weight', torch.randn(nc, D))
         mtp = self.multi_token_pred_len
         reg('to_reward_pred.params.0', torch.ones(mtp, D))
         reg('to_reward_pred.params.1', torch.stack([_linear_w(self.reward_num_bins, D) for _ in range(mtp)]))
@@ -383,6 +387,7 @@ class DynamicsWorldModel(nn.Module):
         c.num_discrete_action_types = len(self.num_discrete_actions)
         for i, n in enumerate(self.num_discrete_actions):
             c.num_discrete_actions[i] = n
+        c.num_continuous_actions = self.num_continuous_actions
         c.multi_token_pred_len = self.multi_token_pred_len
         c.policy_head_mlp_depth, c.value_head_mlp_depth = self.policy_head_mlp_depth, self.value_head_mlp_depth
         c.terminal_mlp_depth, c.predict_terminals = self.terminal_mlp_depth, int(self.predict_terminals)
@@ -556,7 +561,7 @@ class DynamicsWorldModel(nn.Module):
 
     # ------------------------------------------------------------------------------ forward (inference branch)
     @torch.no_grad()
-    def forward(self, *, latents, signal_levels, step_sizes, discrete_actions=None, tasks=None, time_cache=None,
+    def forward(self, *, latents, signal_levels, step_sizes, discrete_actions=None, continuous_actions=None, tasks=None, time_cache=None,
                 latent_is_noised=True, return_pred_only=True, return_intermediates=True, commit_cache=True, **kwargs):
         """Inference branch of DynamicsWorldModel.forward (dreamer4.py:6792-7295): latents are already noised,
         returns (pred_flow, (agent_embed, next_time_cache)).  The training branch is out of scope."""
@@ -575,23 +580,29 @@ class DynamicsWorldModel(nn.Module):
             signal_levels = torch.full((B, T), signal_levels)
         sig = signal_levels.to(dev).expand(B, T).to(torch.int32).contiguous() if signal_levels.ndim == 2 else \
             signal_levels.to(dev).reshape(-1, 1).expand(B, T).to(torch.int32).contiguous()
-        prev = None
-        na = len(self.num_discrete_actions)
-        if discrete_actions is not None and discrete_actions.shape[1] > 0:
-            a = discrete_actions.to(dev)
+        na, nc = len(self.num_discrete_actions), self.num_continuous_actions
+
+        def pair(a, pad):
+            """action token of frame t = the action of frame t-1 (dreamer4.py:7103-7115); frame 0 has none (`pad`)"""
+            if a is None or a.shape[1] == 0:
+                return None
+            a = a.to(dev)
             a = a[..., None] if a.ndim == 2 else a
             if time_cache is not None and T == 1 and a.shape[1] == 1:
-                prev = a.contiguous()                                   # sequential step: already paired (dreamer4.py:7103)
-            else:
-                if a.shape[1] == T:
-                    a = a[:, :-1]
-                assert a.shape[1] == T - 1
-                prev = torch.cat((torch.full((B, 1, na), -1, dtype=torch.long, device=dev), a), dim=1).contiguous()
+                return a.contiguous()                                   # sequential step: already paired
+            if a.shape[1] == T:
+                a = a[:, :-1]
+            assert a.shape[1] == T - 1
+            return torch.cat((torch.full((B, 1, a.shape[-1]), pad, dtype=a.dtype, device=dev), a), dim=1).contiguous()
+
+        prev = pair(discrete_actions.long() if discrete_actions is not None else None, -1)
+        prev_c = pair(continuous_actions.float() if continuous_actions is not None else None, float('nan') if na == 0 else 0.)
+        assert (prev is None) == (prev_c is None) or na == 0 or nc == 0, 'pass both discrete and continuous actions, or neither'
         tk = tasks.to(dev).long().contiguous() if tasks is not None else None
         pred = torch.empty(B, T, *self.latent_shape, device=dev)
         agent = torch.empty(B, T, self.dim, device=dev)
         lat = latents.to(dev).float().reshape(B, T, *self.latent_shape).contiguous()
-        _lib.check(lib.d4_wm_forward(self._engine, _lib.ptr(lat), _lib.ptr(sig), step, _lib.ptr(prev), _lib.ptr(tk), B, T,
+        _lib.check(lib.d4_wm_forward(self._engine, _lib.ptr(lat), _lib.ptr(sig), step, _lib.ptr(prev), _lib.ptr(prev_c), _lib.ptr(tk), B, T,
                                      int(time_cache is not None), int(commit_cache), _lib.ptr(pred), _lib.ptr(agent), self._stream()))
         self._cache_serial += 1
         self._mark_slots(cached, cached + T, self._cache_serial)      # every evaluation writes its new frames' K/V (scratch unless committed)
@@ -645,8 +656,8 @@ class DynamicsWorldModel(nn.Module):
         parity runs; otherwise they are drawn on the device from `generator`."""
         if prompt is not None or return_decoded_video:
             raise NotImplementedError('video prompts / decoding need the VideoTokenizer, which is out of scope (SURVEY.md 8f)')
-        if latent_gene_ids is not None or prompt_proprio is not None or prompt_continuous_actions is not None or aug_id not in (False, None, 0):
-            raise NotImplementedError('latent genes / proprio / continuous actions / aug conditioning are not implemented')
+        if latent_gene_ids is not None or prompt_proprio is not None or aug_id not in (False, None, 0):
+            raise NotImplementedError('latent genes / proprio / aug conditioning are not implemented')
         assert agent_index == 0
         if return_for_policy_optimization:
             return_agent_actions = return_log_probs_and_values = return_rewards_per_frame = True
@@ -654,12 +665,12 @@ class DynamicsWorldModel(nn.Module):
         return_agent_actions = return_agent_actions or return_log_probs_and_values
         assert log2(num_steps).is_integer(), f'number of steps {num_steps} must be a power of 2'
         assert 0 < num_steps <= self.max_steps, f'number of steps {num_steps} must be between 0 and {self.max_steps}'
-        if return_agent_actions and not self.num_discrete_actions:
+        if return_agent_actions and not (self.num_discrete_actions or self.num_continuous_actions):
             raise AssertionError('the model has no actions (dreamer4.py:6626)')
 
         dev, B, T = self.device, batch_size, time_steps
         n, dl = self.latent_shape
-        na, A = len(self.num_discrete_actions), sum(self.num_discrete_actions)
+        na, A, nc = len(self.num_discrete_actions), sum(self.num_discrete_actions), self.num_continuous_actions
         if isinstance(tasks, int):
             tasks = torch.full((B,), tasks)
         assert tasks is None or tasks.shape[0] == B
@@ -693,6 +704,9 @@ class DynamicsWorldModel(nn.Module):
                 gumbel_u=torch.rand(F_, B, A, device=dev, generator=g) if return_agent_actions else None,
                 bern_u=torch.rand(F_, B, device=dev, generator=g) if sample_terminals else None,
             )
+            if return_agent_actions and nc > 0:       # (normal, uniform) per rejection round of the two gammas behind each Beta draw
+                noise['beta'] = torch.stack((torch.randn(F_, B, nc, 2, 6, device=dev, generator=g),
+                                             torch.rand(F_, B, nc, 2, 6, device=dev, generator=g).clamp(1e-6, 1. - 1e-6)), dim=-1)
         nz = {k: (v.to(dev).float().contiguous() if v is not None else None) for k, v in noise.items()}
         assert nz['latent'].shape[0] >= F_
 
@@ -704,12 +718,19 @@ class DynamicsWorldModel(nn.Module):
         if not use_time_cache:
             ctx_hist = latents.clone()
         actions = None
-        if return_agent_actions or prompt_discrete_actions is not None:
+        if na > 0 and (return_agent_actions or prompt_discrete_actions is not None):
             actions = torch.zeros(B, T, na, dtype=torch.long, device=dev)
             if prompt_discrete_actions is not None:
                 pa = prompt_discrete_actions.to(dev)
                 pa = pa[..., None] if pa.ndim == 2 else pa
                 actions[:, :pa.shape[1]] = pa[:, :T]
+        actions_c = None
+        if nc > 0 and (return_agent_actions or prompt_continuous_actions is not None):
+            actions_c = torch.zeros(B, T, nc, device=dev)
+            if prompt_continuous_actions is not None:
+                pc = prompt_continuous_actions.to(dev).float()
+                pc = pc[..., None] if pc.ndim == 2 else pc
+                actions_c[:, :pc.shape[1]] = pc[:, :T]
         rewards = torch.zeros(B, T, device=dev)
         if prompt_rewards is not None:
             rewards[:, :prompt_rewards.shape[1]] = prompt_rewards.to(dev)[:, :T]
@@ -717,6 +738,8 @@ class DynamicsWorldModel(nn.Module):
         log_probs = torch.empty(B, F_, na, device=dev)
         values = torch.empty(B, F_, device=dev)
         logits = torch.empty(B, F_, A, device=dev)
+        log_probs_c = torch.empty(B, F_, nc, device=dev)
+        cparams = torch.empty(B, F_, nc, 2, device=dev)
         lens = torch.full((B,), T, dtype=torch.long, device=dev)
         terminals = torch.zeros(B, dtype=torch.uint8, device=dev)
         tk = tasks.to(dev).long().contiguous() if tasks is not None else None
@@ -726,7 +749,9 @@ class DynamicsWorldModel(nn.Module):
         io.use_time_cache, io.sample_terminals = int(use_time_cache), int(sample_terminals)
         io.sample_actions = int(return_agent_actions)
         io.context_signal_noise, io.discrete_temperature = context_signal_noise, discrete_temperature
+        io.continuous_temperature = continuous_temperature
         P_ = _lib.ptr
+        io.beta_noise, io.actions_cont, io.log_probs_cont, io.cont_params = P_(nz.get('beta')), P_(actions_c), P_(log_probs_c), P_(cparams)
         io.noise_latent, io.noise_context = P_(nz['latent']), P_(nz.get('context'))
         io.gumbel_u, io.bern_u, io.tasks = P_(nz.get('gumbel_u')), P_(nz.get('bern_u')), P_(tk)
         io.latents, io.actions, io.rewards, io.ctx_hist = P_(latents), P_(actions), P_(rewards), P_(ctx_hist)
@@ -768,7 +793,8 @@ class DynamicsWorldModel(nn.Module):
             video=None,
             proprio=None,
             agent_embed=agent_embed[:, :Fp] if store_agent_embed else None,
-            old_action_unembeds=Actions(logits[:, :Fp], None) if (return_agent_actions and store_old_action_unembeds) else None,
+            old_action_unembeds=Actions(logits[:, :Fp] if na > 0 else None, cparams[:, :Fp] if nc > 0 else None)
+            if (return_agent_actions and store_old_action_unembeds) else None,
             step_size=self.max_steps // num_steps,
             agent_index=agent_index,
             lens=lens,
@@ -777,8 +803,8 @@ class DynamicsWorldModel(nn.Module):
             is_from_world_model=True,
             episode_return=(rewards * step_mask.float()).sum(dim=-1),
             rewards=rewards if return_rewards_per_frame else None,
-            actions=Actions(actions[:, :Tp], None) if return_agent_actions else None,
-            log_probs=Actions(log_probs[:, :Fp], None) if return_log_probs_and_values else None,
+            actions=Actions(actions[:, :Tp] if na > 0 else None, actions_c[:, :Tp] if nc > 0 else None) if return_agent_actions else None,
+            log_probs=Actions(log_probs[:, :Fp] if na > 0 else None, log_probs_c[:, :Fp] if nc > 0 else None) if return_log_probs_and_values else None,
             values=values[:, :Fp] if return_log_probs_and_values else None,
         )
         return (gen, new_cache) if return_time_cache else gen

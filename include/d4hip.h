@@ -43,6 +43,7 @@ typedef struct d4_config {
     int32_t num_spatial_tokens, num_register_tokens, max_steps, num_tasks;
     int32_t num_discrete_action_types;
     int32_t num_discrete_actions[D4_MAX_ACTION_TYPES];
+    int32_t num_continuous_actions;             /* Beta policy head: continuous_dist_type='beta', no norm stats (D4:1131, 1172-1196) */
     int32_t multi_token_pred_len;
     int32_t policy_head_mlp_depth, value_head_mlp_depth, terminal_mlp_depth, predict_terminals;
     int32_t reward_num_bins, value_num_bins;
@@ -100,13 +101,15 @@ int d4_engine_cache_import(d4_engine* e, const float* src, int batch, int frames
  *   signal_levels  [batch][frames] int32 in [0, max_steps)
  *   prev_actions   [batch][frames][action_types] int64: the action token of each frame, i.e. the
  *                  action taken at the previous frame; a negative first entry means "no action"
- *                  (zero token, D4:7110-7126).  NULL = zero tokens everywhere.
+ *                  (zero token, D4:7110-7126).  NULL = zero tokens everywhere (models with discrete actions).
+ *   prev_cont      [batch][frames][num_continuous_actions] float, same pairing; "no action" = NaN in the first
+ *                  entry (only consulted when the model has no discrete actions).  NULL allowed as above.
  *   tasks          [batch] int64 or NULL
  *   use_cache      attend over the frames already in the KV cache (their count is the rotary offset)
  *   commit_cache   keep the new frames' K/V in the cache (the "extra clean step" of D4:6545)
  * Outputs: pred [batch][frames][n][dl], agent_embed [batch][frames][dim]. */
 int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_levels, int step_size,
-                  const int64_t* prev_actions, const int64_t* tasks, int batch, int frames,
+                  const int64_t* prev_actions, const float* prev_cont, const int64_t* tasks, int batch, int frames,
                   int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream);
 
 /* DynamicsWorldModel.generate(...) D4:6308-6774 with every random draw injected. */
@@ -120,21 +123,26 @@ typedef struct d4_rollout_io {
     int32_t sample_actions;        /* return_agent_actions (D4:6625): policy head + Gumbel sample + value head */
     float context_signal_noise;    /* D4:6319 */
     float discrete_temperature;
+    float continuous_temperature;
     /* injected noise, one slice per generated frame f = 0 .. time_steps - prompt_frames - 1 */
     const float* noise_latent;     /* [F][batch][n][dl] normal   (D4:6475) */
     const float* noise_context;    /* [F][batch][n][dl] normal   (D4:6670); may be NULL when use_time_cache */
     const float* gumbel_u;         /* [F][batch][A] uniform (0,1) (MultiCategorical.sample) */
     const float* bern_u;           /* [F][batch] uniform         (D4:6611); NULL unless sample_terminals */
+    const float* beta_noise;       /* [F][batch][nc][2][6][2] (normal, uniform) per gamma rejection round (Readout.sample_continuous) */
     const int64_t* tasks;          /* [batch] or NULL */
     /* in/out histories, time-major stride = time_steps; prompt entries pre-filled by the caller */
     float* latents;                /* [batch][time_steps][n][dl]  (unclamped; caller clamps, D4:6686) */
     int64_t* actions;              /* [batch][time_steps][action_types] */
+    float* actions_cont;           /* [batch][time_steps][nc] continuous actions in the Beta's native (0, 1) range */
     float* rewards;                /* [batch][time_steps] */
     float* ctx_hist;               /* [batch][time_steps][n][dl] fixed context noise per frame (prompt entries =
                                       the prompt latents, D4:6400); NULL allowed when use_time_cache */
     /* outputs for generated frames only, index = frame - prompt_frames, stride = F */
     float* agent_embed;            /* [batch][F][dim] */
     float* log_probs;              /* [batch][F][action_types] */
+    float* log_probs_cont;         /* [batch][F][nc] */
+    float* cont_params;            /* [batch][F][nc][2] raw Beta parameters (old_action_unembeds.continuous, D4:6749-6750) */
     float* values;                 /* [batch][F] */
     float* action_logits;          /* [batch][F][A]   (old_action_unembeds, D4:6749-6750) */
     int64_t* lens;                 /* [batch]  pre-filled with time_steps */
@@ -156,6 +164,9 @@ typedef struct d4_learn_io {
     const float* agent_embed;      /* [batch][time][dim] */
     const int64_t* actions;        /* [batch][time][action_types] */
     const float* old_log_probs;    /* [batch][time][action_types] */
+    const float* actions_cont;     /* [batch][time][nc] */
+    const float* old_log_probs_cont;   /* [batch][time][nc] */
+    const float* old_cont_params;  /* [batch][time][nc][2] (pmpo KL) or NULL */
     const float* old_values;       /* [batch][time] */
     const float* rewards;          /* [batch][time] */
     const float* old_action_logits;/* [batch][time][A] (pmpo KL) or NULL */

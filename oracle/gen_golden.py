@@ -23,6 +23,9 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   blocks.npz       block-level intermediates of that parallel forward (forward hooks on the reference's modules)
   learn.npz        learn_from_experience ppo / spo / pmpo: losses + head gradients (autograd), GAE returns
   trainer.npz      3 DreamTrainer-style steps (trainers.py:1430-1452): losses, grad norms, final head weights
+  postln.npz       head MLPs in the Linear -> LayerNorm -> SiLU recipe (weights_postln.npz): rollout, ppo / pmpo losses and gradients
+  continuous.npz   continuous (Beta) actions: a mixed discrete + continuous model (weights_continuous.npz: rollout, ppo / spo / pmpo
+                   losses and gradients) and a continuous-only one (weights_contonly.npz: tempered rollout, env-wrapper chained calls)
 """
 from __future__ import annotations
 
@@ -43,7 +46,7 @@ OUT = os.path.join(ROOT, 'tests', 'golden')
 META = dict(
     oracle='shim',
     reference='lucidrains/dreamer4 v0.16.3 dreamer4/dreamer4.py imported unmodified',
-    restated_third_party='x_mlps_pytorch(create_mlp, Ensemble) hl_gauss_pytorch discrete_continuous_embed_readout(MultiCategorical) '
+    restated_third_party='x_mlps_pytorch(create_mlp, Ensemble) hl_gauss_pytorch discrete_continuous_embed_readout(MultiCategorical, Readout, BetaDist) '
                          'assoc_scan einx torch_einops_utils  -- PARITY UNPINNED against the real packages',
 )
 
@@ -79,6 +82,21 @@ CFG_NOTERM = dict(dim=16, dim_latent=4, num_latent_tokens=3, depth=1, time_block
                   num_discrete_actions=(5,), num_tasks=2, predict_terminals=False, reward_num_bins=15, value_num_bins=15, multi_token_pred_len=1)
 
 
+CFG_POSTLN = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                  num_discrete_actions=(4,), num_tasks=0, reward_num_bins=31, value_num_bins=31, multi_token_pred_len=2,
+                  policy_head_mlp_depth=2, value_head_mlp_depth=1, head_mlp_recipe='post_layer')
+
+
+CFG_CONT = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                num_discrete_actions=(3,), num_continuous_actions=3, num_tasks=0, reward_num_bins=31, value_num_bins=31,
+                multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1)
+
+
+CFG_CONTONLY = dict(dim=16, dim_latent=4, num_latent_tokens=3, depth=2, time_block_every=1, attn_heads=1, attn_dim_head=16,
+                    num_discrete_actions=(), num_continuous_actions=2, num_tasks=0, reward_num_bins=15, value_num_bins=15,
+                    multi_token_pred_len=1, policy_head_mlp_depth=1, value_head_mlp_depth=1)
+
+
 def fixture_config():
     return Config(**CFG)
 
@@ -92,11 +110,16 @@ def exp_dict(prefix, e, out):
     out[prefix + 'agent_embed'] = npy(e.agent_embed)
     out[prefix + 'rewards'] = npy(e.rewards)
     out[prefix + 'values'] = npy(e.values)
-    out[prefix + 'log_probs'] = npy(e.log_probs.discrete)
-    out[prefix + 'actions'] = npy(e.actions.discrete)
+    if e.actions.discrete is not None:
+        out[prefix + 'log_probs'] = npy(e.log_probs.discrete)
+        out[prefix + 'actions'] = npy(e.actions.discrete)
+        out[prefix + 'unembeds'] = npy(e.old_action_unembeds.discrete)
+    if e.actions.continuous is not None:
+        out[prefix + 'log_probs_cont'] = npy(e.log_probs.continuous)
+        out[prefix + 'actions_cont'] = npy(e.actions.continuous)
+        out[prefix + 'cont_params'] = npy(e.old_action_unembeds.continuous)
     out[prefix + 'lens'] = npy(e.lens)
     out[prefix + 'terminals'] = npy(e.terminals)
-    out[prefix + 'unembeds'] = npy(e.old_action_unembeds.discrete)
     out[prefix + 'episode_return'] = npy(e.episode_return)
 
 
@@ -130,7 +153,130 @@ def min_margin(e, noise, cfg):
     return float((top[..., 0] - top[..., 1]).min())
 
 
+HEADS = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed', 'action_embedder.continuous_action_unembed')
+
+
+def save_weights(name, W, cfgd):
+    np.savez(os.path.join(OUT, name), **{k: npy(v) for k, v in W.items() if v.numel() > 0},
+             **{'meta_' + k: np.array(v) for k, v in META.items()}, **{'cfg_' + k: np.array(v) for k, v in cfgd.items()})
+
+
+def learn_into(out, m, e, objectives):
+    for obj in objectives:
+        m.zero_grad()
+        pl_, vl_ = m.learn_from_experience(e, objective=obj)
+        pl_.backward(); vl_.backward()
+        out[f'{obj}_policy_loss'], out[f'{obj}_value_loss'] = npy(pl_), npy(vl_)
+        for k, p in m.named_parameters():
+            if k.startswith(HEADS) and p.numel() > 0 and p.grad is not None:
+                if p.ndim == 1 or 'unembed' in k or p.numel() <= 4096:
+                    out[f'{obj}_grad/{k}'] = npy(p.grad)
+                else:
+                    out[f'{obj}_gnorm/{k}'] = npy(p.grad.norm())
+                    out[f'{obj}_gsample/{k}'] = npy(p.grad.flatten()[::97])
+
+
+def gen_postln():
+    """postln.npz / weights_postln.npz: the head MLPs in the OTHER plausible recipe of x_mlps_pytorch's normed MLP
+    (Linear -> LayerNorm -> SiLU, bare last Linear; oracle/shim/x_mlps_pytorch/normed_mlp.py RECIPE = 'post_layer')."""
+    cfg = Config(**CFG_POSTLN)
+    m = build_reference_model(cfg, seed=21)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)
+        g = torch.Generator().manual_seed(22)
+        for k, p in m.named_parameters():          # LayerNorm biases default to zero: make them visible
+            if k.startswith(HEADS + ('to_state_terminal_pred',)) and k.endswith('.1.bias') and p.ndim == 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    W = weights_of(m)
+    assert 'policy_head.layers.0.1.bias' in W and f'policy_head.layers.{cfg.policy_head_mlp_depth + 1}.weight' in W
+    save_weights('weights_postln.npz', W, CFG_POSTLN)
+    out = {}
+    nz = make_noise(cfg, 5, 3, 901)
+    with injected(nz):
+        e = m.generate(5, batch_size=3, return_for_policy_optimization=True)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg))
+    learn_into(out, m, e, ('ppo', 'pmpo'))
+    np.savez(os.path.join(OUT, 'postln.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('postln margin', out['cached_margin'], 'lens', out['cached_lens'])
+
+
+def gen_continuous():
+    """continuous.npz: continuous (Beta) actions through the Readout / BetaDist stand-in — a mixed discrete + continuous model
+    (rollout, ppo / spo / pmpo losses and gradients) and a continuous-only one (tempered sampling, env-wrapper style chained calls
+    with prompt_continuous_actions and the carried time cache)."""
+    from oracle import restate
+    cfg = Config(**CFG_CONT)
+    m = build_reference_model(cfg, seed=31)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)
+    W = weights_of(m)
+    save_weights('weights_continuous.npz', W, CFG_CONT)
+    out = {}
+
+    def beta_margin(e, nz, temperature=1.):
+        F = e.old_action_unembeds.continuous.shape[1]
+        return restate.beta_accept_margin(e.old_action_unembeds.continuous, nz['beta'][:F].transpose(0, 1), temperature)
+
+    # the noise seed is the first one whose draws are decided with a comfortable margin: the accept / reject decisions of the gamma
+    # sampler and the discrete arg-max are then the same in every fp32 implementation (SURVEY.md 8c "margin")
+    for seed in range(911, 960):
+        nz = make_noise(cfg, 5, 3, seed)
+        with injected(nz):
+            e = m.generate(5, batch_size=3, return_for_policy_optimization=True)
+        if beta_margin(e, nz) >= 2e-3 and min_margin(e, nz, cfg) >= 1e-2 and int(e.lens.min()) >= 2:
+            break
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_seed'] = np.array(seed)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg))
+    out['cached_beta_margin'] = np.array(beta_margin(e, nz))
+    learn_into(out, m, e, ('ppo', 'spo', 'pmpo'))
+    # continuous-only model
+    cfg2 = Config(**CFG_CONTONLY)
+    m2 = build_reference_model(cfg2, seed=33)
+    W2 = weights_of(m2)
+    save_weights('weights_contonly.npz', W2, CFG_CONTONLY)
+    for seed in range(921, 960):
+        nz = make_noise(cfg2, 4, 2, seed)
+        with injected(nz):
+            e = m2.generate(4, batch_size=2, return_for_policy_optimization=True, continuous_temperature=0.7)
+        if beta_margin(e, nz, 0.7) >= 2e-3 and int(e.lens.min()) >= 2:
+            break
+    exp_dict('only_', e, out); noise_dict('only_', nz, out)
+    out['only_beta_margin'] = np.array(beta_margin(e, nz, 0.7))
+    m2.zero_grad()
+    pl_, vl_ = m2.learn_from_experience(e, objective='ppo')
+    out['only_ppo_policy_loss'], out['only_ppo_value_loss'] = npy(pl_), npy(vl_)
+    for seed in range(931, 980):
+        nz = make_noise(cfg2, 3, 2, seed)
+        lat_hist = torch.zeros(2, 0, 3, 4); act_hist = torch.zeros(2, 0, 2); tc = None
+        env, worst = {}, float('inf')
+        for i in range(3):
+            sub = {k: v[i:i + 1] for k, v in nz.items()}
+            kw = dict(prompt_latents=lat_hist, prompt_continuous_actions=act_hist) if i > 0 else {}
+            with injected(sub):
+                e, tc = m2.generate(i + 1, batch_size=2, return_rewards_per_frame=True, return_agent_actions=True,
+                                    return_log_probs_and_values=True, time_cache=tc, return_time_cache=True, return_terminals=False, **kw)
+            worst = min(worst, beta_margin(e, sub))
+            lat_hist, act_hist = e.latents, e.actions.continuous
+            env[f'env{i}_latents'], env[f'env{i}_actions_cont'], env[f'env{i}_values'] = npy(e.latents), npy(e.actions.continuous), npy(e.values)
+        if worst >= 2e-3:
+            break
+    out.update(env); noise_dict('env_', nz, out)
+    out['env_beta_margin'] = np.array(worst)
+    np.savez(os.path.join(OUT, 'continuous.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('continuous margins', out['cached_margin'], out['cached_beta_margin'], out['only_beta_margin'], out['env_beta_margin'], 'lens', out['cached_lens'], out['only_lens'])
+
+
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous)
+
+
 def main():
+    if len(sys.argv) > 1:                     # python -m oracle.gen_golden postln continuous : only these families
+        os.makedirs(OUT, exist_ok=True)
+        for name in sys.argv[1:]:
+            EXTRA[name]()
+        return
     os.makedirs(OUT, exist_ok=True)
     D4 = load_reference()
     cfg = fixture_config()
@@ -489,6 +635,8 @@ def main():
     np.savez(os.path.join(OUT, 'noterm.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('noterm margin', out['cached_margin'], 'lens', out['cached_lens'], 'terminals', out['cached_terminals'])
 
+    for fn in EXTRA.values():
+        fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, 'KiB')
 

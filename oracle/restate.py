@@ -539,6 +539,28 @@ def gamma_from_noise(shape_param, noise):
     return out.clamp(min=1e-30)
 
 
+def beta_accept_margin(params, noise, temperature=1.):
+    """Smallest |log u - bound| over the rejection rounds that decided a draw: exact agreement of the accept / reject decisions
+    between fp32 implementations is only well posed when this is comfortably above their rounding differences."""
+    a, b = beta_alpha_beta(params)
+    t = max(float(temperature), 1e-10)
+    best = float('inf')
+    for shape, nz in ((1. + (a - 1.) / t, noise[..., 0, :, :]), (1. + (b - 1.) / t, noise[..., 1, :, :])):
+        d = shape - 1. / 3.
+        c = 1. / torch.sqrt(9. * d)
+        done = torch.zeros_like(shape, dtype=torch.bool)
+        for r in range(nz.shape[-2]):
+            x, u = nz[..., r, 0], nz[..., r, 1]
+            v = (1. + c * x) ** 3
+            gap = (torch.log(u.clamp(min=1e-30)) - (0.5 * x * x + d - d * v + d * torch.log(v.clamp(min=1e-30)))).abs()
+            gap = torch.where(v > 0., gap, v.abs())
+            live = ~done
+            if live.any():
+                best = min(best, float(gap[live].min()))
+            done = done | ((v > 0.) & (torch.log(u.clamp(min=1e-30)) < 0.5 * x * x + d - d * v + d * torch.log(v.clamp(min=1e-30))))
+    return best
+
+
 def sample_continuous(params, noise, temperature=1.):
     """Readout.sample_continuous D4:1379-1383: Beta(1 + (alpha-1)/T, 1 + (beta-1)/T) as a ratio of gammas; noise (..., nc, 2, rounds, 2)."""
     a, b = beta_alpha_beta(params)

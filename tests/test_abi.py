@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in d4hip.h but not exported by libd4hip.so'
     assert set(syms) == set(_lib.SYMBOLS), set(syms) ^ set(_lib.SYMBOLS)
-    assert lib.d4_version() == 1
+    assert lib.d4_version() == 2
 
 
 def _cfg(**over):

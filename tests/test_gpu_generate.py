@@ -296,21 +296,27 @@ def test_full_size_config_vs_oracle(B):
 
 
 def test_config5_shape_vs_oracle():
-    """BASELINE config 5 architecture in fp32 with a discrete action space (dim 1024, depth 12 -> time layers 4, 8, 12,
-    attention inner width 8 x 64 = 512 < dim, 64 x 32 latents): the engine is not specialised to dim 512."""
+    """BASELINE config 5 architecture in fp32: dim 1024, depth 12 -> time layers 4, 8, 12, attention inner width 8 x 64 = 512 < dim,
+    64 x 32 latents, 6 continuous (Beta) actions.  (The engine is not specialised to dim 512; the bf16 form of this config is
+    tests/test_gpu_bf16.py.)"""
     from dreamer4_amd import DynamicsWorldModel
     torch.manual_seed(0)
-    m = randomize_weights(DynamicsWorldModel(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_discrete_actions=4))
+    m = randomize_weights(DynamicsWorldModel(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_continuous_actions=6))
+    with torch.no_grad():
+        m.action_embedder.continuous_action_unembed.mul_(30.)
     cfg, W = oracle_config(m), oracle_weights(m)
-    assert sum(cfg.is_time) == 3
+    assert sum(cfg.is_time) == 3 and cfg.num_discrete_actions == () and cfg.num_continuous_actions == 6
     B, T = 2, 3
-    nz = make_noise(cfg, T, B, 9)
-    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, return_terminals=False)
+    for seed in range(9, 40):
+        nz = make_noise(cfg, T, B, seed)
+        ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, return_terminals=False)
+        if restate.beta_accept_margin(ref['old_cont_params'], nz['beta'].transpose(0, 1)) >= 5e-3:
+            break
     e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
                           return_log_probs_and_values=True, noise=nz)
     close(e.latents, ref['latents'], atol=5e-4); close(e.agent_embed, ref['agent_embed'], atol=1e-3)
-    close(e.values, ref['values'], atol=5e-4); close(e.log_probs.discrete, ref['log_probs'], atol=1e-3)
-    assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
+    close(e.values, ref['values'], atol=5e-4); close(e.log_probs.continuous, ref['log_probs_cont'], atol=2e-3)
+    close(e.actions.continuous, ref['actions_cont'], atol=1e-4)
 
 
 def test_full_size_properties_at_baseline_batch():

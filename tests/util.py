@@ -97,6 +97,8 @@ def golden_model(weights='weights.npz'):
     if 'value_range' in kw:
         venc['reward_range'] = tuple(kw.pop('value_range'))
     kw['num_discrete_actions'] = tuple(kw['num_discrete_actions']) if isinstance(kw['num_discrete_actions'], (tuple, list)) else kw['num_discrete_actions']
+    if 'head_mlp_recipe' in kw:
+        kw['head_mlp_recipe'] = str(kw['head_mlp_recipe'])
     kw = {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in kw.items()}
     m = DynamicsWorldModel(**kw, reward_encoder_kwargs=renc, value_encoder_kwargs=venc)
     _, W = golden_oracle(weights)
@@ -116,4 +118,4 @@ def t(a):
 
 
 def golden_noise(g, prefix):
-    return {k: t(g[prefix + 'noise_' + k]) for k in ('latent', 'context', 'gumbel_u', 'bern_u')}
+    return {k: t(g[prefix + 'noise_' + k]) for k in ('latent', 'context', 'gumbel_u', 'bern_u', 'beta') if prefix + 'noise_' + k in g}
