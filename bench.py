@@ -90,6 +90,69 @@ def cpu_baseline(max_threads=16, target_s=12.0):
                        f'at dim=512 depth=6: {steps} imagined steps in {dt:.1f} s, torch fp32, {cores} threads')
 
 
+CFG4 = dict(dim=512, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=6, num_discrete_actions=4)
+CFG5 = dict(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_continuous_actions=6)
+PEAK_BF16_MFMA_TFLOPS = 2500.          # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+FLOP_PER_IMAGINED_STEP_CFG5 = 33.9e9   # cfg 5, per generated frame of one trajectory
+
+
+def cfg4_env_latency(device, horizon=50):
+    """BASELINE config 4, secondary numbers (driver-timed because they are part of this process): dim 512 depth 6, 4 x 16 latents,
+    4 discrete user-chosen actions, one generated frame per call with the KV cache carried, exactly the call
+    DynamicsWorldModelWrapper.step makes (dreamer4/env.py:445-483).  ms per env step at B = 1 and B = 16 (second of two passes)."""
+    from dreamer4_amd import DynamicsWorldModel
+    from dreamer4_amd.synthetic import randomize_weights
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG4), terminal_bias=-10.).to(device)
+    out = {}
+    for B in (1, 16):
+        g = torch.Generator(device=device).manual_seed(1)
+        acts_all = torch.randint(0, 4, (B, horizon, 1), device=device, generator=g)
+        for rep in range(2):
+            lat = torch.zeros(B, 0, 4, 16, device=device); rew = torch.zeros(B, 0, device=device); tc = None
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for t in range(horizon):
+                kw = dict(prompt_latents=lat, prompt_discrete_actions=acts_all[:, :t], prompt_rewards=rew) if t > 0 else {}
+                e, tc = m.generate(t + 1, batch_size=B, return_rewards_per_frame=True, return_terminals=True, time_cache=tc,
+                                   return_time_cache=True, generator=g, **kw)
+                lat, rew = e.latents, e.rewards
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out[f'b{B}_ms_per_env_step'] = round(1e3 * dt / horizon, 3)
+        out[f'b{B}_steps_per_sec'] = round(B * horizon / dt, 1)
+    out['workload'] = f'cfg4: dim=512 depth=6 latents=4x16, horizon {horizon}, one generate() call per env step (prompt + carried time cache), rewards + terminals'
+    return out
+
+
+def cfg5_bf16(device, lib, B=128, frames=16, reps=2):
+    """BASELINE config 5, secondary numbers: dim 1024 depth 12, 64 x 32 latents, 6 continuous (Beta) actions, B = 128 per GPU
+    (1024 / 8), H = 15, trunk GEMMs on the bf16 MFMA path.  Rollout only (the learner is the same fp32 code as config 2)."""
+    from dreamer4_amd import DynamicsWorldModel, _lib
+    from dreamer4_amd.synthetic import randomize_weights
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG5, matmul_dtype='bf16'), terminal_bias=-10.).to(device)
+    g = torch.Generator(device=device).manual_seed(1234)
+    gk = dict(return_for_policy_optimization=True, num_steps=NUM_STEPS, generator=g)
+    m.generate(frames, batch_size=B, **gk)
+    torch.cuda.synchronize()
+    lib.d4_profile_bf16_enable(5)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e = m.generate(frames, batch_size=B, **gk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    lib.d4_profile_bf16_enable(0)
+    ms, fl, cnt = C.c_double(), C.c_double(), C.c_int64()
+    _lib.check(lib.d4_profile_bf16_read(C.byref(ms), C.byref(fl), C.byref(cnt)))
+    steps = B * e.latents.shape[1]
+    ach = fl.value / max(ms.value, 1e-9) / 1e9
+    return dict(value=round(steps / dt, 1), unit='imagined steps/s', ms_per_rollout=round(1e3 * dt, 2), dtype='bf16 MFMA (fp32 accumulate / norms / softmax)',
+                workload=f'cfg5: dim=1024 depth=12 latents=64x32, 6 continuous actions, B={B}, H={frames - 1}, num_steps={NUM_STEPS}; rollout only',
+                rollout_algorithmic_tflops=round(FLOP_PER_IMAGINED_STEP_CFG5 * steps / dt / 1e12, 1),
+                roofline=dict(bound='mfma', kernel='gemm_bf16_kernel (all bf16 trunk GEMMs)', achieved=round(ach, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s',
+                              frac=round(ach / PEAK_BF16_MFMA_TFLOPS, 4), launches_timed=int(cnt.value), event_stride=5,
+                              avg_launch_us=round(1e3 * ms.value / max(cnt.value, 1), 2)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,6 +160,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the per-launch HIP-event timing of the GEMMs')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary cfg4 (decode latency) / cfg5 (bf16) measurements')
     args = ap.parse_args()
 
     from dreamer4_amd import DreamTrainer, _lib, parallel
@@ -202,6 +266,11 @@ def main():
         rollout_steps_per_sec=round(world * B_LOCAL * (HORIZON + 1) / (sum(gen_ms) / len(gen_ms) * 1e-3), 1),
         roofline=roofline,
     )
+    if world == 1 and not args.no_secondary:
+        del trainer, model
+        torch.cuda.empty_cache()
+        out['cfg4_env_step'] = cfg4_env_latency(device)
+        out['cfg5_bf16'] = cfg5_bf16(device, lib)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)

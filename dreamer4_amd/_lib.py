@@ -27,7 +27,7 @@ class Config(C.Structure):
         ('multi_token_pred_len', C.c_int32),
         ('policy_head_mlp_depth', C.c_int32), ('value_head_mlp_depth', C.c_int32),
         ('terminal_mlp_depth', C.c_int32), ('predict_terminals', C.c_int32),
-        ('reward_num_bins', C.c_int32), ('value_num_bins', C.c_int32), ('head_mlp_recipe', C.c_int32),
+        ('reward_num_bins', C.c_int32), ('value_num_bins', C.c_int32), ('matmul_bf16', C.c_int32), ('head_mlp_recipe', C.c_int32),
         ('pool_heads', C.c_int32), ('pool_dim_head', C.c_int32),
         ('gae_discount_factor', C.c_float), ('gae_lambda', C.c_float), ('ppo_eps_clip', C.c_float),
         ('policy_entropy_weight', C.c_float), ('use_delight_gating', C.c_int32),
@@ -89,6 +89,8 @@ SYMBOLS = {
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),
     'd4_learn': (_I, [_P, C.POINTER(LearnIO), _P]),
     'd4_adamw_clip': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),
+    'd4_profile_bf16_enable': (_I, [_I]),
+    'd4_profile_bf16_read': (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'd4_profile_enable': (_I, [_I]),
     'd4_profile_read': (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
     'd4_profile_classes': (_I, []),
@@ -97,6 +99,7 @@ SYMBOLS = {
     'd4_debug_buffer': (_I, [_P, C.c_char_p, C.POINTER(_P)]),
     'd4_gemm': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'd4_gemm_batched': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _L, _L, _L, _P]),
+    'd4_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'd4_rmsnorm': (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
     'd4_hl_gauss_scalar': (_I, [_P, _I, _P, _P, _I, _I, _P]),
     'd4_gae': (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace d4 {
 
@@ -489,6 +490,120 @@ __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     if (act) p.out[(int64_t)row * p.ldo + hl] = o;
 }
 
+// Head dim 64, lanes spread over (key, feature group): lane = (key j & 3) * 16 + feature group, a float4 of K / V per lane, so ONE
+// pass of the wave scores four keys at once (q . k is a 16-lane DPP row reduction) instead of one key per full-wave reduction, and
+// tanh / exp are evaluated for four keys per pass.  Keys are processed in chunks of 64 (16 passes) with an online softmax across
+// chunks, so the dependent chain is ceil((pos + 1) / 64) chunk steps + 16 independent passes each, not pos + 1 serial reductions.
+//   STAGE = true  (several queries of one (column, head): the parallel multi-frame evaluation): the chunk's K / V tiles are staged
+//                 ONCE in LDS by the block's waves (coalesced float4), every wave (= query frame) then reads them from LDS;
+//   STAGE = false (cached decode, one query per (column, head)): each K / V float4 is read exactly once — straight to registers.
+constexpr int TA_CHUNK = 64;
+template <bool STAGE>
+__global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float kv_s[];              // STAGE: [2][TA_CHUNK][64]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int unit = STAGE ? blockIdx.x : blockIdx.x * nw + w;                // (b, s, h)
+    const int units = p.B * p.S * p.H;
+    if (!STAGE && unit >= units) return;
+    const int h = unit % p.H, s = (unit / p.H) % p.S, b = unit / (p.H * p.S);
+    const int t0 = p.t0_dev ? *p.t0_dev : p.t0;
+    const int hd = p.H * 64;
+    const int cS = p.cache_S > 0 ? p.cache_S : p.S;
+    const int64_t col = (int64_t)b * cS + s, cols = (int64_t)p.cache_batch * cS;
+    const float* ck = p.cache + ((col * p.H + h) * p.Tcap) * 64;
+    const float* cv = ck + cols * p.H * p.Tcap * 64;
+    const int fg = lane & 15, kr = lane >> 4;                                  // feature group (4 floats), key residue
+    const float qscale = 0.125f;
+
+    const int rounds = STAGE ? (p.Tq + nw - 1) / nw : 1;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int tq = STAGE ? rd * nw + w : 0;
+        const bool active = tq < p.Tq;                                         // (STAGE: idle waves still help staging / hit the barriers)
+        const int row = (b * p.Tq + (active ? tq : 0)) * p.S + s;
+        const float* pr = p.proj + (int64_t)row * p.ldp;
+        const int pos = t0 + (active ? tq : 0);
+        // q: rotate-half rotary on features 4 fg .. 4 fg + 3 (partner features +-32 live 8 lanes away in the row)
+        f32x4 q4 = *reinterpret_cast<const f32x4*>(pr + h * 64 + fg * 4);
+        {
+            f32x4 part;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[e] = __shfl_xor(q4[e], 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = fg * 4 + e;
+                float sn, cs;
+                sincosf((float)pos * p.inv_freq[d & 31], &sn, &cs);
+                q4[e] = q4[e] * cs + (d < 32 ? -part[e] : part[e]) * sn;
+            }
+        }
+        float m = -FLT_MAX, l = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int nkeys = STAGE ? t0 + p.Tq : pos + 1;                          // keys any query of this block needs
+        for (int c0 = 0; c0 < nkeys; c0 += TA_CHUNK) {
+            const int cn = min(TA_CHUNK, nkeys - c0);
+            if (STAGE) {
+                __syncthreads();                                               // previous chunk fully consumed
+                for (int i = threadIdx.x; i < cn * 16; i += blockDim.x) {
+                    reinterpret_cast<f32x4*>(kv_s)[i] = reinterpret_cast<const f32x4*>(ck + (int64_t)c0 * 64)[i];
+                    reinterpret_cast<f32x4*>(kv_s + TA_CHUNK * 64)[i] = reinterpret_cast<const f32x4*>(cv + (int64_t)c0 * 64)[i];
+                }
+                __syncthreads();
+            }
+            if (!active) continue;
+            const f32x4* kt = STAGE ? reinterpret_cast<const f32x4*>(kv_s) : reinterpret_cast<const f32x4*>(ck + (int64_t)c0 * 64);
+            const f32x4* vt = STAGE ? reinterpret_cast<const f32x4*>(kv_s + TA_CHUNK * 64) : reinterpret_cast<const f32x4*>(cv + (int64_t)c0 * 64);
+            float sc[TA_CHUNK / 4];
+            float cm = -FLT_MAX;
+#pragma unroll
+            for (int ps = 0; ps < TA_CHUNK / 4; ++ps) {
+                const int j = ps * 4 + kr;
+                const bool ok = j < cn && c0 + j <= pos;                       // causal
+                const f32x4 k4 = ok ? kt[j * 16 + fg] : f32x4{0.f, 0.f, 0.f, 0.f};
+                float d = row_sum16(q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3]) * qscale;
+                if (p.softclamp > 0.f) d = tanhf(d / p.softclamp) * p.softclamp;
+                sc[ps] = ok ? d : -FLT_MAX;
+                cm = fmaxf(cm, sc[ps]);
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));                                // chunk max over the four key residues
+            const float mn = fmaxf(m, cm);
+            const float alpha = expf(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= alpha;
+#pragma unroll
+            for (int ps = 0; ps < TA_CHUNK / 4; ++ps) {
+                const int j = ps * 4 + kr;
+                if (sc[ps] > -FLT_MAX) {
+                    const float e_ = expf(sc[ps] - mn);
+                    const f32x4 v4 = vt[j * 16 + fg];
+                    l += e_;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += e_ * v4[e];
+                }
+            }
+            m = mn;
+        }
+        if (!active) continue;
+        // fold the four key residues (lanes fg, fg + 16, fg + 32, fg + 48)
+        l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16); acc[e] += __shfl_xor(acc[e], 32); }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[e] / l;
+        // belief: orthogonalise against this step's (mixed) value            D4:2049-2054
+        const f32x4 vi = *reinterpret_cast<const f32x4*>(cv + (int64_t)pos * 64 + fg * 4);
+        const float vn2 = row_sum16(vi[0] * vi[0] + vi[1] * vi[1] + vi[2] * vi[2] + vi[3] * vi[3]);
+        const float inv = 1.f / fmaxf(sqrtf(vn2), 1e-12f);
+        const float dot = row_sum16(o[0] * vi[0] + o[1] * vi[1] + o[2] * vi[2] + o[3] * vi[3]) * inv;
+        const float gate = sigmoidf(pr[3 * hd + h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (o[e] - dot * (vi[e] * inv)) * gate;
+        if (kr == 0) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.ldo + h * 64 + fg * 4) = o;
+    }
+}
+
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.t0 + p.Tq <= p.Tcap, "time attention: cache capacity %d exceeded (t0=%d, Tq=%d)", p.Tcap, p.t0, p.Tq);
     const int waves = p.B * p.Tq * p.S * p.H;
@@ -503,7 +618,17 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
 int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
     const int waves = p.B * p.Tq * p.S * p.H;
     if (waves == 0) return 0;
-    if (p.dh == 64) hipLaunchKernelGGL(time_attn_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    static const bool legacy = getenv("D4_TIME_ATTN_LEGACY") != nullptr;       // the one-key-per-reduction form (kept for head dims 16 / 32)
+    if (p.dh == 64 && !legacy && (p.ldp % 4) == 0 && (p.ldo % 4) == 0) {
+        const int units = p.B * p.S * p.H;
+        if (p.Tq == 1) hipLaunchKernelGGL(time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
+        else {
+            // one block per (column, head): min(Tq, 4) waves = query frames, the chunk's K / V staged once in LDS
+            const int nwv = p.Tq < 4 ? p.Tq : 4;
+            hipLaunchKernelGGL(time_attn64_kernel<true>, dim3(units), dim3(64 * nwv), (size_t)2 * TA_CHUNK * 64 * sizeof(float), stream, p);
+        }
+    }
+    else if (p.dh == 64) hipLaunchKernelGGL(time_attn_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else if (p.dh == 32) hipLaunchKernelGGL(time_attn_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(time_attn_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();

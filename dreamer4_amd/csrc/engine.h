@@ -69,6 +69,12 @@ struct d4_engine {
     bool warm = false;
     hipStream_t capture_stream = nullptr;             // use graphs when batch * tokens_per_frame <= this (launch-bound regime)
 
+    // ---- bf16 compute (opt-in): bf16 mirrors of every weight the trunk GEMMs read, carved from one arena of the workspace
+    bool bf16 = false;
+    uint16_t* bf16_arena = nullptr; size_t bf16_cap = 0, bf16_used = 0;
+    struct Mirror { const float* src; size_t n; uint16_t* dst; };
+    std::vector<Mirror> mirrors;
+
     // ---- bound (raw) weights
     std::vector<d4::AttnW> layer_attn;
     std::vector<d4::FfW> layer_ff;

@@ -65,6 +65,14 @@ int engine_layout(d4_engine* e, bool assign) {
     e->action_offsets = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
     e->action_sizes = reinterpret_cast<int32_t*>(alloc_bytes(sizeof(int32_t) * D4_MAX_ACTION_TYPES));
 
+    if (e->bf16) {
+        // every GEMM weight of the trunk once more in bf16: prepared images + the raw output projections (upper bound from the config)
+        const size_t per_layer = (size_t)(e->Nproj0 + hd) * D + (size_t)3 * e->inner_pad * D;
+        const size_t per_pool = (size_t)(hp + e->php + 2 * hp) * D + (size_t)D * hp;
+        const size_t extra = (size_t)(hd + c.attn_heads + 2 * hd + hd) * D + (size_t)2 * hd * dl + (size_t)2 * hd * D + (size_t)dl * (hd > D ? hd : D) + (size_t)D * hd + (size_t)D * dl;
+        e->bf16_cap = (size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096;
+        e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * sizeof(uint16_t)));
+    }
     e->slabs = fl((size_t)e->nslab * M * D);
     e->xpool = fl(M * D);
     e->cslabs = fl((size_t)e->nslab * Fr * (ns + 1) * D);
@@ -273,6 +281,32 @@ int engine_resolve(d4_engine* e) {
     return r.rc;
 }
 
+// ------------------------------------------------------------------------------------- bf16 mirrors
+// The trunk's GEMMs run on the bf16 MFMA kernel when the engine was created with matmul_bf16: engine_forward sets the thread's
+// active engine, and every GEMM issued below it swaps its weight pointer for the bf16 mirror made at prepare time.
+static thread_local d4_engine* t_bf16 = nullptr;
+
+static int mirror_weight(d4_engine* e, const float* src, size_t n, hipStream_t s) {
+    if (!e->bf16 || !src || n == 0) return 0;
+    n = (n + 7) / 8 * 8;
+    D4_REQUIRE(e->bf16_used + n <= e->bf16_cap, "bf16 weight arena exhausted (%zu + %zu > %zu)", e->bf16_used, n, e->bf16_cap);
+    uint16_t* dst = e->bf16_arena + e->bf16_used;
+    e->bf16_used += n;
+    e->mirrors.push_back({src, n, dst});
+    return cvt_f32_to_bf16(src, dst, (int64_t)n, s);
+}
+
+static int engine_gemm(GemmArgs& g, hipStream_t s) {
+    if (d4_engine* e = t_bf16) {
+        g.Wb = nullptr;
+        for (const auto& m : e->mirrors)
+            if (g.W >= m.src && g.W < m.src + m.n) { g.Wb = m.dst + (g.W - m.src); break; }
+        D4_REQUIRE(g.Wb != nullptr, "bf16 engine: a trunk GEMM weight has no bf16 mirror (M=%d N=%d K=%d)", g.M, g.N, g.K);
+        if (!gemm_bf16_applicable(g)) g.Wb = nullptr;       // e.g. K not a multiple of 32: this call stays on the fp32 kernel
+    }
+    return gemm(g, s);
+}
+
 // ------------------------------------------------------------------------------------- prepare
 static int fold_attn_rows(float* dst, int D, const float* w, const float* gamma, int rows, hipStream_t s) {
     return fold_rows(w, gamma, dst, rows, D, D, s);
@@ -287,14 +321,14 @@ static int prep_ff(const FfW& f, FfPrep& p, d4_engine* e, hipStream_t s) {
 static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                        int flags, const float* bias, const float* R, int ldr, hipStream_t s) {
     GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS};
-    return gemm(g, s);
+    return engine_gemm(g, s);
 }
 
 static int gemm_c2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags,
                    const float* bias, const float* R, int ldr, float* C2, int S, int ns, int has_agent, hipStream_t s) {
     GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS, 0};
     g.C2 = C2; g.ldc2 = N; g.c2_S = S; g.c2_lo = 1; g.c2_hi = 1 + ns; g.c2_last = has_agent;
-    return gemm(g, s);
+    return engine_gemm(g, s);
 }
 
 int engine_prepare(d4_engine* e, hipStream_t s) {
@@ -351,6 +385,37 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
     if ((rc = gemm_simple(e->latent_w, D, e->lq_out.to_out, hd, e->lout_w, hd, dl, hd, D, GEMM_TRANS_B, nullptr, nullptr, 0, s))) return rc;
     }
 
+    // ---- bf16 mirrors of everything the trunk's GEMMs read (prepared images above + the raw output projections)
+    if (e->bf16) {
+        e->mirrors.clear(); e->bf16_used = 0;
+        auto mir = [&](const float* w, size_t n) { return mirror_weight(e, w, n, s); };
+        for (int l = 0; l < c.depth; ++l) {
+            if ((rc = mir(e->proj_w[l], (size_t)(l == 0 ? e->Nproj0 : e->Nproj) * D))) return rc;
+            if ((rc = mir(e->layer_attn[l].to_out, (size_t)D * hd))) return rc;
+        }
+        for (int l = 0; l <= c.depth; ++l) {
+            if ((rc = mir(e->ffp[l].w1, (size_t)2 * e->inner_pad * D))) return rc;
+            if ((rc = mir(e->ffp[l].w2, (size_t)D * e->inner_pad))) return rc;
+        }
+        for (int p = 0; p < c.depth; ++p) {
+            if ((rc = mir(e->pq_w[p], (size_t)(hp + e->php) * D))) return rc;
+            if ((rc = mir(e->pkv_w[p], (size_t)2 * hp * D))) return rc;
+            if ((rc = mir(e->pools[p].to_out, (size_t)D * hp))) return rc;
+        }
+        if ((rc = mir(e->cq_w, (size_t)(hd + h) * D))) return rc;
+        if ((rc = mir(e->ckv_w, (size_t)2 * hd * D))) return rc;
+        if ((rc = mir(e->cross.to_out, (size_t)D * hd))) return rc;
+        if (ns == n) {
+            if ((rc = mir(e->lin_w, (size_t)D * dl))) return rc;
+            if ((rc = mir(e->lout_w, (size_t)dl * D))) return rc;
+        } else {
+            if ((rc = mir(e->lin_kv_w, (size_t)2 * hd * dl))) return rc;
+            if ((rc = mir(e->lq_in.to_out, (size_t)D * hd))) return rc;
+            if ((rc = mir(e->lout_kv_w, (size_t)2 * hd * D))) return rc;
+            if ((rc = mir(e->lout_w, (size_t)dl * hd))) return rc;
+        }
+    }
+
     int32_t offs[D4_MAX_ACTION_TYPES] = {0}, sizes[D4_MAX_ACTION_TYPES] = {0};
     int o = 0;
     for (int a = 0; a < e->na; ++a) { offs[a] = o; sizes[a] = c.num_discrete_actions[a]; o += sizes[a]; }
@@ -367,11 +432,11 @@ static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const fl
     int rc;
     GemmArgs g1{x, ldx, fp.w1, e->D, e->ffh, e->inner_pad, fp.b1, nullptr, 0, rows, 2 * e->inner_pad, e->D,
                 GEMM_RMS_ROWSCALE | GEMM_SWIGLU, RMS_EPS, 2.0 * rows * (2.0 * e->inner) * e->D};
-    if ((rc = gemm(g1, s))) return rc;
+    if ((rc = engine_gemm(g1, s))) return rc;
     GemmArgs g2{e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, out_b, x, ldx, rows, e->D, e->inner_pad, 0, RMS_EPS,
                 2.0 * rows * (double)e->D * e->inner};
     if (y_compact) { g2.C2 = y_compact; g2.ldc2 = e->D; g2.c2_S = S; g2.c2_lo = 1; g2.c2_hi = 1 + e->c.num_spatial_tokens; g2.c2_last = has_agent; }
-    return gemm(g2, s);
+    return engine_gemm(g2, s);
 }
 
 static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s, const float* hiddens = nullptr,
@@ -393,7 +458,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         if ((rc = pool_mix(pm, s))) return rc;
         GemmArgs gv{e->pool_u, c.pool_heads * D, e->pkv_w[p] + (size_t)hp * D, D, e->pool_att, hp, nullptr, nullptr, 0, M, 64, D, 0, RMS_EPS};
         gv.batch = c.pool_heads; gv.strideA = D; gv.strideW = (int64_t)64 * D; gv.strideC = 64;
-        if ((rc = gemm(gv, s))) return rc;
+        if ((rc = engine_gemm(gv, s))) return rc;
     } else {
     if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
     SmallAttnArgs sa{};
@@ -417,8 +482,19 @@ void engine_drop_graphs(d4_engine* e) {
     e->graphs.clear();
 }
 
+static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
+                               const int64_t* tasks, bool need_agent, hipStream_t s, const int* t0_dev);
+
 int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
                    const int64_t* tasks, bool need_agent, hipStream_t s, const int* t0_dev) {
+    t_bf16 = e->bf16 ? e : nullptr;           // the trunk's GEMMs below pick their bf16 weight mirrors; heads and learner stay fp32
+    const int rc = engine_forward_impl(e, latents, B, Tq, t0, step_log2, tasks, need_agent, s, t0_dev);
+    t_bf16 = nullptr;
+    return rc;
+}
+
+static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
+                               const int64_t* tasks, bool need_agent, hipStream_t s, const int* t0_dev) {
     const d4_config& c = e->c;
     D4_REQUIRE(e->prepared, "engine not prepared");
     D4_REQUIRE(B >= 1 && B <= e->maxB, "batch %d exceeds max_batch %d", B, e->maxB);
@@ -688,6 +764,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->nslab = 2 * c.depth + 1;
     e->na = c.num_discrete_action_types;
     e->nc = c.num_continuous_actions;
+    e->bf16 = c.matmul_bf16 != 0;
     D4_REQUIRE(e->nc >= 0 && e->nc <= 64, "num_continuous_actions out of range");
     e->A = 0;
     for (int a = 0; a < e->na; ++a) e->A += c.num_discrete_actions[a];
@@ -988,6 +1065,8 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     return 0;
 }
 
+int d4_profile_bf16_enable(int stride) { d4::gemm_bf16_profile_enable(stride); return 0; }
+int d4_profile_bf16_read(double* ms, double* flops, int64_t* count) { return d4::gemm_bf16_profile_read(ms, flops, count); }
 int d4_profile_enable(int on) { return d4::gemm_profile_enable(on); }
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { return d4::gemm_profile_read(ms, flops, count, nclass); }
 int d4_profile_classes(void) { return d4::gemm_profile_classes(); }
@@ -1025,6 +1104,13 @@ int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, 
     d4::GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
     g.batch = batch; g.strideA = strideA; g.strideW = strideW; g.strideC = strideC;
     return d4::gemm(g, static_cast<hipStream_t>(stream));
+}
+
+int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
+                 const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream) {
+    d4::GemmArgs g{A, lda, reinterpret_cast<const float*>(Wb), ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.Wb = Wb;
+    return d4::gemm_bf16(g, static_cast<hipStream_t>(stream));
 }
 
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim, float eps, void* stream) {

@@ -346,7 +346,8 @@ static hipEvent_t prof_event() {
     return e;
 }
 
-bool gemm_profile_active() { return g_prof_mask != 0; }
+bool gemm_bf16_profile_active();
+bool gemm_profile_active() { return g_prof_mask != 0 || gemm_bf16_profile_active(); }
 
 int gemm_profile_enable(int mask) {
     g_prof_stride = (mask >> 16) > 0 ? (mask >> 16) : 1;
@@ -685,6 +686,7 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(!((p.flags & GEMM_RMS_ROWSCALE) && ta), "gemm: rms rowscale needs a non-transposed A");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (p.N % 64) != 0), "gemm: swiglu needs N %% 64 == 0 (packed pairs)");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (ta || tb)), "gemm: swiglu epilogue is forward-only");
+    if (p.Wb) return gemm_bf16(p, stream);
     // test hook: 100 + c forces configuration c of the second family, 0 .. N_TILE_CFG-1 a configuration of this one
     if (g_forced_cfg >= 100 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);
     if (gemm_skinny_applicable(p)) return gemm_skinny(p, stream);

@@ -1,0 +1,277 @@
+// bf16 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) — the opt-in compute type of the trunk
+// (BASELINE config 5: "MFMA bf16"; the headline config 2 stays fp32, as the reference computes).
+//
+//   C[m, n] = epilogue( rowscale[m] * sum_k bf16(A[m, k]) * Wb[n, k] )          A fp32 [M][K], Wb bf16 [N][K], C fp32
+//
+// Weights are converted to bf16 ONCE at engine prepare (gamma-folded images and the raw output projections alike);
+// activations stay fp32 in HBM (residual stream, attention-pool context, every glue kernel is unchanged) and are rounded to
+// bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) on their way into LDS, which is numerically the same as storing them in
+// bf16.  Norms stay fp32: the folded RMSNorm's 1/rms is accumulated from the fp32 registers before the rounding.
+// Same epilogues as gemm_kernel (row scale, bias, SiLU, SiLU-GLU pairing, residual, accumulate, row-compacted second output);
+// the 32x32 C/D layout is dtype independent on gfx950, so the epilogue code is the fp32 kernel's.
+//
+// Staging is global -> registers -> LDS, double-buffered in LDS with the loads of k-tile j+1 in flight under the MFMAs of
+// k-tile j.  LDS rows are [BK + 8] bf16 (16 bytes of padding: the 16 lanes a ds_read_b128 services together land on 16
+// distinct 16-byte slots).  A 32x32x16 MFMA takes 8 consecutive k per lane (lane >> 5 selects the k half), so fragments
+// are single ds_read_b128 and the fp32 -> bf16 staging writes are ds_write_b128 of 8 converted values.
+#include "common.h"
+#include <hip/hip_ext.h>
+#include "kernels.h"
+#include <stdlib.h>
+#include <vector>
+
+namespace d4 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WGM, int WGN, int BK>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
+    static_assert(BK == 32 || BK == 64, "k-tile");
+    constexpr int LDS_LD = BK + 8;                  // bf16 elements per LDS row
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+    constexpr int G = BK / 8;                       // 8-element groups per tile row
+    constexpr int A_G = BM * G / NT, B_G = BN * G / NT;
+    static_assert(TM >= 1 && TN >= 1 && A_G >= 1 && B_G >= 1, "tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [2][BM][LDS_LD]
+    __bf16* Bs = As + 2 * BM * LDS_LD;                                // [2][BN][LDS_LD]
+    float* rowscale_s = reinterpret_cast<float*>(Bs + 2 * BN * LDS_LD);   // [BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    int bid = blockIdx.x;
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    {
+        const int nblk = nbm * nbn, nx = 8;
+        const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    const int bm0 = (bid / nbn) * BM, bn0 = (bid % nbn) * BN;
+    const int bz = blockIdx.y;
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wb) + bz * p.strideW;
+    p.A += bz * p.strideA; p.C += bz * p.strideC;
+    if (p.R) p.R += bz * p.strideC;
+
+    const int rowsA = min(BM, p.M - bm0), rowsB = min(BN, p.N - bn0);
+    auto uniform_rsrc = [](const void* base, int64_t bytes) {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+    };
+    // rows past the matrix edge fall outside num_records and read as zeros
+    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(p.A + (int64_t)bm0 * p.lda, ((int64_t)(rowsA - 1) * p.lda + p.K) * 4);
+    const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(Wb + (int64_t)bn0 * p.ldw, ((int64_t)(rowsB - 1) * p.ldw + p.K) * 2);
+
+    f32x4 ra[A_G][2];
+    f32x4 rb[B_G];                                  // 8 bf16 as 16 raw bytes
+    float ssq[A_G];
+#pragma unroll
+    for (int i = 0; i < A_G; ++i) ssq[i] = 0.f;
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_G; ++i) {
+            const int idx = tid + i * NT, r = idx / G, c = (idx % G) * 8;
+            const uint32_t off = (uint32_t)((r * p.lda + k0 + c) * 4);
+            ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0));
+            ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off + 16, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < B_G; ++i) {
+            const int idx = tid + i * NT, r = idx / G, c = (idx % G) * 8;
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (uint32_t)((r * p.ldw + k0 + c) * 2), 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        __bf16* as = As + buf * BM * LDS_LD;
+        __bf16* bs = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < A_G; ++i) {
+            const int idx = tid + i * NT, r = idx / G, c = (idx % G) * 8;
+            const f32x4 v0 = ra[i][0], v1 = ra[i][1];
+            bf16x8 o;
+            o[0] = (__bf16)v0[0]; o[1] = (__bf16)v0[1]; o[2] = (__bf16)v0[2]; o[3] = (__bf16)v0[3];
+            o[4] = (__bf16)v1[0]; o[5] = (__bf16)v1[1]; o[6] = (__bf16)v1[2]; o[7] = (__bf16)v1[3];
+            *reinterpret_cast<bf16x8*>(as + r * LDS_LD + c) = o;
+            ssq[i] = ssq[i] + ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < B_G; ++i) {
+            const int idx = tid + i * NT, r = idx / G, c = (idx % G) * 8;
+            *reinterpret_cast<f32x4*>(bs + r * LDS_LD + c) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = p.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const __bf16* as = As + cur * BM * LDS_LD + (wm * TM * 32 + lrow) * LDS_LD + lhalf * 8;
+        const __bf16* bs = Bs + cur * BN * LDS_LD + (wn * TN * 32 + lrow) * LDS_LD + lhalf * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDS_LD + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDS_LD + ks * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (p.flags & GEMM_RMS_ROWSCALE) {
+#pragma unroll
+        for (int i = 0; i < A_G; ++i) {
+            float s = ssq[i];
+            s += dpp_f<0xB1>(s);
+            s += dpp_f<0x4E>(s);                       // G (4 or 8) consecutive lanes share one row
+            if constexpr (G == 8) s += dpp_f<0x141>(s);
+            const int idx = tid + i * NT;
+            if ((idx % G) == 0) rowscale_s[idx / G] = rsqrtf(s / (float)p.K + p.rms_eps);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lr = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+            const int gm = bm0 + lr;
+            if (gm >= p.M) continue;
+            const float rs = (p.flags & GEMM_RMS_ROWSCALE) ? rowscale_s[lr] : 1.f;
+            if (swiglu) {
+                if constexpr (TN % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < TN; j += 2) {
+                        const int gn = bn0 + wn * TN * 32 + j * 32 + lrow;       // packed column of the value
+                        if (gn >= p.N) continue;
+                        float val = acc[i][j][e] * rs, gate = acc[i][j + 1][e] * rs;
+                        if (p.bias) { val += p.bias[gn]; gate += p.bias[gn + 32]; }
+                        const int on = (gn / 64) * 32 + (gn % 64);
+                        p.C[(int64_t)gm * p.ldc + on] = val * siluf(gate);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int gn = bn0 + wn * TN * 32 + j * 32 + lrow;
+                    if (gn >= p.N) continue;
+                    float v = acc[i][j][e] * rs;
+                    if (p.bias) v += p.bias[gn];
+                    if (p.flags & GEMM_SILU) v = siluf(v);
+                    if (p.R) v += p.R[(int64_t)gm * p.ldr + gn];
+                    if (p.flags & GEMM_ACCUMULATE) v += p.C[(int64_t)gm * p.ldc + gn];
+                    p.C[(int64_t)gm * p.ldc + gn] = v;
+                    if (p.C2) {
+                        const int ts = gm % p.c2_S;
+                        const int keep = p.c2_hi - p.c2_lo;
+                        const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : ((p.c2_last && ts == p.c2_S - 1) ? keep : -1);
+                        if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + p.c2_last) + rank) * p.ldc2 + gn] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- fp32 -> bf16 weight images (engine prepare) ---------------------------------------------------------------
+__global__ void cvt_bf16_kernel(const float* src, __bf16* dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (__bf16)src[i];
+}
+int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    int64_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)g), dim3(256), 0, s, src, reinterpret_cast<__bf16*>(dst), n);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- per-launch timing (bench.py's cfg-5 leg) ----------------------------------------------------------------------------------
+struct Bf16Prof { hipEvent_t a, b; double flops; };
+static std::vector<Bf16Prof> g_bprof;
+static int g_bprof_stride = 0, g_bprof_tick = 0;        // 0 = off; n = every n-th launch carries an event pair
+void gemm_bf16_profile_enable(int stride) { g_bprof_stride = stride; g_bprof_tick = 0; }
+bool gemm_bf16_profile_active() { return g_bprof_stride > 0; }
+int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count) {
+    *ms = 0; *flops = 0; *count = 0;
+    for (auto& r : g_bprof) {
+        D4_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        D4_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        *ms += t; *flops += r.flops; *count += 1;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_bprof.clear();
+    return 0;
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK>
+static int launch_bf16(const GemmArgs& p, hipStream_t stream) {
+    constexpr int LDS_LD = BK + 8;
+    const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD) * 2 + BM * sizeof(float);
+    auto k = gemm_bf16_kernel<BM, BN, WGM, WGN, BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
+    if (g_bprof_stride > 0 && (g_bprof_tick++ % g_bprof_stride) == 0) {
+        Bf16Prof r{};
+        D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));
+        r.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+        hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, r.a, r.b, 0, p);
+        g_bprof.push_back(r);
+    } else {
+        hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+    }
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm_bf16_applicable(const GemmArgs& p) {
+    return p.Wb != nullptr && !(p.flags & (GEMM_TRANS_A | GEMM_TRANS_B)) && (p.K % 32) == 0 && (p.lda % 4) == 0 && (p.ldw % 8) == 0 &&
+           ((uintptr_t)p.Wb % 16) == 0 && (p.strideW % 8) == 0;
+}
+
+// tile choice by rule (every configuration sums k in the same order with the same MFMA: identical bits)
+int gemm_bf16(const GemmArgs& p, hipStream_t stream) {
+    D4_REQUIRE(gemm_bf16_applicable(p), "gemm_bf16: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
+    const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+    const int nb = p.batch > 0 ? p.batch : 1;
+    const bool k64 = (p.K % 64) == 0;
+    const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
+    if (t128 >= 200 && p.N > 64) return k64 ? launch_bf16<128, 128, 2, 2, 64>(p, stream) : launch_bf16<128, 128, 2, 2, 32>(p, stream);
+    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 200))
+        return k64 ? launch_bf16<64, 128, 2, 2, 64>(p, stream) : launch_bf16<64, 128, 2, 2, 32>(p, stream);
+    return k64 ? launch_bf16<64, 64, 2, 2, 64>(p, stream) : launch_bf16<64, 64, 2, 2, 32>(p, stream);
+}
+
+}  // namespace d4

@@ -30,9 +30,16 @@ struct GemmArgs {
     float* C2 = nullptr; int ldc2 = 0, c2_S = 0, c2_lo = 0, c2_hi = 0, c2_last = 1;    // c2_last = 0: the frame has no trailing agent row
     // strided batch (blockIdx.y): A += b * strideA, W += b * strideW, C/R += b * strideC   (elements)
     int batch = 1; int64_t strideA = 0, strideW = 0, strideC = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
+    const uint16_t* Wb = nullptr;      // bf16 image of W (same [N][ldw] layout): when set the call runs on the bf16 MFMA kernel (gemm_bf16.hip)
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
+// bf16 MFMA path (gemm_bf16.hip): A fp32 rounded to bf16 on the way into LDS, W pre-converted, fp32 accumulate / epilogue
+bool gemm_bf16_applicable(const GemmArgs& p);
+int gemm_bf16(const GemmArgs& p, hipStream_t stream);
+int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
+void gemm_bf16_profile_enable(int stride);
+int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count);
 // second fp32 family (gemm2.hip): 16x16x4 MFMA fed by an LDS-DMA ring; non-transposed operands, K % 32 == 0
 bool gemm2_applicable(const GemmArgs& p);
 bool gemm2_config_valid(int c, const GemmArgs& p);

@@ -43,12 +43,22 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
         raise ValueError(f'unknown objective {objective}')
     dev = model.device
     exp = experience.to(dev)
-    if exp.agent_embed is None:
-        raise NotImplementedError('learn_from_experience needs the agent embeddings stored by generate(store_agent_embed=True); '
-                                  're-running the trunk (dreamer4.py:6045-6070) is not implemented')
     assert all(v is not None for v in (exp.log_probs, exp.actions, exp.values, exp.rewards, exp.step_size)), \
         'the generations need to contain the log probs, values, and rewards for policy optimization'
-    agent = exp.agent_embed.float().contiguous()
+    if exp.agent_embed is None:
+        # generate(store_agent_embed=False): recompute the agent embeddings with one parallel forward over the stored latents at
+        # the clean signal level, conditioned on the stored actions (dreamer4.py:6045-6070)
+        if exp.latents is None:
+            raise ValueError('an Experience without agent embeddings needs its latents to recompute them')
+        if exp.latents.shape[1] != exp.values.shape[1]:
+            raise NotImplementedError('recomputing agent embeddings for an experience with prompt frames is not implemented')
+        tasks = getattr(exp, 'tasks', None)
+        with torch.no_grad():
+            _, (agent, _) = model.forward(latents=exp.latents, signal_levels=model.max_steps - 1, step_sizes=exp.step_size,
+                                          discrete_actions=exp.actions.discrete, continuous_actions=exp.actions.continuous, tasks=tasks)
+    else:
+        agent = exp.agent_embed
+    agent = agent.float().contiguous()
     B, T = agent.shape[:2]
     na = len(model.num_discrete_actions)
 

@@ -161,6 +161,7 @@ class DynamicsWorldModel(nn.Module):
         normalize_advantages=None,
         policy_entropy_weight=.01,
         head_mlp_recipe='pre_rms',
+        matmul_dtype='fp32',
         **kwargs,
     ):
         """`head_mlp_recipe` is not a reference argument: it names the layer recipe of x_mlps_pytorch's normed MLP (see MLP_RECIPES)."""
@@ -168,6 +169,11 @@ class DynamicsWorldModel(nn.Module):
         if head_mlp_recipe not in MLP_RECIPES:
             raise ValueError(f'head_mlp_recipe must be one of {sorted(MLP_RECIPES)}')
         self.head_mlp_recipe = head_mlp_recipe
+        # 'bf16' (not a reference argument): the trunk's GEMMs run on the bf16 MFMA path — bf16 weights and activations, fp32
+        # accumulation, norms, softmax and residual stream (BASELINE config 5); the default is the reference's own fp32 arithmetic
+        if matmul_dtype not in ('fp32', 'bf16'):
+            raise ValueError("matmul_dtype must be 'fp32' or 'bf16'")
+        self.matmul_dtype = matmul_dtype
         for k, v in kwargs.items():
             if k not in _UNSUPPORTED_DEFAULTS:
                 raise TypeError(f'unknown argument {k!r}')
@@ -393,6 +399,7 @@ class DynamicsWorldModel(nn.Module):
         c.terminal_mlp_depth, c.predict_terminals = self.terminal_mlp_depth, int(self.predict_terminals)
         c.reward_num_bins, c.value_num_bins = self.reward_num_bins, self.value_num_bins
         c.head_mlp_recipe = MLP_RECIPES[self.head_mlp_recipe]
+        c.matmul_bf16 = int(self.matmul_dtype == 'bf16')
         c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
         c.gae_discount_factor, c.gae_lambda, c.ppo_eps_clip = self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip
         c.policy_entropy_weight = self.policy_entropy_weight

@@ -47,6 +47,8 @@ typedef struct d4_config {
     int32_t multi_token_pred_len;
     int32_t policy_head_mlp_depth, value_head_mlp_depth, terminal_mlp_depth, predict_terminals;
     int32_t reward_num_bins, value_num_bins;
+    int32_t matmul_bf16;                        /* 1: trunk GEMMs on the bf16 MFMA path (bf16 weights + activations, fp32 accumulate, fp32 norms /
+                                                   softmax / residual stream); 0: fp32 MFMA as the reference computes (default) */
     int32_t head_mlp_recipe;                    /* D4_MLP_PRE_RMS / D4_MLP_POST_LAYER: layer recipe of the policy / value / terminal MLPs (engine.h) */
     int32_t pool_heads, pool_dim_head;          /* AttentionPool defaults 4 x 64 (D4:2147-2148) */
     /* learn_from_experience hyper-parameters (D4:4731-4744) */
@@ -196,6 +198,9 @@ int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_
  * (mask >> 16)-th launch (0 -> every launch) of an enabled configuration carries a HIP event pair on its dispatch (launch stream); d4_profile_read sums elapsed ms / algorithmic flops /
  * launches per configuration and clears the log.  d4_profile_classes() configurations exist; d4_profile_class_name(c) is the
  * prefix of the kernel name rocprofv3 reports for configuration c ("gemm_kernel<BM, BN, WGM, WGN, BK, 1"). */
+/* bf16 path: every `stride`-th bf16 GEMM launch carries an event pair (0 = off); read sums ms / flops / launches and clears. */
+int d4_profile_bf16_enable(int stride);
+int d4_profile_bf16_read(double* ms, double* flops, int64_t* count);
 int d4_profile_enable(int mask);
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int d4_profile_classes(void);
@@ -216,6 +221,9 @@ int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
 int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
                     const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int batch,
                     int64_t strideA, int64_t strideW, int64_t strideC, void* stream);
+/* the bf16 MFMA kernel alone: A fp32 [M][lda] (rounded to bf16 on the way in), Wb bf16 [N][ldw] (raw 16-bit patterns), C fp32 */
+int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
+                 const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
                float eps, void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,

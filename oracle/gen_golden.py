@@ -197,6 +197,21 @@ def gen_postln():
     exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
     out['cached_margin'] = np.array(min_margin(e, nz, cfg))
     learn_into(out, m, e, ('ppo', 'pmpo'))
+    # an experience generated with store_agent_embed=False: learn_from_experience re-runs the world model over the stored latents
+    # to get the agent embeddings (D4:6045-6070)
+    nz = make_noise(cfg, 4, 3, 902)
+    with injected(nz):
+        e2 = m.generate(4, batch_size=3, return_for_policy_optimization=True, store_agent_embed=False, return_terminals=False)
+    assert e2.agent_embed is None
+    exp_dict_noembed = dict(latents=e2.latents, rewards=e2.rewards, values=e2.values, log_probs=e2.log_probs.discrete, actions=e2.actions.discrete,
+                            lens=e2.lens, terminals=e2.terminals, unembeds=e2.old_action_unembeds.discrete)
+    for k, v in exp_dict_noembed.items():
+        out['noembed_' + k] = npy(v)
+    m.zero_grad()
+    pl_, vl_ = m.learn_from_experience(e2, objective='ppo')
+    pl_.backward(); vl_.backward()
+    out['noembed_ppo_policy_loss'], out['noembed_ppo_value_loss'] = npy(pl_), npy(vl_)
+    out['noembed_ppo_grad_unembed'] = npy(m.action_embedder.discrete_action_unembed.grad)
     np.savez(os.path.join(OUT, 'postln.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('postln margin', out['cached_margin'], 'lens', out['cached_lens'])
 

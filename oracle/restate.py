@@ -776,8 +776,17 @@ def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, 
     gate_temp = cfg.delight_temperature if delight_temperature is None else delight_temperature
     normalize = (objective != 'pmpo') if normalize_advantages is None else normalize_advantages
     returns, old_values, adv, mask = returns_and_advantage(cfg, exp, normalize=normalize, eps=eps)
-    agent_embeds = exp['agent_embed'].detach()
     na, nc = len(cfg.num_discrete_actions), cfg.num_continuous_actions
+    if exp.get('agent_embed') is None:
+        # generate(store_agent_embed=False): the agent embeddings are recomputed with ONE parallel forward over the stored
+        # latents at the clean signal level, conditioned on the stored actions  D4:6045-6070
+        lat = exp['latents']
+        sig = torch.full(lat.shape[:2], cfg.max_steps - 1, dtype=torch.long)
+        with torch.no_grad():
+            _, agent_embeds, _ = wm_forward(cfg, W, lat, sig, exp['step_size'], exp.get('actions') if na > 0 else None, None, None,
+                                            cont_actions=exp.get('actions_cont') if nc > 0 else None)
+    else:
+        agent_embeds = exp['agent_embed'].detach()
     Tn = agent_embeds.shape[1]
 
     pe = policy_head(cfg, W, agent_embeds)

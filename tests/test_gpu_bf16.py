@@ -1,0 +1,92 @@
+"""GPU: the opt-in bf16 MFMA path of the trunk (BASELINE config 5: "MFMA bf16").  bf16 weights + activations, fp32 accumulation,
+norms, softmax and residual stream.  Stated error: the kernel alone is exact up to fp32 summation order against a reference
+computed from the SAME bf16-rounded operands; the engine in bf16 stays within 3e-2 (absolute, on latents in [-1, 1], values and
+agent embeddings of unit scale) of the engine in fp32 on identical weights and noise at the config-5 shape."""
+import ctypes as C
+
+import pytest
+import torch
+
+from dreamer4_amd import DynamicsWorldModel, _lib
+from util import make_noise, oracle_config, randomize_weights, small_model
+
+pytestmark = pytest.mark.gpu
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize('M,N,K,flags', [(128, 128, 64, 0), (3584, 512, 512, 0), (200, 300, 96, 1), (1920, 2752, 1024, 5), (45, 388, 32, 3),
+                                         (1920, 1552, 1024, 1), (17, 64, 2752, 0), (8192, 1024, 32, 1)])
+def test_gemm_bf16_kernel(M, N, K, flags):
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g)
+    b = torch.randn(N, device='cuda', generator=g)
+    swiglu = bool(flags & _lib.GEMM_SWIGLU)
+    R = None if swiglu else torch.randn(M, N, device='cuda', generator=g)
+    Wb = W.to(torch.bfloat16).contiguous()
+    Nout = N // 2 if swiglu else N
+    out = torch.full((M, Nout), float('nan'), device='cuda')
+    _lib.check(lib.d4_gemm_bf16(_lib.ptr(A), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, 1.1920929e-07, stream()))
+    Ad, Wd = A.to(torch.bfloat16).double(), Wb.double()
+    ref = Ad @ Wd.t()
+    if flags & _lib.GEMM_RMS_ROWSCALE:
+        ref = ref * torch.rsqrt(A.double().pow(2).mean(-1, keepdim=True) + 1.1920929e-07)      # fp32 norm of the UNROUNDED activations
+    ref = ref + b.double()
+    if flags & _lib.GEMM_SILU:
+        ref = torch.nn.functional.silu(ref)
+    if swiglu:
+        r = ref.reshape(M, N // 64, 2, 32)
+        ref = (r[:, :, 0] * torch.nn.functional.silu(r[:, :, 1])).reshape(M, N // 2)
+    if R is not None:
+        ref = ref + R.double()
+    err = (out.double() - ref).abs().max().item()
+    tol = 3e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
+    assert err <= tol, f'M{M} N{N} K{K} flags{flags}: err {err:.3e} > {tol:.3e}'
+
+
+def _pair(kw, seed=0):
+    torch.manual_seed(seed)
+    a = randomize_weights(DynamicsWorldModel(**kw), seed=seed)
+    b = DynamicsWorldModel(**kw, matmul_dtype='bf16')
+    b.load_state_dict(a.state_dict())
+    return a.cuda(), b.cuda()
+
+
+def test_small_engine_bf16_tracks_fp32():
+    kw = dict(dim=64, dim_latent=8, num_latent_tokens=6, depth=4, time_block_every=2, attn_heads=2, num_discrete_actions=4)
+    a, b = _pair(kw)
+    cfg = oracle_config(a)
+    nz = make_noise(cfg, 4, 3, 7)
+    ea = a.generate(4, batch_size=3, return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, noise=nz)
+    eb = b.generate(4, batch_size=3, return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, noise=nz)
+    d = (ea.latents - eb.latents).abs().max().item()
+    assert 0. < d < 3e-2, d            # not bit-identical (it really ran in bf16), and close
+    assert (ea.values - eb.values).abs().max().item() < 0.2           # values live on [-20, 20]
+
+
+def test_config5_shape_bf16_vs_fp32_at_the_per_gpu_batch():
+    """dim 1024, depth 12, 64 x 32 latents, 6 continuous (Beta) actions, B = 128 (= 1024 / 8 GPUs), 3 frames x (4 + 1) evaluations:
+    the bf16 engine against the fp32 engine on identical weights and noise."""
+    kw = dict(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_continuous_actions=6)
+    a, b = _pair(kw)
+    with torch.no_grad():
+        for m in (a, b):
+            m.action_embedder.continuous_action_unembed.mul_(30.)
+    cfg = oracle_config(a)
+    B, T = 128, 3
+    nz = make_noise(cfg, T, B, 3)
+    gk = dict(return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, return_terminals=False)
+    ea = a.generate(T, batch_size=B, noise=nz, **gk)
+    eb = b.generate(T, batch_size=B, noise=nz, **gk)
+    lat = (ea.latents - eb.latents).abs()
+    emb = (ea.agent_embed - eb.agent_embed).abs()
+    print(f'\\ncfg5 bf16 vs fp32: latents max {lat.max().item():.3e} mean {lat.mean().item():.3e} | agent_embed max {emb.max().item():.3e} '
+          f'(scale {ea.agent_embed.abs().max().item():.2f}) | values max {(ea.values - eb.values).abs().max().item():.3e}')
+    assert lat.max().item() < 3e-2 and lat.mean().item() < 3e-3
+    assert emb.max().item() < 3e-2 * max(1., ea.agent_embed.abs().max().item())
+    # frame 0's Beta parameters come from one evaluation chain: the sampled continuous actions agree to bf16 accuracy
+    pa, pb = ea.old_action_unembeds.continuous[:, 0], eb.old_action_unembeds.continuous[:, 0]
+    assert (pa - pb).abs().max().item() < 2e-2 * pa.abs().max().item()            # raw parameters of scale ~25: 1-2 % relative

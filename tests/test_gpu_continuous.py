@@ -135,3 +135,19 @@ def test_continuous_generate_and_learn_vs_oracle_on_fresh_models(kw):
         for k, v in Wg.items():
             if v.requires_grad and v.grad is not None:
                 close(P[k].grad, v.grad, atol=5e-6 + 2e-4 * v.grad.abs().max().item(), rtol=2e-3)
+
+
+def test_learn_without_stored_agent_embeddings_vs_reference_fixture():
+    """generate(store_agent_embed=False): learn_from_experience recomputes the agent embeddings with one parallel forward over the
+    stored latents (dreamer4.py:6045-6070) — here through d4_wm_forward."""
+    g = load_golden('postln.npz')
+    m = golden_model('weights_postln.npz').cuda()
+    exp = Experience(latents=t(g['noembed_latents']), agent_embed=None, rewards=t(g['noembed_rewards']), values=t(g['noembed_values']),
+                     log_probs=Actions(t(g['noembed_log_probs']), None), actions=Actions(t(g['noembed_actions']), None), lens=t(g['noembed_lens']),
+                     terminals=t(g['noembed_terminals']), is_truncated=~t(g['noembed_terminals']),
+                     old_action_unembeds=Actions(t(g['noembed_unembeds']), None), step_size=16)
+    pl, vl = m.learn_from_experience(exp, objective='ppo')
+    close(pl, g['noembed_ppo_policy_loss'], atol=1e-5); close(vl, g['noembed_ppo_value_loss'], atol=1e-5)
+    pl.backward(retain_graph=True); vl.backward()
+    ref = t(g['noembed_ppo_grad_unembed'])
+    close(m.action_embedder.discrete_action_unembed.grad, ref, atol=2e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-3)

@@ -499,3 +499,37 @@ def test_all_terminated_early_exit_also_truncates_the_time_cache():
     e, tc = m.generate(4, batch_size=2, return_for_policy_optimization=True, return_time_cache=True, noise=nz)
     assert e.latents.shape[1] == 1 and bool(e.terminals.all())
     assert tc.frames == 1 and tc.kv().shape[-2] == 1
+
+
+def test_config4_env_wrapper_pattern_at_full_size_vs_oracle():
+    """BASELINE config 4 at its real size: dim 512, depth 6, 4 x 16 latents (one spatial token per latent token), 4 discrete actions
+    chosen by the environment's user (uniform random), B = 1, horizon 50, driven exactly as DynamicsWorldModelWrapper.step does
+    (dreamer4/env.py:445-483): one generated frame per call, every previous latent / action / reward passed back as the prompt, the
+    time KV cache carried, rewards and terminals returned.  50 chained calls against the oracle's 50 chained calls."""
+    from dreamer4_amd import DynamicsWorldModel
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=6, num_discrete_actions=4),
+                          terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, H = 1, 50
+    nz = make_noise(cfg, H, B, 77)
+    user_actions = torch.randint(0, 4, (B, H, 1), generator=torch.Generator().manual_seed(5))
+    m = m.cuda()
+    lat_o = torch.zeros(B, 0, 4, 16); rew_o = torch.zeros(B, 0); cache = None
+    lat_e = torch.zeros(B, 0, 4, 16, device='cuda'); rew_e = torch.zeros(B, 0, device='cuda'); tc = None
+    worst = 0.
+    for i in range(H):
+        sub = {k: v[i:i + 1] for k, v in nz.items()}
+        acts = user_actions[:, :i]
+        kw_o = dict(prompt_latents=lat_o, prompt_discrete_actions=acts, prompt_rewards=rew_o) if i > 0 else {}
+        ref = restate.generate(cfg, W, i + 1, batch_size=B, noise=sub, cache=cache, sample_actions=False, **kw_o)
+        cache, lat_o, rew_o = ref['cache'], ref['latents'], ref['rewards']
+        kw_e = dict(prompt_latents=lat_e, prompt_discrete_actions=acts.cuda(), prompt_rewards=rew_e) if i > 0 else {}
+        e, tc = m.generate(i + 1, batch_size=B, return_rewards_per_frame=True, return_terminals=True, time_cache=tc, return_time_cache=True,
+                           noise=sub, **kw_e)
+        lat_e, rew_e = e.latents, e.rewards
+        assert tc.frames == i + 1 and e.latents.shape[1] == i + 1
+        worst = max(worst, (e.latents[:, -1].cpu() - ref['latents'][:, -1]).abs().max().item())
+        close(e.latents[:, -1], ref['latents'][:, -1], atol=5e-4); close(e.rewards[:, -1], ref['rewards'][:, -1], atol=2e-3)
+        assert not bool(e.terminals.any())
+    print(f'\ncfg4 full size, 50 chained env steps: worst latent deviation from the oracle {worst:.2e}')

@@ -36,7 +36,7 @@ def test_policy_and_value_parameter_groups():
 
 
 @pytest.mark.parametrize('kw', [dict(num_agents=2), dict(dim_proprio=4), dict(use_time_rnn=True), dict(actor_depth=1),
-                                dict(num_continuous_actions=2), dict(add_state_pred_head=True), dict(mot_temporal=True)])
+                                dict(num_continuous_actions=2, continuous_dist_type='gaussian'), dict(continuous_norm_stats=((0., 1.),)), dict(add_state_pred_head=True), dict(mot_temporal=True)])
 def test_out_of_scope_options_raise_instead_of_being_ignored(kw):
     with pytest.raises(NotImplementedError):
         DynamicsWorldModel(dim=64, dim_latent=8, num_latent_tokens=6, num_discrete_actions=4, **kw)
