@@ -120,6 +120,11 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise D4Error(f'{LIB_PATH} is missing: run `python -m dreamer4_amd.build` (hipcc, gfx950). '
                       'There is no CPU fallback for the imagination path.')
+    # tile choices of the benchmark configurations measured on MI355X, shipped with the package: preloaded by the GEMM dispatcher so
+    # that those shapes never time anything at first use (reproducible performance, no first-call synchronisation)
+    default_table = os.path.join(_HERE, 'gemm_tune_default.txt')
+    if os.path.isfile(default_table):
+        os.environ.setdefault('D4_GEMM_TUNE_DEFAULT', default_table)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

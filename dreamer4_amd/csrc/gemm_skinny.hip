@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     const int steps = (p.K + 15) >> 4;                           // 16 k per step (4 MFMAs of k = 4)
     const int per = (steps + 3) >> 2;
     const int s1 = min((q + 1) * per, steps);
-    constexpr int U = TM >= 4 ? 2 : 4;                           // steps whose loads are issued together
+    constexpr int U = TM >= 4 ? 2 : 4;                           // steps whose loads are issued together (8 / 4 measured: no gain at M = 15)
     for (int s0 = q * per; s0 < s1; s0 += U) {
         f32x4 w4[U], a4[U][TM];
 #pragma unroll

@@ -189,3 +189,23 @@ def test_gae_matches_the_reference_fixture(lib):
     _lib.check(lib.d4_gae(_lib.ptr(r), _lib.ptr(v), _lib.ptr(lens), _lib.ptr(tr), _lib.ptr(te), 0.997, 0.95, r.shape[0], r.shape[1],
                           _lib.ptr(out), stream()))
     assert torch.allclose(out.cpu(), t(g['gae_returns']), atol=1e-6)
+
+
+def test_torch_library_ops_run_the_hip_kernels_and_trace_without_graph_breaks(lib):
+    x = torch.randn(37, 64, device='cuda'); w = torch.randn(64, device='cuda'); W = torch.randn(96, 64, device='cuda'); b = torch.randn(96, device='cuda')
+
+    def f(x):
+        h = torch.ops.d4hip.rmsnorm(x, w, 1.1920929e-07)
+        return torch.ops.d4hip.linear(h, W, b, None, _lib.GEMM_SILU, 0.)
+
+    ref = torch.nn.functional.silu(torch.nn.functional.rms_norm(x, (64,), w, eps=None) @ W.t() + b)
+    assert torch.allclose(f(x), ref, atol=1e-4, rtol=1e-4)
+    compiled = torch.compile(f, backend='eager', fullgraph=True)       # fullgraph: the custom ops are traceable (no graph break)
+    assert torch.allclose(compiled(x), ref, atol=1e-4, rtol=1e-4)
+    r = torch.randn(4, 7, device='cuda'); v = torch.randn(4, 7, device='cuda')
+    lens = torch.tensor([7, 3, 5, 1], device='cuda'); tr = torch.tensor([True, False, False, True], device='cuda')
+    out = torch.ops.d4hip.gae(r, v, lens, tr, ~tr, 0.997, 0.95)
+    ref2 = torch.empty_like(r)
+    tr8, te8 = tr.to(torch.uint8), (~tr).to(torch.uint8)               # (kept alive: a temporary would be freed before the launch)
+    _lib.check(lib.d4_gae(_lib.ptr(r), _lib.ptr(v), _lib.ptr(lens), _lib.ptr(tr8), _lib.ptr(te8), 0.997, 0.95, 4, 7, _lib.ptr(ref2), stream()))
+    assert torch.equal(out, ref2)

@@ -111,3 +111,20 @@ def test_two_process_gloo_data_parallel_semantics(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count('DP_OK_') == 2, out.stdout
+
+
+def test_custom_ops_are_registered_with_the_dispatcher_and_traceable():
+    """SURVEY.md 8b: the single-kernel entry points are torch.library ops (fake implementations let torch.compile trace them);
+    on CPU tensors they raise instead of falling back."""
+    import dreamer4_amd  # noqa: F401
+    for name in ('rmsnorm', 'linear', 'hl_gauss_to_scalar', 'gae'):
+        assert hasattr(torch.ops.d4hip, name)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(3, 5, 64); w = torch.empty(128, 64)
+        y = torch.ops.d4hip.linear(x, w, None, None, 4, 1e-6)           # SiLU-GLU pairs halve the width
+        assert y.shape == (3, 5, 64)
+        assert torch.ops.d4hip.rmsnorm(x, torch.empty(64), 1e-6).shape == x.shape
+        assert torch.ops.d4hip.hl_gauss_to_scalar(torch.empty(7, 255), torch.empty(255)).shape == (7,)
+    with pytest.raises(D4Error, match='no CPU fallback'):
+        torch.ops.d4hip.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-6)

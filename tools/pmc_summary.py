@@ -1,6 +1,6 @@
 """Merge rocprofv3 --pmc passes (counter_collection.csv + kernel_trace.csv per pass) into a per-kernel table.
 
-usage: python tools/pmc_summary.py <dir_pass1> [<dir_pass2> ...] > profiles/<name>.txt
+usage: python tools/pmc_summary.py <dir_pass1> [<dir_pass2> ...] [--json profiles/pmc_traffic.json] > profiles/<name>.txt
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced read stream -> it is doubled here
@@ -21,7 +21,13 @@ def short(name):
 def main():
     per = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> per-dispatch values
     dur = collections.defaultdict(list)
-    for d in sys.argv[1:]:
+    args = list(sys.argv[1:])
+    json_path = None
+    if '--json' in args:
+        i = args.index('--json')
+        json_path = args[i + 1]
+        del args[i:i + 2]
+    for d in args:
         cc = glob.glob(os.path.join(d, '*counter_collection.csv'))[0]
         kt = glob.glob(os.path.join(d, '*kernel_trace.csv'))[0]
         trace = {r['Dispatch_Id']: r for r in csv.DictReader(open(kt))}
@@ -62,6 +68,20 @@ def main():
             line += f' {avg[c]:22.1f}'
         line += f' {gbs:26.1f} {mfma:12.1f}'
         print(line)
+    if json_path:
+        import json
+        out = dict(method='rocprofv3 --pmc FETCH_SIZE (+GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES) and --pmc WRITE_SIZE (+SQ_WAIT_INST_ANY '
+                          'SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY) in separate passes over tools/rollout_profile_target.py (4 frames of the cfg-2 rollout, tile '
+                          'choices preloaded from the tuning cache so no timing launches are counted); KiB units; FETCH_SIZE doubled (gfx950 reports 1/2 of '
+                          'a wide coalesced read stream, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported', kernels={})
+        for _, k, n, md, avg, gbs, mfma in sorted(rows, reverse=True):
+            if md * n < 50e3 or 'FETCH_SIZE' not in avg or 'WRITE_SIZE' not in avg or k.startswith(('at::', '__amd')):
+                continue
+            out['kernels'][k] = dict(launches=n, avg_us=round(md / 1e3, 2), fetch_size_kib_per_launch=round(avg['FETCH_SIZE'], 1),
+                                     write_size_kib_per_launch=round(avg['WRITE_SIZE'], 1),
+                                     hbm_bytes_per_launch=int((2 * avg['FETCH_SIZE'] + avg['WRITE_SIZE']) * 1024), hbm_gbs=round(gbs, 1),
+                                     mfma_busy_pct=None if mfma != mfma else round(mfma, 1))
+        json.dump(out, open(json_path, 'w'), indent=1)
 
 
 if __name__ == '__main__':
