@@ -7,6 +7,7 @@ All compute runs in hand-written HIP kernels behind the C-ABI of include/d4hip.h
 from dreamer4_amd.experience import Actions, Experience, combine_experiences
 from dreamer4_amd.world_model import DynamicsWorldModel, TimeCache
 from dreamer4_amd.trainer import DreamTrainer
+from dreamer4_amd.tokenizer import VideoTokenizer
 from dreamer4_amd import ops  # noqa: F401  (registers torch.ops.d4hip.*)
 
-__all__ = ['Actions', 'Experience', 'combine_experiences', 'DynamicsWorldModel', 'TimeCache', 'DreamTrainer']
+__all__ = ['Actions', 'Experience', 'combine_experiences', 'DynamicsWorldModel', 'TimeCache', 'DreamTrainer', 'VideoTokenizer']

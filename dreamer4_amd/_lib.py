@@ -35,6 +35,8 @@ class Config(C.Structure):
         ('pmpo_kl_div_loss_weight', C.c_float), ('pmpo_reverse_kl', C.c_int32),
         ('hl_gauss_sigma_to_bin_ratio', C.c_float), ('hl_gauss_eps', C.c_float),
         ('value_min', C.c_float), ('value_max', C.c_float),
+        ('mode', C.c_int32), ('patch_size', C.c_int32), ('channels', C.c_int32), ('image_height', C.c_int32), ('image_width', C.c_int32),
+        ('decoder_flow_steps', C.c_int32), ('decoder_pos_mlp_depth', C.c_int32),
         ('max_batch', C.c_int32), ('max_frames', C.c_int32), ('max_parallel_frames', C.c_int32),
         ('max_learn_rows', C.c_int32),
     ]
@@ -86,6 +88,8 @@ SYMBOLS = {
     'd4_engine_cache_export': (_I, [_P, _P, _I, _P]),
     'd4_engine_cache_import': (_I, [_P, _P, _I, _I, _P]),
     'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'd4_decoder_forward': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'd4_euler_step': (_I, [_P, _P, _L, _F, _F, _P]),
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),
     'd4_learn': (_I, [_P, C.POINTER(LearnIO), _P]),
     'd4_adamw_clip': (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _F, _P, _P]),

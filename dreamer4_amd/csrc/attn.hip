@@ -231,7 +231,119 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Attention over up to ATTN_MAXK keys per (group, head) with head dim 64: the space layers of the video tokenizer's decoder
+// (~100 tokens per frame: patches + latents, D4:3654-3668).  One 4-wave block per (group, head):
+//   phase 1  the keys are prepared ONCE, cooperatively, into LDS: value-residual lerp on V, K l2-norm * (gamma + 1) * sqrt(dh), 1 / |v|
+//   phase 2  wave w owns queries w, w + 4, ...; lanes are spread over (key residue j & 3, feature group of 4) exactly as in
+//            time_attn64_kernel, so one pass scores four keys with a 16-lane DPP row reduction, softclamp / exp run for four keys at
+//            once, and K / V fragments are conflict-free 16-byte LDS reads; keys go in chunks of 64 with an online softmax.
+constexpr int ATTN_MAXK = 160;
+__global__ __launch_bounds__(256) void attn_wide_kernel(SmallAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float wide_s[];            // K [nk][64] | V [nk][64] | 1/|v| [nk]
+    const int nk = p.nk, nq = p.nq;
+    float* Ks = wide_s;
+    float* Vs = wide_s + nk * 64;
+    float* vinv_s = Vs + nk * 64;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int hl = h * 64 + lane;
+    const float kscale = (p.k_gamma[hl] + 1.f) * 8.f;
+    for (int j = w; j < nk; j += 4) {
+        float kj = p.k[g * p.k_group_stride + j * p.k_item_stride + hl];
+        float vj = p.v[g * p.v_group_stride + j * p.v_item_stride + hl];
+        if (p.vres) vj = lerp_torch(vj, p.vres[g * p.r_group_stride + j * p.r_item_stride + hl], sigmoidf(p.mix[g * p.m_group_stride + j * p.m_item_stride + h]));
+        const float nrm = sqrtf(wave_sum(kj * kj));
+        Ks[j * 64 + lane] = kj / fmaxf(nrm, 1e-12f) * kscale;
+        Vs[j * 64 + lane] = vj;
+        if (p.belief) { const float vn = sqrtf(wave_sum(vj * vj)); if (lane == 0) vinv_s[j] = 1.f / fmaxf(vn, 1e-12f); }
+    }
+    __syncthreads();
+
+    const int fg = lane & 15, kr = lane >> 4;
+    const f32x4* kt = reinterpret_cast<const f32x4*>(Ks);
+    const f32x4* vt = reinterpret_cast<const f32x4*>(Vs);
+    for (int i = w; i < nq; i += 4) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + g * p.q_group_stride + i * p.q_item_stride + h * 64 + fg * 4);
+        // ordinary queries may not see the trailing special keys (D4:1781)
+        const int vis = (p.mask_special > 0 && i < nq - p.mask_special) ? nk - p.mask_special : nk;
+        float m = -FLT_MAX, l = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < vis; c0 += 64) {
+            const int cn = min(64, vis - c0);
+            const int passes = (cn + 3) / 4;
+            float sc[16];
+            float cm = -FLT_MAX;
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                sc[ps] = -FLT_MAX;
+                if (ps < passes) {
+                    const int j = ps * 4 + kr;
+                    const bool ok = j < cn;
+                    const f32x4 k4 = ok ? kt[(c0 + j) * 16 + fg] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    float d = row_sum16(q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3]) * 0.125f;
+                    if (p.softclamp > 0.f) d = tanhf(d / p.softclamp) * p.softclamp;
+                    sc[ps] = ok ? d : -FLT_MAX;
+                    cm = fmaxf(cm, sc[ps]);
+                }
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float mn = fmaxf(m, cm);
+            const float alpha = expf(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= alpha;
+#pragma unroll
+            for (int ps = 0; ps < 16; ++ps) {
+                if (ps < passes && sc[ps] > -FLT_MAX) {
+                    const float e_ = expf(sc[ps] - mn);
+                    const f32x4 v4 = vt[(c0 + ps * 4 + kr) * 16 + fg];
+                    l += e_;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += e_ * v4[e];
+                }
+            }
+            m = mn;
+        }
+        l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16); acc[e] += __shfl_xor(acc[e], 32); }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[e] / l;
+        if (p.belief) {                                       // self attention: orthogonalise against token i's own (mixed) value
+            const f32x4 vi = vt[i * 16 + fg];
+            const float inv = vinv_s[i];
+            const float dot = row_sum16(o[0] * vi[0] + o[1] * vi[1] + o[2] * vi[2] + o[3] * vi[3]) * inv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] -= dot * (vi[e] * inv);
+        }
+        if (p.gate) {
+            const float gt = sigmoidf(p.gate[g * p.g_group_stride + i * p.g_item_stride + h]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= gt;
+        }
+        if (kr == 0) *reinterpret_cast<f32x4*>(p.out + g * p.o_group_stride + i * p.o_item_stride + h * 64 + fg * 4) = o;
+    }
+}
+
 int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
+    if (p.nk > 64 || (p.nq == p.nk && p.nk > 16 && p.belief && p.dh == 64)) {
+        // wide form (tokenizer decoder): needs 16-byte aligned rows for the float4 q loads / out stores
+        D4_REQUIRE(p.nk <= ATTN_MAXK && p.dh == 64, "attention: %d keys (max %d) / head dim %d (64) not supported by the wide kernel", p.nk, ATTN_MAXK, p.dh);
+        D4_REQUIRE(p.q_lo == 0 && p.q_hi == 0, "attention: query restriction is not implemented in the wide kernel");
+        const size_t lds = (size_t)(2 * p.nk * 64 + p.nk) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * ATTN_MAXK * 64 + ATTN_MAXK) * sizeof(float))));
+            attr_set = true;
+        }
+        if (p.groups * p.heads == 0) return 0;
+        hipLaunchKernelGGL(attn_wide_kernel, dim3(p.groups * p.heads), dim3(256), lds, stream, p);
+        D4_LAUNCH_CHECK();
+        return 0;
+    }
     D4_REQUIRE(p.nk >= 1 && p.nk <= 64, "small_attn: nk=%d out of range [1,64]", p.nk);
     D4_REQUIRE(p.dh == 16 || p.dh == 32 || p.dh == 64, "small_attn: head dim %d (16, 32 or 64)", p.dh);
     D4_REQUIRE(!p.belief || p.nq == p.nk, "small_attn: belief needs self attention");
@@ -554,15 +666,20 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
             const f32x4* vt = STAGE ? reinterpret_cast<const f32x4*>(kv_s + TA_CHUNK * 64) : reinterpret_cast<const f32x4*>(cv + (int64_t)c0 * 64);
             float sc[TA_CHUNK / 4];
             float cm = -FLT_MAX;
+            const int last = min(cn - 1, pos - c0);                            // last key of this chunk the query may see (causal)
+            const int passes = __builtin_amdgcn_readfirstlane(last < 0 ? 0 : last / 4 + 1);      // wave-uniform: skipped passes cost one scalar branch
 #pragma unroll
             for (int ps = 0; ps < TA_CHUNK / 4; ++ps) {
-                const int j = ps * 4 + kr;
-                const bool ok = j < cn && c0 + j <= pos;                       // causal
-                const f32x4 k4 = ok ? kt[j * 16 + fg] : f32x4{0.f, 0.f, 0.f, 0.f};
-                float d = row_sum16(q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3]) * qscale;
-                if (p.softclamp > 0.f) d = tanhf(d / p.softclamp) * p.softclamp;
-                sc[ps] = ok ? d : -FLT_MAX;
-                cm = fmaxf(cm, sc[ps]);
+                sc[ps] = -FLT_MAX;
+                if (ps < passes) {
+                    const int j = ps * 4 + kr;
+                    const bool ok = j <= last;
+                    const f32x4 k4 = ok ? kt[j * 16 + fg] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    float d = row_sum16(q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3]) * qscale;
+                    if (p.softclamp > 0.f) d = tanhf(d / p.softclamp) * p.softclamp;
+                    sc[ps] = ok ? d : -FLT_MAX;
+                    cm = fmaxf(cm, sc[ps]);
+                }
             }
             cm = fmaxf(cm, __shfl_xor(cm, 16));
             cm = fmaxf(cm, __shfl_xor(cm, 32));                                // chunk max over the four key residues
@@ -574,7 +691,7 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
 #pragma unroll
             for (int ps = 0; ps < TA_CHUNK / 4; ++ps) {
                 const int j = ps * 4 + kr;
-                if (sc[ps] > -FLT_MAX) {
+                if (ps < passes && sc[ps] > -FLT_MAX) {
                     const float e_ = expf(sc[ps] - mn);
                     const f32x4 v4 = vt[j * 16 + fg];
                     l += e_;

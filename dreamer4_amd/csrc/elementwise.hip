@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, int
     for (int i = 0; i < MAXI; ++i) {
         const int c = lane + 64 * i;
         if (c < D) {
-            float o = (v[i] - mean) * rstd * g[c] + b[c];
+            float o = (v[i] - mean) * rstd * g[c] + (b ? b[c] : 0.f);
             if (silu) o = siluf(o);
             yr[c] = o;
         }
@@ -390,6 +390,85 @@ int build_latent_input(float* out, const float* hist, const float* ctx_noise, co
     const int64_t n = (int64_t)B * Tq * n_el;
     if (n == 0) return 0;
     hipLaunchKernelGGL(build_latent_kernel, grid1d(n), dim3(256), 0, s, out, hist, ctx_noise, x, B, Tq, n_el, hist_t_stride, w);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------- tokenizer decoder glue
+// 'b c t (h p1) (w p2) -> (b t h w) (p1 p2 c)' (D4:3896) and its inverse (D4:3556); patch row = ((b T + t) nh + h) nw + w
+__global__ void video_patch_kernel(const float* src, float* dst, int B, int C, int T, int nh, int nw, int ps, int to_patches) {
+    const int H = nh * ps, W = nw * ps, dp = ps * ps * C;
+    const int64_t n = (int64_t)B * C * T * H * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // i enumerates the patch-row layout (contiguous writes when to_patches, contiguous reads otherwise)
+        int64_t r = i;
+        const int c = (int)(r % C); r /= C;
+        const int p2 = (int)(r % ps); r /= ps;
+        const int p1 = (int)(r % ps); r /= ps;
+        const int w = (int)(r % nw); r /= nw;
+        const int h = (int)(r % nh); r /= nh;
+        const int t = (int)(r % T); r /= T;
+        const int b = (int)r;
+        const int64_t v = ((((int64_t)b * C + c) * T + t) * H + (h * ps + p1)) * W + (w * ps + p2);
+        if (to_patches) dst[i] = src[v]; else dst[v] = src[i];
+        (void)dp;
+    }
+}
+int video_to_patches(const float* video, float* patches, int B, int C, int T, int nh, int nw, int ps, hipStream_t s) {
+    const int64_t n = (int64_t)B * C * T * nh * ps * nw * ps;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(video_patch_kernel, grid1d(n), dim3(256), 0, s, video, patches, B, C, T, nh, nw, ps, 1);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+int patches_to_video(const float* patches, float* video, int B, int C, int T, int nh, int nw, int ps, hipStream_t s) {
+    const int64_t n = (int64_t)B * C * T * nh * ps * nw * ps;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(video_patch_kernel, grid1d(n), dim3(256), 0, s, patches, video, B, C, T, nh, nw, ps, 0);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+// tokens[f][s] = s < P ? pos[s] + img[f][s] : lat[f][s - P]   for the n_lat latent tokens kept (the last latent token — the trunk's one
+// "special" token — is never visible to another token, D4:1781, and only patch rows are read back: it is dropped); the patch rows
+// are also written to the row-compacted copy the final attention pool reads
+__global__ void decoder_pack_kernel(float* tokens, float* compact, const float* pos, const float* img, const float* lat, int frames, int P,
+                                    int n_lat, int n_total, int D) {
+    const int S = P + n_lat;
+    const int64_t n = (int64_t)frames * S * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int s = (int)((i / D) % S);
+        const int64_t f = i / ((int64_t)D * S);
+        float v;
+        if (s < P) {
+            v = pos[(int64_t)s * D + d] + img[(f * P + s) * D + d];
+            compact[(f * P + s) * D + d] = v;
+        } else {
+            v = lat[(f * n_total + (s - P)) * D + d];
+        }
+        tokens[i] = v;
+    }
+}
+int decoder_pack_tokens(float* tokens, float* compact, const float* pos, const float* img, const float* lat, int frames, int P, int n_lat, int n_total, int D, hipStream_t s) {
+    const int64_t n = (int64_t)frames * (P + n_lat) * D;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(decoder_pack_kernel, grid1d(n), dim3(256), 0, s, tokens, compact, pos, img, lat, frames, P, n_lat, n_total, D);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+// out[(h, w)][0..1] = (linspace(-1, 1, nh)[h], linspace(-1, 1, nw)[w]), remaining columns of the row zero   D4:3617-3620
+__global__ void coord_grid_kernel(float* out, int nh, int nw, int ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh * nw) return;
+    const int h = i / nw, w = i % nw;
+    for (int c = 0; c < ld; ++c) out[(int64_t)i * ld + c] = 0.f;
+    // torch.linspace(-1, 1, n): start + step * i for the first half, end - step * (n - 1 - i) for the second (n = 1 -> -1)
+    auto lin = [](int k, int n) { const float step = n > 1 ? 2.f / (float)(n - 1) : 0.f; return k < n / 2 ? -1.f + step * (float)k : 1.f - step * (float)(n - 1 - k); };
+    out[(int64_t)i * ld + 0] = nh > 1 ? lin(h, nh) : -1.f;
+    out[(int64_t)i * ld + 1] = nw > 1 ? lin(w, nw) : -1.f;
+}
+int coord_grid(float* out, int nh, int nw, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(coord_grid_kernel, dim3(cdiv(nh * nw, 128)), dim3(128), 0, s, out, nh, nw, ld);
     D4_LAUNCH_CHECK();
     return 0;
 }

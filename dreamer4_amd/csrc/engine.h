@@ -69,6 +69,14 @@ struct d4_engine {
     bool warm = false;
     hipStream_t capture_stream = nullptr;             // use graphs when batch * tokens_per_frame <= this (launch-bound regime)
 
+    // ---- decoder mode (video tokenizer's decoder, D4:3490-3682): tokens per frame = [P patches | n latent tokens]
+    bool decoder = false;
+    int P = 0, dim_patch = 0, nph = 0, npw = 0;
+    int keep_lo = 1, keep_hi = 1;          // token rows of a frame the final stage needs (dynamics: the spatial tokens; decoder: the patches)
+    const float *ld_w = nullptr, *time_embed = nullptr, *npt_w = nullptr, *npt_b = nullptr, *npt_ln = nullptr, *t2p_w = nullptr, *t2p_b = nullptr, *final_norm = nullptr;
+    d4::Mlp posmlp;
+    float *pos_emb = nullptr, *t2p_wf = nullptr, *dec_in = nullptr, *img_tok = nullptr, *lat_tok = nullptr, *dec_out = nullptr, *posA = nullptr, *posB = nullptr, *zerosD = nullptr;
+
     // ---- bf16 compute (opt-in): bf16 mirrors of every weight the trunk GEMMs read, carved from one arena of the workspace
     bool bf16 = false;
     uint16_t* bf16_arena = nullptr; size_t bf16_cap = 0, bf16_used = 0;

@@ -73,12 +73,25 @@ int engine_layout(d4_engine* e, bool assign) {
         e->bf16_cap = (size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096;
         e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * sizeof(uint16_t)));
     }
+    const size_t KR = e->decoder ? (size_t)e->P : (size_t)ns + 1;        // token rows per frame the final stage keeps (compact copies)
     e->slabs = fl((size_t)e->nslab * M * D);
     e->xpool = fl(M * D);
-    e->cslabs = fl((size_t)e->nslab * Fr * (ns + 1) * D);
-    e->xfc = fl(Fr * (ns + 1) * D);
-    e->xpool_c = fl(Fr * (ns + 1) * D);
-    e->att_c = fl(Fr * (ns + 1) * hd);
+    e->cslabs = fl((size_t)e->nslab * Fr * KR * D);
+    e->xfc = fl(Fr * KR * D);
+    e->xpool_c = fl(Fr * KR * D);
+    e->att_c = fl(Fr * KR * hd);
+    if (e->decoder) {
+        const size_t P = e->P, dp = e->dim_patch;
+        e->pos_emb = fl(P * D);
+        e->t2p_wf = fl(dp * D);
+        e->dec_in = fl(Fr * P * dp);
+        e->dec_out = fl(Fr * P * dp);
+        e->img_tok = fl(Fr * P * D);
+        e->lat_tok = fl(Fr * (size_t)n * D);
+        e->posA = fl(P * (size_t)(2 * D > 4 ? 2 * D : 4));
+        e->posB = fl(P * (size_t)(2 * D > 4 ? 2 * D : 4));
+        e->zerosD = fl((size_t)(2 * D > (int)dp ? 2 * D : dp));
+    }
     e->proj0 = fl(M * e->Nproj0);
     e->proj = fl(M * e->Nproj);
     e->att = fl(M * hd);
@@ -232,19 +245,35 @@ int engine_resolve(d4_engine* e) {
     const int D = e->D, h = c.attn_heads;
     e->layer_attn.assign(c.depth, AttnW{});
     e->layer_ff.assign(c.depth, FfW{});
+    const std::string tp = e->decoder ? "decoder.transformer." : "transformer.";
     for (int l = 0; l < c.depth; ++l) {
-        r.attn(e->layer_attn[l], keyf("transformer.layers.%d.2.fn.", l), D, D, h, false, true, c.attn_dim_head);
-        r.ff(e->layer_ff[l], keyf("transformer.layers.%d.3.fn.", l), D, e->inner);
+        r.attn(e->layer_attn[l], tp + keyf("layers.%d.2.fn.", l), D, D, h, false, true, c.attn_dim_head);
+        r.ff(e->layer_ff[l], tp + keyf("layers.%d.3.fn.", l), D, e->inner);
     }
     e->pools.assign(c.depth, AttnW{});
     for (int p = 0; p < c.depth - 1; ++p)
-        r.attn(e->pools[p], keyf("transformer.attn_pools.%d.fn.attn.", p), D, D, c.pool_heads, true, false);
-    r.attn(e->pools[c.depth - 1], "transformer.final_attn_pool.fn.attn.", D, D, c.pool_heads, true, false);
+        r.attn(e->pools[p], tp + keyf("attn_pools.%d.fn.attn.", p), D, D, c.pool_heads, true, false);
+    r.attn(e->pools[c.depth - 1], tp + "final_attn_pool.fn.attn.", D, D, c.pool_heads, true, false);
+    e->vres_norm = r.get((tp + "to_value_residual.0.weight").c_str(), D);
+    e->vres_w = r.get((tp + "to_value_residual.1.weight").c_str(), (int64_t)e->hd * D);
+    e->inv_freq = r.get((tp + "time_rotary.inv_freq").c_str(), c.attn_dim_head / 2);
+    if (e->decoder) {
+        // VideoTokenizer / VideoDecoderNetwork pieces around the trunk (D4:3526-3557, 3894-3899, 3938).  The trunk's final special
+        // cross-attention / feedforward only update the one special token (the last latent token), which nothing reads: not bound.
+        const int dp = e->dim_patch;
+        e->ld_w = r.get("latents_to_decoder.weight", (int64_t)D * c.dim_latent);
+        e->time_embed = r.get("time_embed.weight", (int64_t)c.decoder_flow_steps * D);
+        e->npt_w = r.get("noised_patch_to_tokens.1.weight", (int64_t)D * dp);
+        e->npt_b = r.get("noised_patch_to_tokens.1.bias", D);
+        e->npt_ln = r.get("noised_patch_to_tokens.2.weight", D);
+        e->t2p_w = r.get("decoder.tokens_to_patch.0.weight", (int64_t)dp * D);
+        e->t2p_b = r.get("decoder.tokens_to_patch.0.bias", dp);
+        e->final_norm = r.get((tp + "final_norm.weight").c_str(), D);
+        r.mlp(e->posmlp, "decoder.to_decoder_pos_emb.");
+        return r.rc;
+    }
     r.attn(e->cross, "transformer.final_special_cross_attn.fn.", D, D, h, true, false, c.attn_dim_head);
     r.ff(e->sff, "transformer.final_special_ff.fn.", D, e->inner);
-    e->vres_norm = r.get("transformer.to_value_residual.0.weight", D);
-    e->vres_w = r.get("transformer.to_value_residual.1.weight", (int64_t)e->hd * D);
-    e->inv_freq = r.get("transformer.time_rotary.inv_freq", c.attn_dim_head / 2);
     e->latent_norm = r.get("to_latent_pred.0.weight", D);
     e->latent_w = r.get("to_latent_pred.2.weight", (int64_t)c.dim_latent * D);
     if (c.num_spatial_tokens == c.num_latent_tokens) {
@@ -285,6 +314,7 @@ int engine_resolve(d4_engine* e) {
 // The trunk's GEMMs run on the bf16 MFMA kernel when the engine was created with matmul_bf16: engine_forward sets the thread's
 // active engine, and every GEMM issued below it swaps its weight pointer for the bf16 mirror made at prepare time.
 static thread_local d4_engine* t_bf16 = nullptr;
+static thread_local int t_keep_lo = 1;         // first token row of a frame the compacted copies keep (set by engine_forward)
 
 static int mirror_weight(d4_engine* e, const float* src, size_t n, hipStream_t s) {
     if (!e->bf16 || !src || n == 0) return 0;
@@ -327,7 +357,7 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
 static int gemm_c2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags,
                    const float* bias, const float* R, int ldr, float* C2, int S, int ns, int has_agent, hipStream_t s) {
     GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS, 0};
-    g.C2 = C2; g.ldc2 = N; g.c2_S = S; g.c2_lo = 1; g.c2_hi = 1 + ns; g.c2_last = has_agent;
+    g.C2 = C2; g.ldc2 = N; g.c2_S = S; g.c2_lo = t_keep_lo; g.c2_hi = t_keep_lo + ns; g.c2_last = has_agent;
     return engine_gemm(g, s);
 }
 
@@ -351,13 +381,47 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
         if (l == 0 && (rc = fold_attn_rows(w + (size_t)(3 * hd + 2 * h) * D, D, e->vres_w, e->vres_norm, hd, s))) return rc;
         if ((rc = prep_ff(e->layer_ff[l], e->ffp[l], e, s))) return rc;
     }
-    if ((rc = prep_ff(e->sff, e->ffp[c.depth], e, s))) return rc;
+    if (!e->decoder && (rc = prep_ff(e->sff, e->ffp[c.depth], e, s))) return rc;
     for (int p = 0; p < c.depth; ++p) {
         const AttnW& a = e->pools[p];
         if ((rc = fold_attn_rows(e->pq_w[p], D, a.to_q, a.norm, hp, s))) return rc;
         if ((rc = fold_attn_rows(e->pq_w[p] + (size_t)hp * D, D, a.to_gates, a.norm, e->php, s))) return rc;
         if ((rc = fold_attn_rows(e->pkv_w[p], D, a.to_k, a.norm_ctx, hp, s))) return rc;
         if ((rc = fold_attn_rows(e->pkv_w[p] + (size_t)hp * D, D, a.to_v, a.norm_ctx, hp, s))) return rc;
+    }
+    if (e->decoder) {
+        // positional embedding of the patch grid: the normed MLP (recipe: engine.h) of the (row, column) coordinates — batch independent,
+        // evaluated once here (D4:3617-3625).  Its first layer has K = 2: coordinates / weight are zero-padded to 4 columns.
+        const Mlp& m = e->posmlp;
+        const int P = e->P;
+        float* cur = e->posA;
+        if ((rc = coord_grid(cur, e->nph, e->npw, 4, s))) return rc;
+        float* other = e->posB;
+        for (int i = 0; i < m.nl; ++i) {
+            const int din = m.dims[i], dout = m.dims[i + 1], ld_in = i == 0 ? 4 : din;
+            const bool last = i == m.nl - 1;
+            const float* w = m.w[i];
+            if (i == 0) {                                     // [dout][2] -> [dout][4]
+                if ((rc = pad_cols(m.w[0], e->t2p_wf, dout, 2, 4, s))) return rc;      // (t2p_wf is free until the end of prepare)
+                w = e->t2p_wf;
+            }
+            const float* lin_in = cur;
+            if (m.recipe == D4_MLP_PRE_RMS) {
+                // RMSNorm over the din real columns (for i == 0: 2 of the 4), written back in place with the padding kept zero
+                if ((rc = rmsnorm_rows(cur, ld_in, m.g[i], cur, ld_in, P, din, RMS_EPS, s))) return rc;
+            }
+            float* out = last ? e->pos_emb : other;
+            const int act = (!last && !m.post_norm(i)) ? GEMM_SILU : 0;
+            if ((rc = gemm_simple(lin_in, ld_in, w, ld_in, out, dout, P, dout, ld_in, act, m.b[i], nullptr, 0, s))) return rc;
+            if (m.post_norm(i) && (rc = layernorm_rows(out, dout, m.g[i], m.nb[i], out, dout, P, dout, 1e-5f, 1, s))) return rc;
+            other = cur; cur = out;
+        }
+        // final RMSNorm of the trunk folded into the patch projection: W . diag(gamma), 1 / rms applied inside the GEMM   D4:3246, 3555
+        if ((rc = fold_rows(e->t2p_w, e->final_norm, e->t2p_wf, e->dim_patch, D, D, s))) return rc;
+        if ((rc = fill_f32(e->zerosD, 0.f, 2 * D > e->dim_patch ? 2 * D : e->dim_patch, s))) return rc;
+        D4_HIP(hipStreamSynchronize(s));
+        e->prepared = true;
+        return 0;
     }
     if ((rc = fold_attn_rows(e->cq_w, D, e->cross.to_q, e->cross.norm, hd, s))) return rc;
     if ((rc = fold_attn_rows(e->cq_w + (size_t)hd * D, D, e->cross.to_gates, e->cross.norm, h, s))) return rc;
@@ -435,7 +499,7 @@ static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const fl
     if ((rc = engine_gemm(g1, s))) return rc;
     GemmArgs g2{e->ffh, e->inner_pad, fp.w2, e->inner_pad, y, ldy, out_b, x, ldx, rows, e->D, e->inner_pad, 0, RMS_EPS,
                 2.0 * rows * (double)e->D * e->inner};
-    if (y_compact) { g2.C2 = y_compact; g2.ldc2 = e->D; g2.c2_S = S; g2.c2_lo = 1; g2.c2_hi = 1 + e->c.num_spatial_tokens; g2.c2_last = has_agent; }
+    if (y_compact) { g2.C2 = y_compact; g2.ldc2 = e->D; g2.c2_S = S; g2.c2_lo = e->keep_lo; g2.c2_hi = e->keep_hi; g2.c2_last = has_agent; }
     return engine_gemm(g2, s);
 }
 
@@ -471,7 +535,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     sa.groups = M; sa.heads = c.pool_heads; sa.nq = 1; sa.nk = L;
     if ((rc = small_attn(sa, s))) return rc;
     }
-    if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, S, c.num_spatial_tokens, has_agent, s);
+    if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, S, e->keep_hi - e->keep_lo, has_agent, s);
     return gemm_simple(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, s);
 }
 
@@ -488,6 +552,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
 int engine_forward(d4_engine* e, const float* latents, int B, int Tq, int t0, int step_log2,
                    const int64_t* tasks, bool need_agent, hipStream_t s, const int* t0_dev) {
     t_bf16 = e->bf16 ? e : nullptr;           // the trunk's GEMMs below pick their bf16 weight mirrors; heads and learner stay fp32
+    t_keep_lo = e->keep_lo;
     const int rc = engine_forward_impl(e, latents, B, Tq, t0, step_log2, tasks, need_agent, s, t0_dev);
     t_bf16 = nullptr;
     return rc;
@@ -509,8 +574,21 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
     const int Fr = B * Tq, M = Fr * S;
     int rc;
 
-    // ---- latents -> spatial tokens (LearnedQueriesAttentionPool, D4:7168; a plain Linear when there is one per latent)
+    float* slab0 = e->slabs;
+    auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
+    const int nkeep = e->decoder ? e->P : ns + has_agent, Mc = Fr * nkeep;          // rows the final stage reads
+    auto cslab = [&](int j) { return e->cslabs + (size_t)j * Mc * D; };
     const bool same_len = ns == n;
+    if (e->decoder) {
+        // tokens = [pos_emb + patch tokens of the noised video | latent tokens] (D4:3625-3654); `latents` here are the latent TOKENS
+        // input row-major [Fr][n][dl]; the noised video's patch rows were laid out in e->dec_in by d4_decoder_forward
+        const int P = e->P, dp = e->dim_patch;
+        if ((rc = gemm_simple(e->dec_in, dp, e->npt_w, dp, e->img_tok, D, Fr * P, D, dp, 0, e->npt_b, nullptr, 0, s))) return rc;
+        if ((rc = layernorm_rows(e->img_tok, D, e->npt_ln, nullptr, e->img_tok, D, Fr * P, D, 1e-5f, 0, s))) return rc;
+        if ((rc = gemm_simple(latents, dl, e->ld_w, dl, e->lat_tok, D, Fr * n, D, dl, 0, e->time_embed + (size_t)step_log2 * D, nullptr, 0, s))) return rc;
+        if ((rc = decoder_pack_tokens(slab0, e->cslabs, e->pos_emb, e->img_tok, e->lat_tok, Fr, P, n - 1, n, D, s))) return rc;
+    } else {
+    // ---- latents -> spatial tokens (LearnedQueriesAttentionPool, D4:7168; a plain Linear when there is one per latent)
     if (same_len) {
         if ((rc = gemm_simple(latents, dl, e->lin_w, dl, e->space, D, Fr * n, D, dl, 0, e->lin_b, nullptr, 0, s))) return rc;
     } else {
@@ -531,10 +609,6 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
     }
 
     // ---- pack tokens (D4:7182-7222)
-    float* slab0 = e->slabs;
-    auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
-    const int nkeep = ns + has_agent, Mc = Fr * nkeep;          // rows the final pool / latent head / agent read
-    auto cslab = [&](int j) { return e->cslabs + (size_t)j * Mc * D; };
     {
         AssembleArgs a{};
         a.tokens = slab0; a.space = e->space; a.signal_embed = e->signal_embed; a.step_embed = e->step_embed;
@@ -547,6 +621,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         a.compact = e->cslabs; a.has_agent = has_agent;
         D4_REQUIRE(tasks == nullptr || c.num_tasks > 0, "tasks given but num_tasks == 0");
         if ((rc = assemble_tokens(a, s))) return rc;
+    }
     }
 
     // ---- trunk (AxialSpaceTimeTransformer.forward, D4:3040-3223)
@@ -598,7 +673,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         }
         float* h1 = slab(2 * l + 1);
         float* h2 = slab(2 * l + 2);
-        if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, ns, has_agent, s))) return rc;
+        if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, e->keep_hi - e->keep_lo, has_agent, s))) return rc;
         if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2), S, has_agent))) return rc;
         if (l != c.depth - 1) {
             float* xc = (!need_agent && l == c.depth - 2 && !e->is_time[c.depth - 1] && S <= 16 && S >= 8) ? e->xpool_c : nullptr;
@@ -614,6 +689,11 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
     float* xfc = e->xfc;
     const float* last = slab(2 * c.depth);
     if ((rc = copy_rows(cslab(2 * c.depth), D, xfc, D, Mc, D, s))) return rc;
+    if (e->decoder) {
+        // final attention pool on the patch rows, then final RMSNorm (folded) -> Linear(dim, channels * patch^2)   D4:3242-3246, 3555
+        if ((rc = pool_block(e, c.depth - 1, xfc, xfc, e->nslab, Mc, s, e->cslabs))) return rc;
+        return gemm_simple(xfc, D, e->t2p_wf, D, e->dec_out, e->dim_patch, Mc, e->dim_patch, D, GEMM_RMS_ROWSCALE, e->t2p_b, nullptr, 0, s);
+    }
     if (need_agent) {
         // agent token cross-attends the non-special tokens of its frame, then its own feedforward (D4:3227-3238)
         const float* agent_in = last + (size_t)(S - 1) * D;
@@ -742,14 +822,35 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     D4_REQUIRE(c.dim % 4 == 0 && c.dim_latent % 4 == 0, "dim and dim_latent must be multiples of 4");
     D4_REQUIRE(c.depth >= 1 && c.time_block_every >= 1, "bad depth/time_block_every");
     D4_REQUIRE(c.num_discrete_action_types >= 0 && c.num_discrete_action_types <= D4_MAX_ACTION_TYPES, "too many action types");
-    D4_REQUIRE(c.num_latent_tokens <= 64 && c.num_spatial_tokens <= 64, "at most 64 latent / spatial tokens");
+    const bool decoder = c.mode == D4_MODE_DECODER;
+    D4_REQUIRE(c.mode == D4_MODE_DYNAMICS || decoder, "unknown engine mode %d", c.mode);
+    D4_REQUIRE(c.num_latent_tokens <= 64 && (decoder || c.num_spatial_tokens <= 64), "at most 64 latent / spatial tokens");
+    if (decoder) {
+        D4_REQUIRE(c.attn_dim_head == 64, "decoder mode: attn_dim_head must be 64 (the wide attention kernel)");
+        D4_REQUIRE(c.patch_size >= 1 && c.channels >= 1 && c.image_height % c.patch_size == 0 && c.image_width % c.patch_size == 0 && c.image_height > 0 && c.image_width > 0,
+                   "decoder mode: image %d x %d must be a positive multiple of the patch size %d", c.image_height, c.image_width, c.patch_size);
+        D4_REQUIRE((c.channels * c.patch_size * c.patch_size) % 4 == 0, "decoder mode: channels * patch_size^2 must be a multiple of 4");
+        D4_REQUIRE(c.decoder_flow_steps >= 1, "decoder mode: decoder_flow_steps >= 1 (the flow decoder is the reference's default, D4:3875)");
+        D4_REQUIRE(c.num_discrete_action_types == 0 && c.num_continuous_actions == 0 && c.matmul_bf16 == 0, "decoder mode: no actions / bf16");
+        D4_REQUIRE(c.decoder_pos_mlp_depth >= 0 && c.decoder_pos_mlp_depth <= 6, "decoder_pos_mlp_depth out of range");
+    }
     D4_REQUIRE((c.max_steps & (c.max_steps - 1)) == 0, "max_steps must be a power of two");
     D4_REQUIRE(c.policy_head_mlp_depth <= 6 && c.value_head_mlp_depth <= 6 && c.terminal_mlp_depth <= 6, "mlp depth > 6");
     d4_engine* e = new d4_engine();
     e->c = c;
     e->D = c.dim;
     e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + ((c.num_discrete_action_types > 0 || c.num_continuous_actions > 0) ? 1 : 0) + 1;   // no action token without an action space
-    D4_REQUIRE(e->S <= 64 && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
+    e->keep_lo = 1; e->keep_hi = 1 + c.num_spatial_tokens;
+    e->decoder = decoder;
+    if (decoder) {
+        e->nph = c.image_height / c.patch_size; e->npw = c.image_width / c.patch_size;
+        e->P = e->nph * e->npw;
+        e->dim_patch = c.channels * c.patch_size * c.patch_size;
+        e->S = e->P + c.num_latent_tokens;                     // [patches | latent tokens]; the last latent token is the trunk's one special token
+        e->keep_lo = 0; e->keep_hi = e->P;
+        D4_REQUIRE(e->S - 1 <= 160, "decoder mode: %d tokens per frame exceed the wide attention kernel's 160", e->S - 1);
+    }
+    D4_REQUIRE((decoder || e->S <= 64) && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
     e->hd = c.attn_heads * c.attn_dim_head;
     e->php = c.pool_heads;
     e->hp = c.pool_heads * 64;
@@ -782,6 +883,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth, c.head_mlp_recipe);
+    d4::mlp_dims(e->posmlp, 2, 2 * c.dim, c.dim, decoder ? c.decoder_pos_mlp_depth : 0, c.head_mlp_recipe);      // D4:3526-3532
     if (const char* gm = getenv("D4_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);     // 0 disables graph replay
     d4::engine_layout(e, false);
     *out = e;
@@ -869,6 +971,7 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
                   const int64_t* prev_actions, const float* prev_cont, const int64_t* tasks, int batch, int frames,
                   int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream) {
     D4_REQUIRE(e && latents && signal_levels, "null argument");
+    D4_REQUIRE(!e->decoder, "d4_wm_forward needs a dynamics engine");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int sl, rc;
     if ((rc = step_log2_of(step_size, &sl))) return rc;
@@ -895,8 +998,28 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
     return 0;
 }
 
+int d4_decoder_forward(d4_engine* e, const float* latents, const float* noised_video, int time_index, int batch, int frames,
+                       float* pred_video, void* stream) {
+    D4_REQUIRE(e && latents && noised_video && pred_video, "null argument");
+    D4_REQUIRE(e->decoder, "d4_decoder_forward needs an engine created with mode = D4_MODE_DECODER");
+    D4_REQUIRE(batch >= 1 && batch <= e->maxB && frames >= 1 && frames <= e->maxTq, "batch / frames exceed the decoder engine's capacity (%d x %d)", e->maxB, e->maxTq);
+    D4_REQUIRE(time_index >= 0 && time_index < e->c.decoder_flow_steps, "flow step %d outside [0, %d)", time_index, e->c.decoder_flow_steps);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const d4_config& c = e->c;
+    int rc;
+    if ((rc = d4::video_to_patches(noised_video, e->dec_in, batch, c.channels, frames, e->nph, e->npw, c.patch_size, s))) return rc;
+    if ((rc = d4::engine_forward(e, latents, batch, frames, 0, time_index, nullptr, false, s))) return rc;
+    return d4::patches_to_video(e->dec_out, pred_video, batch, c.channels, frames, e->nph, e->npw, c.patch_size, s);
+}
+
+int d4_euler_step(float* x, const float* pred, int64_t n, float one_minus_t, float dt, void* stream) {
+    D4_REQUIRE(x && pred && n >= 0 && n < (int64_t)1 << 31, "euler_step: bad arguments");
+    return d4::euler_step(x, (int)n, pred, (int)n, 1, (int)n, one_minus_t, dt, static_cast<hipStream_t>(stream));
+}
+
 int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     D4_REQUIRE(e && io, "null argument");
+    D4_REQUIRE(!e->decoder, "d4_rollout needs a dynamics engine");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const d4_config& c = e->c;
     const int B = io->batch, T = io->time_steps, P = io->prompt_frames, K = io->num_steps;

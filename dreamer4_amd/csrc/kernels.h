@@ -191,6 +191,11 @@ struct SampleArgs {
     float cont_temperature = 1.f;
 };
 int sample_actions_terminals(const SampleArgs& p, hipStream_t s);
+// tokenizer decoder glue: video <-> patch rows ('b c t (h p1) (w p2) <-> (b t h w) (p1 p2 c)', D4:3556, 3896), token packing, coordinate grid
+int video_to_patches(const float* video, float* patches, int B, int C, int T, int nh, int nw, int ps, hipStream_t s);
+int patches_to_video(const float* patches, float* video, int B, int C, int T, int nh, int nw, int ps, hipStream_t s);
+int decoder_pack_tokens(float* tokens, float* compact, const float* pos, const float* img, const float* lat, int frames, int P, int n_lat, int n_total, int D, hipStream_t s);
+int coord_grid(float* out, int nh, int nw, int ld, hipStream_t s);
 int cunembed_gather(const float* U, float* w, int nc, int mtp, int d, hipStream_t s);
 int cunembed_scatter_grad(const float* g, float* dU, int nc, int mtp, int d, hipStream_t s);
 

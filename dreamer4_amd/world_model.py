@@ -109,7 +109,7 @@ _NOT_BOUND = {'zero', 'ema_returns_mean', 'ema_returns_var', 'reward_loss_weight
               'discrete_action_loss_weight', 'continuous_action_loss_weight'}
 
 _UNSUPPORTED_DEFAULTS = dict(
-    video_tokenizer=None, aux_image_encoder=None, num_agents=1, num_video_views=1, mot_temporal=False,
+    aux_image_encoder=None, num_agents=1, num_video_views=1, mot_temporal=False,
     dim_proprio=None, dim_state=None, dim_critic_state=None, critic_state_embedder=None,
     spatial_pre_encoder_depth=0, action_pre_encoder_depth=0, actor_depth=0, critic_depth=0,
     pred_orig_latent=True, use_time_rnn=False, add_reward_embed_to_agent_token=False,
@@ -145,6 +145,7 @@ class DynamicsWorldModel(nn.Module):
         ff_kwargs: dict = dict(),
         num_discrete_actions: int | tuple = 0,
         num_continuous_actions=0,
+        video_tokenizer=None,
         multi_token_pred_len=8,
         value_head_mlp_depth=3,
         policy_head_mlp_depth=3,
@@ -183,6 +184,13 @@ class DynamicsWorldModel(nn.Module):
             raise NotImplementedError('only the default hl_gauss reward/value encoder is implemented')
         if attn_kwargs or transformer_kwargs or ff_kwargs:
             raise NotImplementedError('attn_kwargs / transformer_kwargs / ff_kwargs must be empty (reference defaults)')
+        # the tokenizer is only used to decode generated latents (generate(return_decoded_video=True), dreamer4.py:6694-6711); like
+        # the reference, its latent shape provides the defaults.  Kept out of the module tree (its weights are not this model's).
+        object.__setattr__(self, 'video_tokenizer', video_tokenizer)
+        if video_tokenizer is not None:
+            num_latent_tokens = num_latent_tokens if num_latent_tokens is not None else video_tokenizer.num_latent_tokens
+            assert video_tokenizer.num_latent_tokens == num_latent_tokens and video_tokenizer.dim_latent == dim_latent, \
+                'latent shape of the video tokenizer does not match the world model'
         if num_latent_tokens is None:
             raise AssertionError('`num_latent_tokens` must be set')
         if attn_dim_head not in (16, 32, 64):
@@ -661,8 +669,11 @@ class DynamicsWorldModel(nn.Module):
         Extra keyword-only arguments: `noise` injects the four per-frame random draws
         (`latent`, `context` (F,B,n,dl) normal; `gumbel_u` (F,B,A), `bern_u` (F,B) uniform) for
         parity runs; otherwise they are drawn on the device from `generator`."""
-        if prompt is not None or return_decoded_video:
-            raise NotImplementedError('video prompts / decoding need the VideoTokenizer, which is out of scope (SURVEY.md 8f)')
+        if prompt is not None:
+            raise NotImplementedError('video prompts need the VideoTokenizer encoder, which is out of scope (SURVEY.md 8f-2)')
+        return_decoded_video = (self.video_tokenizer is not None) if return_decoded_video is None else return_decoded_video      # dreamer4.py:6695
+        if return_decoded_video and self.video_tokenizer is None:
+            raise AssertionError('return_decoded_video=True needs a video_tokenizer')
         if latent_gene_ids is not None or prompt_proprio is not None or aug_id not in (False, None, 0):
             raise NotImplementedError('latent genes / proprio / aug conditioning are not implemented')
         assert agent_index == 0
@@ -789,15 +800,20 @@ class DynamicsWorldModel(nn.Module):
         else:
             self._live_cache = None
         latents = latents[:, :Tp].clamp(-1., 1.)
+        video = None
+        if return_decoded_video:                                   # dreamer4.py:6699-6711
+            video = self.video_tokenizer.decode(latents, height=image_height, width=image_width, generator=generator,
+                                                noise=(noise or {}).get('video') if isinstance(noise, dict) else None)
 
         if not (return_rewards_per_frame or return_agent_actions):
-            return (latents, new_cache) if return_time_cache else latents
+            out = video if return_decoded_video else latents       # dreamer4.py:6723-6729
+            return (out, new_cache) if return_time_cache else out
 
         step_mask = torch.arange(Tp, device=dev) < lens[:, None]
         rewards = rewards[:, :Tp]
         gen = Experience(
             latents=latents,
-            video=None,
+            video=video,
             proprio=None,
             agent_embed=agent_embed[:, :Fp] if store_agent_embed else None,
             old_action_unembeds=Actions(logits[:, :Fp] if na > 0 else None, cparams[:, :Fp] if nc > 0 else None)

@@ -32,6 +32,8 @@ extern "C" {
 #endif
 
 #define D4_MAX_ACTION_TYPES 8
+#define D4_MODE_DYNAMICS 0
+#define D4_MODE_DECODER 1
 #define D4_MLP_PRE_RMS 0        /* RMSNorm -> Linear -> SiLU                        (x_mlps_pytorch create_mlp: recipe unpinned) */
 #define D4_MLP_POST_LAYER 1     /* Linear -> LayerNorm -> SiLU, bare last Linear */
 
@@ -57,6 +59,10 @@ typedef struct d4_config {
     float delight_temperature, pmpo_pos_to_neg_weight, pmpo_kl_div_loss_weight;
     int32_t pmpo_reverse_kl;
     float hl_gauss_sigma_to_bin_ratio, hl_gauss_eps, value_min, value_max;
+    /* mode D4_MODE_DECODER: the engine is the video tokenizer's decoder (VideoDecoderNetwork, D4:3490-3682) instead of the dynamics
+     * model — the same trunk kernels over [patches | latent tokens] per frame; constructor arguments of VideoTokenizer (D4:3686-3764). */
+    int32_t mode;
+    int32_t patch_size, channels, image_height, image_width, decoder_flow_steps, decoder_pos_mlp_depth;
     /* capacities the workspace is sized for */
     int32_t max_batch;            /* trajectories per call */
     int32_t max_frames;           /* KV-cache capacity in frames (prompt + generated) */
@@ -113,6 +119,18 @@ int d4_engine_cache_import(d4_engine* e, const float* src, int batch, int frames
 int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_levels, int step_size,
                   const int64_t* prev_actions, const float* prev_cont, const int64_t* tasks, int batch, int frames,
                   int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream);
+
+/* VideoTokenizer.decode_step (D4:4137-4184) on an engine created with mode = D4_MODE_DECODER: one evaluation of the decoder.
+ *   latents       [batch][frames][n][dl]
+ *   noised_video  [batch][channels][frames][H][W]   the flow sample being denoised (pure noise on the first step, D4:4212)
+ *   time_index    flow step i in [0, decoder_flow_steps)   (time_embed row, D4:4155)
+ * Output: pred_video [batch][channels][frames][H][W] (the predicted clean video).  VideoTokenizer.decode's Euler update between
+ * steps (D4:4226-4230) is d4_euler_step. */
+int d4_decoder_forward(d4_engine* e, const float* latents, const float* noised_video, int time_index, int batch, int frames,
+                       float* pred_video, void* stream);
+/* x += (pred - x) / one_minus_t * dt, elementwise over n floats: the flow-matching Euler step of generate (D4:6567-6580) and of
+ * VideoTokenizer.decode (D4:4226-4230). */
+int d4_euler_step(float* x, const float* pred, int64_t n, float one_minus_t, float dt, void* stream);
 
 /* DynamicsWorldModel.generate(...) D4:6308-6774 with every random draw injected. */
 typedef struct d4_rollout_io {

@@ -26,6 +26,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   postln.npz       head MLPs in the Linear -> LayerNorm -> SiLU recipe (weights_postln.npz): rollout, ppo / pmpo losses and gradients
   continuous.npz   continuous (Beta) actions: a mixed discrete + continuous model (weights_continuous.npz: rollout, ppo / spo / pmpo
                    losses and gradients) and a continuous-only one (weights_contonly.npz: tempered rollout, env-wrapper chained calls)
+  decode.npz       VideoTokenizer.decode of a reference tokenizer (weights_decode.npz = the decoder half of its state_dict): two flow steps
 """
 from __future__ import annotations
 
@@ -283,7 +284,47 @@ def gen_continuous():
     print('continuous margins', out['cached_margin'], out['cached_beta_margin'], out['only_beta_margin'], out['env_beta_margin'], 'lens', out['cached_lens'], out['only_lens'])
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous)
+CFG_DECODE = dict(dim=32, dim_latent=8, patch_size=4, image_height=16, image_width=24, num_latent_tokens=6, decoder_depth=3, time_block_every=2,
+                  attn_heads=2, attn_dim_head=64, channels=3, decoder_pos_mlp_depth=2, decoder_flow_steps=2)
+
+
+def gen_decode():
+    """decode.npz / weights_decode.npz: VideoTokenizer.decode (D4:4186-4237) of the reference tokenizer — the decoder half of its
+    state_dict, latents, the injected initial flow sample (D4:4212) and the decoded video; two flow steps, one time layer."""
+    D4 = load_reference()
+    torch.manual_seed(41)
+    tok = D4.VideoTokenizer(dim=CFG_DECODE['dim'], dim_latent=CFG_DECODE['dim_latent'], patch_size=CFG_DECODE['patch_size'],
+                            image_height=CFG_DECODE['image_height'], image_width=CFG_DECODE['image_width'],
+                            num_latent_tokens=CFG_DECODE['num_latent_tokens'], encoder_depth=1, decoder_depth=CFG_DECODE['decoder_depth'],
+                            time_block_every=CFG_DECODE['time_block_every'], attn_heads=CFG_DECODE['attn_heads'], attn_dim_head=CFG_DECODE['attn_dim_head'],
+                            channels=CFG_DECODE['channels'], decoder_pos_mlp_depth=CFG_DECODE['decoder_pos_mlp_depth'],
+                            decoder_flow_steps=CFG_DECODE['decoder_flow_steps'], lpips_loss_weight=0.).eval()
+    g = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for k, p in tok.named_parameters():
+            if p.ndim == 1 and ('norm' in k or k.endswith('.0.weight')):
+                p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
+            if k.endswith('gamma'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    keep = ('latents_to_decoder.', 'time_embed.', 'noised_patch_to_tokens.', 'decoder.')
+    W = {k: v.detach().clone().float() for k, v in tok.state_dict().items() if k.startswith(keep)}
+    save_weights('weights_decode.npz', W, CFG_DECODE)
+    B, T = 2, 3
+    lat = torch.randn(B, T, 6, 8, generator=g).clamp(-1., 1.)
+    noise = torch.randn(B, 3, T, 16, 24, generator=g)
+    saved = D4.randn
+    D4.randn = lambda *a, **k: noise.clone()
+    try:
+        with torch.no_grad():
+            video, preds = tok.decode(lat, return_recons_across_steps=True)
+    finally:
+        D4.randn = saved
+    out = dict(latents=npy(lat), noise=npy(noise), video=npy(video), pred_step0=npy(preds[0]))
+    np.savez(os.path.join(OUT, 'decode.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('decode video', tuple(video.shape), 'abs max', float(video.abs().max()))
+
+
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode)
 
 
 def main():

@@ -265,7 +265,8 @@ class TrunkCache:
 
 def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='transformer.', trace: dict | None = None):
     """AxialSpaceTimeTransformer.forward D4:2927-3267 (defaults: value residual, attn pools,
-    final special cross-attn, no final norm).  tokens (b, t, s, d).  When a non-empty cache is
+    final special cross-attn; the final RMSNorm is applied when the weights hold one — the dynamics model builds its trunk
+    with final_norm=False, the tokenizer's decoder with the default True).  tokens (b, t, s, d).  When a non-empty cache is
     given and t > 1 only the last frame is processed (D4:2960-2961)."""
     b, t, s, d = tokens.shape
     h, dh = cfg.attn_heads, cfg.attn_dim_head
@@ -328,6 +329,8 @@ def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='tr
     tokens = attention_pool(cfg, W, pre + 'final_attn_pool.', tokens, layer_hiddens)
     if trace is not None:
         trace['final_pool_out'] = tokens
+    if pre + 'final_norm.weight' in W:                                   # D4:3246
+        tokens = rmsnorm(tokens, W[pre + 'final_norm.weight'])
 
     new_cache = TrunkCache(kv=new_kv, token_count=token_count + t)
     return tokens, new_cache
@@ -721,6 +724,69 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
         out.update(actions_cont=cont_actions, log_probs_cont=torch.cat(cont_log_probs, dim=1),
                    old_cont_params=policy_cont_params(cfg, W, policy_embeds))
     return out
+
+
+# ----------------------------------------------------------------------------- tokenizer decode
+
+@dataclass
+class TokenizerConfig:
+    """VideoTokenizer constructor arguments the decode path reads (names follow D4:3686-3764); supported subset = the defaults:
+    flow decoder with `decoder_flow_steps` Euler steps, no slot attention / causal conv / MOSS / aug conditioning / PoPE."""
+    dim: int
+    dim_latent: int
+    patch_size: int
+    image_height: int
+    image_width: int
+    num_latent_tokens: int = 64
+    decoder_depth: int = 4
+    time_block_every: int = 4
+    attn_heads: int = 8
+    attn_dim_head: int = 64
+    attn_softclamp_value: float = 50.
+    channels: int = 3
+    decoder_pos_mlp_depth: int = 2
+    decoder_flow_steps: int = 1
+    head_mlp_recipe: str = 'pre_rms'
+
+    def trunk(self) -> Config:
+        """The decoder's AxialSpaceTimeTransformer (D4:3582-3594: constructor defaults, i.e. ONE special token — the last latent
+        token — with the final special cross-attention, attention pools, value residual and the final RMSNorm)."""
+        return Config(dim=self.dim, dim_latent=self.dim_latent, num_latent_tokens=self.num_latent_tokens, depth=self.decoder_depth,
+                      time_block_every=self.time_block_every, attn_heads=self.attn_heads, attn_dim_head=self.attn_dim_head,
+                      attn_softclamp_value=50.)          # (the decoder does not forward attn_softclamp_value: D4:3582-3594)
+
+
+def tokenizer_decode_step(tc: TokenizerConfig, W, latents, noised_video, time_index):
+    """VideoTokenizer.decode_step D4:4137-4184 + VideoDecoderNetwork.forward D4:3599-3682.  latents (b, t, n, dl),
+    noised_video (b, c, t, H, W) -> predicted clean video (b, c, t, H, W)."""
+    b, t = latents.shape[:2]
+    p, c = tc.patch_size, tc.channels
+    nh, nw = tc.image_height // p, tc.image_width // p
+    lat = latents @ W['latents_to_decoder.weight'].t() + W['time_embed.weight'][time_index]                      # D4:4151-4157
+    # noised video -> patch tokens: 'b c t (h p1) (w p2) -> b t h w (p1 p2 c)', Linear, LayerNorm without bias    D4:3895-3899
+    x = noised_video.reshape(b, c, t, nh, p, nw, p).permute(0, 2, 3, 5, 4, 6, 1).reshape(b, t, nh, nw, p * p * c)
+    x = x @ W['noised_patch_to_tokens.1.weight'].t() + W['noised_patch_to_tokens.1.bias']
+    x = layernorm(x, W['noised_patch_to_tokens.2.weight'], 0.)
+    # positional embedding of the patch grid: MLP of the (row, column) coordinates in [-1, 1]                      D4:3617-3625
+    gy, gx = torch.meshgrid(torch.linspace(-1., 1., nh), torch.linspace(-1., 1., nw), indexing='ij')
+    pos = mlp(W, 'decoder.to_decoder_pos_emb.', torch.stack((gy, gx), dim=-1), mlp_num_layers(tc.decoder_pos_mlp_depth), tc.head_mlp_recipe)
+    spatial = (pos + x).reshape(b, t, nh * nw, tc.dim)
+    tokens = torch.cat((spatial, lat), dim=2)                                                                     # [patches | latents]  D4:3654
+    tokens, _ = transformer(tc.trunk(), W, tokens, None, pre='decoder.transformer.')
+    patches = tokens[:, :, :nh * nw] @ W['decoder.tokens_to_patch.0.weight'].t() + W['decoder.tokens_to_patch.0.bias']
+    # 'b t h w (p1 p2 c) -> b c t (h p1) (w p2)'                                                                   D4:3556
+    return patches.reshape(b, t, nh, nw, p, p, c).permute(0, 6, 1, 2, 4, 3, 5).reshape(b, c, t, nh * p, nw * p)
+
+
+def tokenizer_decode(tc: TokenizerConfig, W, latents, noise):
+    """VideoTokenizer.decode D4:4186-4237 with its one random draw injected: noise (b, c, t, H, W) normal (D4:4212)."""
+    steps = tc.decoder_flow_steps
+    video = noise
+    for i in range(steps):
+        time = i / steps
+        pred = tokenizer_decode_step(tc, W, latents, video, i)
+        video = video + (pred - video) / (1. - time) * (1. / steps)
+    return video
 
 
 # ----------------------------------------------------------------------------- learning
