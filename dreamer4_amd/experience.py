@@ -1,8 +1,10 @@
 """`Experience` / `Actions`: the hand-off object between generate() and learn_from_experience().
 
-Field-for-field the reference dataclass (dreamer4.py:132-154, 240-246) and its
-`combine_experiences` (dreamer4.py:248-309); the replay-buffer adapters
-(dreamer4.py:172-236) depend on the third-party memmap_replay_buffer and are out of scope.
+Field-for-field the reference dataclass (dreamer4.py:132-154, 240-246), its `combine_experiences`
+(dreamer4.py:248-309) and the flat-dictionary form the replay buffer stores (`to_buffer_dict` /
+`from_buffer_dict`, dreamer4.py:172-186, 218-236).  The buffer object itself is the third-party
+`memmap_replay_buffer.ReplayBuffer` (not in this image): `create_memmap_replay_buffer` /
+`add_to_memmap_buffer` import it lazily, exactly as the reference does, and raise ImportError without it.
 """
 from __future__ import annotations
 
@@ -39,11 +41,62 @@ class Experience:
     is_from_world_model: bool | Tensor = True
     episode_return: Tensor | None = None
 
+    _meta_fields = frozenset({'step_size', 'lens', 'is_truncated', 'terminals', 'agent_index', 'is_from_world_model', 'episode_return'})
+
     @property
     def payload(self):
         for v in (self.latents, self.video, self.critic_state):
             if v is not None:
                 return v
+
+    # ---- memmap replay buffer format (dreamer4.py:172-236): per-step data fields and per-episode meta fields, `Actions` flattened
+    # to `<field>_discrete` / `<field>_continuous`
+    def to_buffer_dict(self):
+        data_dict, meta_dict = {}, {}
+        for f in fields(self):
+            k, v = f.name, getattr(self, f.name)
+            target = meta_dict if k in self._meta_fields else data_dict
+            if isinstance(v, Actions):
+                if v.discrete is not None:
+                    target[f'{k}_discrete'] = v.discrete
+                if v.continuous is not None:
+                    target[f'{k}_continuous'] = v.continuous
+            elif v is not None:
+                target[k] = v
+        return data_dict, meta_dict
+
+    @classmethod
+    def from_buffer_dict(cls, data_dict):
+        kwargs = {}
+        for f in fields(cls):
+            k = f.name
+            dk, ck = f'{k}_discrete', f'{k}_continuous'
+            if dk in data_dict or ck in data_dict:
+                kwargs[k] = Actions(data_dict.get(dk), data_dict.get(ck))
+            elif k in data_dict:
+                kwargs[k] = data_dict[k]
+        return cls(**kwargs)
+
+    @classmethod
+    def create_memmap_replay_buffer(cls, template_experience, *args, **kwargs):
+        from memmap_replay_buffer import ReplayBuffer        # third-party, as in the reference (dreamer4.py:190)
+        data_dict, meta_dict = template_experience.to_buffer_dict()
+
+        def infer(v, is_meta=False):
+            if not torch.is_tensor(v):
+                return type(v).__name__
+            return (str(v.dtype).replace('torch.', '').replace('float32', 'float').replace('int64', 'int'), tuple(v.shape[1:] if is_meta else v.shape[2:]))
+
+        return ReplayBuffer(*args, fields={k: infer(v) for k, v in data_dict.items()},
+                            meta_fields={k: infer(v, True) for k, v in meta_dict.items()}, **kwargs)
+
+    def add_to_memmap_buffer(self, buffer):
+        data_dict, meta_dict = self.to_buffer_dict()
+        batch_size, time_steps = self.payload.shape[:2]
+        meta_batch = {k: (v if torch.is_tensor(v) else [v] * batch_size) for k, v in meta_dict.items()}
+        with buffer.batched_episode(batch_size=batch_size, **meta_batch):
+            for step in range(time_steps):
+                buffer.store_batch(**{k: v[:, step] for k, v in data_dict.items()})
 
     def cpu(self):
         return self.to(torch.device('cpu'))

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from dreamer4_amd import _lib
+from dreamer4_amd.checkpoint import SaveLoad
 from dreamer4_amd.world_model import MLP_RECIPES, _linear_b, _linear_w, _register, mlp_param_specs, mlp_widths
 
 _UNSUPPORTED = dict(
@@ -27,11 +28,13 @@ _UNSUPPORTED = dict(
 )
 
 
-class VideoTokenizer(nn.Module):
+class VideoTokenizer(SaveLoad, nn.Module):
     def __init__(self, dim, dim_latent, patch_size, image_size=None, image_height=None, image_width=None, num_latent_tokens=64,
                  encoder_depth=4, decoder_depth=4, time_block_every=4, attn_dim_head=64, attn_heads=8, decoder_pos_mlp_depth=2,
                  channels=3, decoder_flow_steps=1, head_mlp_recipe='pre_rms', **kwargs):
+        config = dict(locals())
         super().__init__()
+        self._record_config(config)
         for k, v in kwargs.items():
             if k in _UNSUPPORTED:
                 if v != _UNSUPPORTED[k]:

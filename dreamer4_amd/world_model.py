@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from dreamer4_amd import _lib
+from dreamer4_amd.checkpoint import SaveLoad
 from dreamer4_amd.experience import Actions, Experience
 
 
@@ -122,7 +123,7 @@ _UNSUPPORTED_DEFAULTS = dict(
 )
 
 
-class DynamicsWorldModel(nn.Module):
+class DynamicsWorldModel(SaveLoad, nn.Module):
     def __init__(
         self,
         dim,
@@ -166,7 +167,9 @@ class DynamicsWorldModel(nn.Module):
         **kwargs,
     ):
         """`head_mlp_recipe` is not a reference argument: it names the layer recipe of x_mlps_pytorch's normed MLP (see MLP_RECIPES)."""
+        config = dict(locals())
         super().__init__()
+        self._record_config(config)
         if head_mlp_recipe not in MLP_RECIPES:
             raise ValueError(f'head_mlp_recipe must be one of {sorted(MLP_RECIPES)}')
         self.head_mlp_recipe = head_mlp_recipe

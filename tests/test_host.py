@@ -128,3 +128,36 @@ def test_custom_ops_are_registered_with_the_dispatcher_and_traceable():
         assert torch.ops.d4hip.hl_gauss_to_scalar(torch.empty(7, 255), torch.empty(255)).shape == (7,)
     with pytest.raises(D4Error, match='no CPU fallback'):
         torch.ops.d4hip.rmsnorm(torch.zeros(2, 8), torch.ones(8), 1e-6)
+
+
+def test_experience_replay_buffer_dictionaries_round_trip():
+    """dreamer4.py:172-186, 218-236: `Actions` are flattened to <field>_discrete / <field>_continuous, per-episode fields go to the meta dict."""
+    e = Experience(latents=torch.zeros(2, 3, 4, 5), rewards=torch.ones(2, 3), actions=Actions(torch.zeros(2, 3, 1, dtype=torch.long), torch.rand(2, 3, 2)),
+                   log_probs=Actions(torch.zeros(2, 3, 1), None), lens=torch.tensor([3, 2]), is_truncated=torch.tensor([True, False]), step_size=16)
+    data, meta = e.to_buffer_dict()
+    assert set(data) == {'latents', 'rewards', 'actions_discrete', 'actions_continuous', 'log_probs_discrete'}
+    assert set(meta) == {'step_size', 'lens', 'is_truncated', 'agent_index', 'is_from_world_model'}
+    back = Experience.from_buffer_dict({**data, **meta})
+    assert torch.equal(back.actions.continuous, e.actions.continuous) and back.log_probs.continuous is None and back.step_size == 16
+    with pytest.raises(ImportError):
+        Experience.create_memmap_replay_buffer(e, './x', max_episodes=1, max_timesteps=4)
+
+
+def test_save_load_and_init_and_load(tmp_path):
+    """@save_load surface of the reference (dreamer4.py:4660; trainers.py:1083-1088): save / load / init_and_load rebuild the model from the file."""
+    from dreamer4_amd import VideoTokenizer
+    m = small_model(num_continuous_actions=2, head_mlp_recipe='post_layer')
+    p = tmp_path / 'dynamics.pt'
+    m.save(p)
+    m2 = DynamicsWorldModel.init_and_load(p)
+    assert m2.num_continuous_actions == 2 and m2.head_mlp_recipe == 'post_layer' and m2.depth == m.depth
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    m3 = small_model(num_continuous_actions=2, head_mlp_recipe='post_layer')
+    with torch.no_grad():
+        m3.register_tokens.zero_()
+    m3.load(p)
+    assert torch.equal(m3.register_tokens, m.register_tokens)
+    tok = VideoTokenizer(dim=32, dim_latent=8, patch_size=4, image_size=16, num_latent_tokens=6, decoder_depth=2)
+    tok.save(tmp_path / 'tok.pt')
+    tok2 = VideoTokenizer.init_and_load(tmp_path / 'tok.pt')
+    assert tok2.image_height == 16 and torch.equal(tok2.state_dict()['latents_to_decoder.weight'], tok.state_dict()['latents_to_decoder.weight'])
