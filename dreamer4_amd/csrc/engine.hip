@@ -301,9 +301,15 @@ int engine_resolve(d4_engine* e) {
     }
     e->reward_norm = r.get("to_reward_pred.params.0", (int64_t)c.multi_token_pred_len * D);
     e->reward_w = r.get("to_reward_pred.params.1", (int64_t)c.multi_token_pred_len * c.reward_num_bins * D);
-    e->reward_centers = r.get("reward_encoder.centers", c.reward_num_bins);
-    e->value_centers = r.get("value_encoder.centers", c.value_num_bins);
-    e->value_support = r.get("value_encoder.support", c.value_num_bins + 1);
+    if (c.reward_encoder_type == 1) {       // symexp_two_hot: softmax . bin_values; the learner's targets are two-hot over the same values
+        e->reward_centers = r.get("reward_encoder.bin_values", c.reward_num_bins);
+        e->value_centers = r.get("value_encoder.bin_values", c.value_num_bins);
+        e->value_support = e->value_centers;
+    } else {
+        e->reward_centers = r.get("reward_encoder.centers", c.reward_num_bins);
+        e->value_centers = r.get("value_encoder.centers", c.value_num_bins);
+        e->value_support = r.get("value_encoder.support", c.value_num_bins + 1);
+    }
     r.mlp(e->policy, "policy_head.");
     r.mlp(e->value, "value_head.");
     if (c.predict_terminals) r.mlp(e->terminal, "to_state_terminal_pred.0.");
@@ -879,6 +885,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->Tcap = c.max_frames > e->maxTq ? c.max_frames : e->maxTq;
     e->Fr = e->maxB * e->maxTq;
     e->Mmax = e->Fr * e->S;
+    D4_REQUIRE(c.reward_encoder_type == 0 || c.reward_encoder_type == 1, "unknown reward_encoder_type %d", c.reward_encoder_type);
     D4_REQUIRE(c.head_mlp_recipe == D4_MLP_PRE_RMS || c.head_mlp_recipe == D4_MLP_POST_LAYER, "unknown head_mlp_recipe %d", c.head_mlp_recipe);
     d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth, c.head_mlp_recipe);
@@ -1193,7 +1200,7 @@ int d4_profile_bf16_read(double* ms, double* flops, int64_t* count) { return d4:
 int d4_profile_enable(int on) { return d4::gemm_profile_enable(on); }
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { return d4::gemm_profile_read(ms, flops, count, nclass); }
 int d4_profile_classes(void) { return d4::gemm_profile_classes(); }
-int d4_gemm_force_config(int id) { return d4::gemm_force_config(id); }
+int d4_gemm_force_config(int id) { if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1); return d4::gemm_force_config(id >= 200 ? -1 : id); }
 const char* d4_profile_class_name(int c) { return d4::gemm_profile_class_name(c); }
 
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {

@@ -261,17 +261,47 @@ bool gemm_bf16_applicable(const GemmArgs& p) {
            ((uintptr_t)p.Wb % 16) == 0 && (p.strideW % 8) == 0;
 }
 
-// tile choice by rule (every configuration sums k in the same order with the same MFMA: identical bits)
+// tile configurations (every one sums k in the same order with the same MFMA: identical bits, so the choice is free)
+enum { B16_128x128 = 0, B16_128x128_8, B16_64x128, B16_64x64, B16_256x128_8, B16_128x64, B16_N };
+static int g_bf16_forced = -1;          // test / microbenchmark hook
+int gemm_bf16_force_config(int id) { g_bf16_forced = id; return B16_N; }
+
+template <int BK>
+static int launch_bf16_id(int id, const GemmArgs& p, hipStream_t stream) {
+    switch (id) {
+        case B16_128x128: return launch_bf16<128, 128, 2, 2, BK>(p, stream);
+        case B16_128x128_8: return launch_bf16<128, 128, 4, 2, BK>(p, stream);
+        case B16_64x128: return launch_bf16<64, 128, 2, 2, BK>(p, stream);
+        case B16_64x64: return launch_bf16<64, 64, 2, 2, BK>(p, stream);
+        case B16_256x128_8: return launch_bf16<256, 128, 4, 2, BK>(p, stream);
+        case B16_128x64: return launch_bf16<128, 64, 2, 2, BK>(p, stream);
+    }
+    return 2;
+}
+
+static bool bf16_cfg_valid(int id, const GemmArgs& p) {
+    if (id < 0 || id >= B16_N) return false;
+    if (p.flags & GEMM_SWIGLU) return id != B16_64x64 && id != B16_128x64;        // the pairing needs two 32-column sub-tiles per wave
+    return true;
+}
+
+// tile choice by rule
 int gemm_bf16(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(gemm_bf16_applicable(p), "gemm_bf16: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
     const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
     const int nb = p.batch > 0 ? p.batch : 1;
     const bool k64 = (p.K % 64) == 0;
-    const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
-    if (t128 >= 200 && p.N > 64) return k64 ? launch_bf16<128, 128, 2, 2, 64>(p, stream) : launch_bf16<128, 128, 2, 2, 32>(p, stream);
-    if (swiglu || (p.N > 64 && (int64_t)cdiv(p.M, 64) * cdiv(p.N, 128) * nb >= 200))
-        return k64 ? launch_bf16<64, 128, 2, 2, 64>(p, stream) : launch_bf16<64, 128, 2, 2, 32>(p, stream);
-    return k64 ? launch_bf16<64, 64, 2, 2, 64>(p, stream) : launch_bf16<64, 64, 2, 2, 32>(p, stream);
+    int id;
+    if (bf16_cfg_valid(g_bf16_forced, p)) id = g_bf16_forced;
+    else {
+        // measured on the config-5 shapes (tools/gemm_bf16_bench.py, profiles/r02_gemm_bf16_tiles.txt): 64x64 with 4 waves wins while a
+        // GEMM has fewer than ~300 tiles of 128x128 (it is launch / first-tile latency, not matrix work); above that 128x128 with 8 waves
+        const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
+        if (t128 >= 300 && p.N > 64) id = B16_128x128_8;
+        else if (swiglu) id = t128 >= 150 ? B16_128x128_8 : B16_64x128;
+        else id = B16_64x64;
+    }
+    return k64 ? launch_bf16_id<64>(id, p, stream) : launch_bf16_id<32>(id, p, stream);
 }
 
 }  // namespace d4

@@ -37,6 +37,7 @@ int gemm(const GemmArgs& p, hipStream_t stream);
 // bf16 MFMA path (gemm_bf16.hip): A fp32 rounded to bf16 on the way into LDS, W pre-converted, fp32 accumulate / epilogue
 bool gemm_bf16_applicable(const GemmArgs& p);
 int gemm_bf16(const GemmArgs& p, hipStream_t stream);
+int gemm_bf16_force_config(int id);                          // test / microbenchmark hook; returns the number of configurations
 int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
 void gemm_bf16_profile_enable(int stride);
 int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count);

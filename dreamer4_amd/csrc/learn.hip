@@ -274,6 +274,9 @@ __global__ void policy_loss_kernel(PolicyLossArgs p) {
 
 // ------------------------------------------------------------------------------------ value loss fwd + bwd
 // one wave per row: HL-Gauss target probs (erf), CE against log_softmax(value bins)
+// (TWO_HOT: SymExpTwoHot.forward D4:1001-1040 — `support` holds the `bins` bin values; the target puts (right - v) / (right - left) on the
+//  bin to the left of v and the rest on its right neighbour)
+template <bool TWO_HOT>
 __global__ __launch_bounds__(256) void value_loss_kernel(const float* vbins, int ld, const float* returns, const float* mask,
                                                          const float* scal, const float* support, int R, int bins,
                                                          float sigma_sqrt2, float hl_eps, float vmin, float vmax,
@@ -284,9 +287,23 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* vbins, int
     const float count = fmaxf(scal[1], 1.f);
     const float mk = mask[r];
     const float* v = vbins + (int64_t)r * ld;
-    float ret = fminf(fmaxf(returns[r], vmin), vmax);
-    const float z = erff((support[bins] - ret) / sigma_sqrt2) - erff((support[0] - ret) / sigma_sqrt2);
+    float ret = fminf(fmaxf(returns[r], TWO_HOT ? support[0] : vmin), TWO_HOT ? support[bins - 1] : vmax);
+    int li = 0, ri = 0;
+    float wl = 0.f;
+    if (TWO_HOT) {
+        // torch.searchsorted(bin_values, v): first index with bin_values[i] >= v (binary search, wave-uniform)
+        int lo = 0, hi = bins;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (support[mid] < ret) lo = mid + 1; else hi = mid; }
+        li = lo - 1 > 0 ? lo - 1 : 0;
+        ri = li + 1 < bins - 1 ? li + 1 : bins - 1;
+        wl = (support[ri] - ret) / (support[ri] - support[li]);
+    }
+    const float z = TWO_HOT ? 1.f : erff((support[bins] - ret) / sigma_sqrt2) - erff((support[0] - ret) / sigma_sqrt2);
     const float zc = fmaxf(z, hl_eps);
+    auto target = [&](int c) -> float {
+        if (TWO_HOT) return c == ri ? 1.f - wl : (c == li ? wl : 0.f);            // (scatter order of the reference: right written last)
+        return (erff((support[c + 1] - ret) / sigma_sqrt2) - erff((support[c] - ret) / sigma_sqrt2)) / zc;
+    };
     float mx = -FLT_MAX;
     for (int c = lane; c < bins; c += 64) mx = fmaxf(mx, v[c]);
     mx = wave_max(mx);
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* vbins, int
     const float lse = mx + logf(wave_sum(se));
     float loss = 0.f, psum = 0.f;
     for (int c = lane; c < bins; c += 64) {
-        const float pr = (erff((support[c + 1] - ret) / sigma_sqrt2) - erff((support[c] - ret) / sigma_sqrt2)) / zc;
+        const float pr = target(c);
         loss -= pr * (v[c] - lse);
         psum += pr;
     }
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* vbins, int
     psum = wave_sum(psum);
     const float scale = mk / count;
     for (int c = lane; c < bins; c += 64) {
-        const float pr = (erff((support[c + 1] - ret) / sigma_sqrt2) - erff((support[c] - ret) / sigma_sqrt2)) / zc;
+        const float pr = target(c);
         dv[(int64_t)r * ld + c] = (expf(v[c] - lse) * psum - pr) * scale;
     }
     for (int c = bins + lane; c < ld; c += 64) dv[(int64_t)r * ld + c] = 0.f;
@@ -518,9 +535,12 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
     if ((rc = mlp_forward(e, e->value, io->agent_embed, D, R, e->l_vbins, vld, save_v, s))) return rc;
     {
         const float sigma = c.hl_gauss_sigma_to_bin_ratio * (c.value_max - c.value_min) / (float)c.value_num_bins;
-        hipLaunchKernelGGL(value_loss_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, e->l_vbins, vld, e->l_returns, mask_keep, scal,
-                           e->value_support, R, c.value_num_bins, sqrtf(2.f) * sigma, c.hl_gauss_eps, c.value_min, c.value_max,
-                           e->l_dvbins, row_vl);
+        if (c.reward_encoder_type == 1)
+            hipLaunchKernelGGL(value_loss_kernel<true>, dim3(cdiv(R, 4)), dim3(256), 0, s, e->l_vbins, vld, e->l_returns, mask_keep, scal,
+                               e->value_support, R, c.value_num_bins, sqrtf(2.f) * sigma, c.hl_gauss_eps, c.value_min, c.value_max, e->l_dvbins, row_vl);
+        else
+            hipLaunchKernelGGL(value_loss_kernel<false>, dim3(cdiv(R, 4)), dim3(256), 0, s, e->l_vbins, vld, e->l_returns, mask_keep, scal,
+                               e->value_support, R, c.value_num_bins, sqrtf(2.f) * sigma, c.hl_gauss_eps, c.value_min, c.value_max, e->l_dvbins, row_vl);
         D4_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(reduce1_kernel<RED_SUM>, dim3(1), dim3(1024), 0, s, row_pl, nullptr, scal, (int64_t)R, scal + 4);

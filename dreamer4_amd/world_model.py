@@ -183,8 +183,9 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
                 raise TypeError(f'unknown argument {k!r}')
             if v != _UNSUPPORTED_DEFAULTS[k]:
                 raise NotImplementedError(f'{k}={v!r} is outside the supported imagination-path subset (SURVEY.md section 8)')
-        if reward_encoder_type != 'hl_gauss':
-            raise NotImplementedError('only the default hl_gauss reward/value encoder is implemented')
+        if reward_encoder_type not in ('hl_gauss', 'symexp_two_hot'):
+            raise AssertionError(f'unknown reward encoder type {reward_encoder_type}')
+        self.reward_encoder_type = reward_encoder_type
         if attn_kwargs or transformer_kwargs or ff_kwargs:
             raise NotImplementedError('attn_kwargs / transformer_kwargs / ff_kwargs must be empty (reference defaults)')
         # the tokenizer is only used to decode generated latents (generate(return_decoded_video=True), dreamer4.py:6694-6711); like
@@ -211,7 +212,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
             bins = kw.pop('num_bins', 255)
             ratio = kw.pop('sigma_to_bin_ratio', 2.)
             eps = kw.pop('eps', 1e-10)
-            if kw:
+            if kw or (reward_encoder_type == 'symexp_two_hot' and (ratio != 2. or eps != 1e-10)):
                 raise NotImplementedError(f'reward/value encoder options {sorted(kw)} are not implemented')
             return rng, bins, ratio, eps
 
@@ -342,6 +343,10 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         # constructor-built buffers of the HL-Gauss encoders (hl_gauss_pytorch.HLGaussLoss.support / centers)
         for name, rng, bins in (('reward_encoder', self.reward_range, self.reward_num_bins),
                                 ('value_encoder', self.value_range, self.value_num_bins)):
+            if self.reward_encoder_type == 'symexp_two_hot':          # SymExpTwoHot.bin_values (a persistent buffer of the reference, dreamer4.py:958-963)
+                values = torch.linspace(rng[0], rng[1], bins)
+                _register(self, f'{name}.bin_values', values.sign() * (torch.exp(values.abs()) - 1.), buffer=True)
+                continue
             support = torch.linspace(rng[0], rng[1], bins + 1).float()
             _register(self, f'{name}.support', support, buffer=True, persistent=False)
             _register(self, f'{name}.centers', (support[:-1] + support[1:]) / 2, buffer=True, persistent=False)
@@ -410,6 +415,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         c.terminal_mlp_depth, c.predict_terminals = self.terminal_mlp_depth, int(self.predict_terminals)
         c.reward_num_bins, c.value_num_bins = self.reward_num_bins, self.value_num_bins
         c.head_mlp_recipe = MLP_RECIPES[self.head_mlp_recipe]
+        c.reward_encoder_type = int(self.reward_encoder_type == 'symexp_two_hot')
         c.matmul_bf16 = int(self.matmul_dtype == 'bf16')
         c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
         c.gae_discount_factor, c.gae_lambda, c.ppo_eps_clip = self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip

@@ -49,6 +49,7 @@ typedef struct d4_config {
     int32_t multi_token_pred_len;
     int32_t policy_head_mlp_depth, value_head_mlp_depth, terminal_mlp_depth, predict_terminals;
     int32_t reward_num_bins, value_num_bins;
+    int32_t reward_encoder_type;                /* 0 = hl_gauss (default, D4:1041), 1 = symexp_two_hot (D4:947): bins = symexp(linspace), two-hot targets */
     int32_t matmul_bf16;                        /* 1: trunk GEMMs on the bf16 MFMA path (bf16 weights + activations, fp32 accumulate, fp32 norms /
                                                    softmax / residual stream); 0: fp32 MFMA as the reference computes (default) */
     int32_t head_mlp_recipe;                    /* D4_MLP_PRE_RMS / D4_MLP_POST_LAYER: layer recipe of the policy / value / terminal MLPs (engine.h) */
@@ -87,7 +88,8 @@ int d4_engine_set_workspace(d4_engine* e, void* device_ptr, size_t bytes);
  * `grad` may be NULL; when given, d4_learn writes d(loss)/d(param) there (policy / value heads).
  * Pseudo-keys for buffers the reference builds in its constructor:
  *   "reward_encoder.centers" [reward_num_bins], "value_encoder.centers" [value_num_bins],
- *   "value_encoder.support" [value_num_bins + 1]. */
+ *   "value_encoder.support" [value_num_bins + 1]   (hl_gauss);
+ *   symexp_two_hot reads the reference's own buffers "reward_encoder.bin_values" / "value_encoder.bin_values" [num_bins]. */
 int d4_engine_bind(d4_engine* e, const char* key, const float* device_ptr, float* grad, int64_t numel);
 
 /* Build the fused / gamma-folded weight images in the workspace.  Call after binding, and again
@@ -224,7 +226,8 @@ int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int d4_profile_classes(void);
 const char* d4_profile_class_name(int c);
 
-/* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it).
+/* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
+ * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel.
  * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
 int d4_gemm_force_config(int id);
 

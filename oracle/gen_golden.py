@@ -26,6 +26,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   postln.npz       head MLPs in the Linear -> LayerNorm -> SiLU recipe (weights_postln.npz): rollout, ppo / pmpo losses and gradients
   continuous.npz   continuous (Beta) actions: a mixed discrete + continuous model (weights_continuous.npz: rollout, ppo / spo / pmpo
                    losses and gradients) and a continuous-only one (weights_contonly.npz: tempered rollout, env-wrapper chained calls)
+  symexp.npz       reward_encoder_type='symexp_two_hot' (weights_symexp.npz): rollout, ppo losses and gradients
   decode.npz       VideoTokenizer.decode of a reference tokenizer (weights_decode.npz = the decoder half of its state_dict): two flow steps
 """
 from __future__ import annotations
@@ -324,7 +325,33 @@ def gen_decode():
     print('decode video', tuple(video.shape), 'abs max', float(video.abs().max()))
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode)
+CFG_SYMEXP = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                  num_discrete_actions=(4,), num_tasks=0, reward_num_bins=41, value_num_bins=31, reward_range=(-3., 3.), value_range=(-4., 4.),
+                  multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1, reward_encoder_type='symexp_two_hot')
+
+
+def gen_symexp():
+    """symexp.npz / weights_symexp.npz: reward_encoder_type='symexp_two_hot' (SymExpTwoHot, D4:947-1040 — the reference's own code, no
+    stand-in): bins -> scalar in the rollout, two-hot targets in the value loss."""
+    cfg = Config(**CFG_SYMEXP)
+    m = build_reference_model(cfg, seed=51)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)
+    W = weights_of(m)
+    assert 'reward_encoder.bin_values' in W and 'value_encoder.bin_values' in W
+    save_weights('weights_symexp.npz', W, CFG_SYMEXP)
+    out = {}
+    nz = make_noise(cfg, 5, 3, 951)
+    with injected(nz):
+        e = m.generate(5, batch_size=3, return_for_policy_optimization=True)
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg))
+    learn_into(out, m, e, ('ppo',))
+    np.savez(os.path.join(OUT, 'symexp.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('symexp margin', out['cached_margin'], 'lens', out['cached_lens'], 'values', out['cached_values'][0])
+
+
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp)
 
 
 def main():

@@ -85,7 +85,7 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
     normed_mlp.RECIPE = cfg.head_mlp_recipe             # layer recipe of the stand-in normed MLP (restored below)
     torch.manual_seed(seed)
     m = D4.DynamicsWorldModel(
-        num_continuous_actions=cfg.num_continuous_actions,
+        num_continuous_actions=cfg.num_continuous_actions, reward_encoder_type=cfg.reward_encoder_type,
         dim=cfg.dim, dim_latent=cfg.dim_latent, num_latent_tokens=cfg.num_latent_tokens,
         depth=cfg.depth, time_block_every=cfg.time_block_every, attn_heads=cfg.attn_heads,
         attn_dim_head=cfg.attn_dim_head, num_spatial_tokens=cfg.num_spatial_tokens,

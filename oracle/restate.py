@@ -79,6 +79,7 @@ class Config:
     pmpo_kl_div_loss_weight: float = 0.3
     rotary_theta: float = 10000.
     num_continuous_actions: int = 0          # Beta policy head (continuous_dist_type='beta', D4:1131, 1172-1173)
+    reward_encoder_type: str = 'hl_gauss'    # or 'symexp_two_hot' (D4:947-1040)
     head_mlp_recipe: str = 'pre_rms'         # layer recipe of x_mlps_pytorch's normed MLP: 'pre_rms' | 'post_layer' (see mlp())
 
     def __post_init__(self):
@@ -453,6 +454,34 @@ def hl_gauss_to_scalar(logits, vrange, num_bins):
     return (logits.softmax(dim=-1) * centers).sum(dim=-1)
 
 
+def symexp_bin_values(vrange, num_bins):
+    v = torch.linspace(vrange[0], vrange[1], num_bins)
+    return v.sign() * (torch.exp(v.abs()) - 1.)                  # D4:958-960
+
+
+def bins_to_scalar(cfg, logits, vrange, num_bins):
+    """reward / value encoder .bins_to_scalar_value: HLGaussRewardEncoder D4:1088-1096 or SymExpTwoHot D4:987-993."""
+    if cfg.reward_encoder_type == 'symexp_two_hot':
+        return (logits.softmax(dim=-1) * symexp_bin_values(vrange, num_bins)).sum(dim=-1)
+    return hl_gauss_to_scalar(logits, vrange, num_bins)
+
+
+def symexp_two_hot(values, vrange, num_bins):
+    """SymExpTwoHot.forward D4:995-1040."""
+    bv = symexp_bin_values(vrange, num_bins)
+    shape = values.shape
+    v = values.reshape(-1).clamp(min=bv[0], max=bv[-1])
+    idx = torch.searchsorted(bv, v)
+    li = (idx - 1).clamp(min=0)
+    ri = (li + 1).clamp(max=num_bins - 1)
+    lv, rv = bv[li], bv[ri]
+    wl = (rv - v) / (rv - lv)
+    enc = torch.zeros(v.shape[0], num_bins)
+    enc.scatter_(-1, li[:, None], wl[:, None])
+    enc.scatter_(-1, ri[:, None], (1. - wl)[:, None])
+    return enc.reshape(*shape, num_bins)
+
+
 def hl_gauss_to_probs(cfg: Config, values, vrange, num_bins):
     support, _ = hl_gauss_centers(vrange, num_bins)
     sigma = cfg.hl_gauss_sigma_to_bin_ratio * (vrange[1] - vrange[0]) / num_bins
@@ -466,7 +495,7 @@ def reward_head(cfg, W, agent_embed):
     """to_reward_pred.forward_one(x, id=0) -> bins_to_scalar  D4:5067-5075, 6598-6599."""
     x = rmsnorm(agent_embed, W['to_reward_pred.params.0'][0])
     logits = x @ W['to_reward_pred.params.1'][0].t()
-    return hl_gauss_to_scalar(logits, cfg.reward_range, cfg.reward_num_bins)
+    return bins_to_scalar(cfg, logits, cfg.reward_range, cfg.reward_num_bins)
 
 
 def terminal_prob(cfg, W, denoised_latent):
@@ -689,7 +718,7 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
             ca = sample_continuous(cp, noise['beta'][f][:, None], continuous_temperature)
             cont_actions = torch.cat((cont_actions, ca), dim=1)
             cont_log_probs.append(beta_log_prob(cp, ca))
-        values.append(hl_gauss_to_scalar(value_head_bins(cfg, W, one), cfg.value_range, cfg.value_num_bins))
+        values.append(bins_to_scalar(cfg, value_head_bins(cfg, W, one), cfg.value_range, cfg.value_num_bins))
 
         latents = torch.cat((latents, x), dim=1)
         ctx_noise = torch.cat((ctx_noise, noise['context'][f][:, None]), dim=1)
@@ -914,7 +943,8 @@ def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, 
     total_policy_loss = policy_loss + entropy_loss * cfg.policy_entropy_weight
 
     vbins = value_head_bins(cfg, W, agent_embeds)
-    rbins = hl_gauss_to_probs(cfg, returns, cfg.value_range, cfg.value_num_bins)
+    rbins = symexp_two_hot(returns, cfg.value_range, cfg.value_num_bins) if cfg.reward_encoder_type == 'symexp_two_hot' else \
+        hl_gauss_to_probs(cfg, returns, cfg.value_range, cfg.value_num_bins)
     vl = -(rbins * vbins.log_softmax(dim=-1)).sum(dim=-1)
     value_loss = vl[mask].mean()
     return total_policy_loss, value_loss

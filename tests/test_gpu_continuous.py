@@ -151,3 +151,12 @@ def test_learn_without_stored_agent_embeddings_vs_reference_fixture():
     pl.backward(retain_graph=True); vl.backward()
     ref = t(g['noembed_ppo_grad_unembed'])
     close(m.action_embedder.discrete_action_unembed.grad, ref, atol=2e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-3)
+
+
+def test_symexp_two_hot_encoder_vs_reference_fixture():
+    g = load_golden('symexp.npz')
+    m = golden_model('weights_symexp.npz').cuda()
+    assert m.reward_encoder_type == 'symexp_two_hot' and 'value_encoder.bin_values' in m.state_dict()
+    e = m.generate(5, batch_size=3, return_for_policy_optimization=True, noise=golden_noise(g, 'cached_'))
+    check_rollout(e, g, 'cached_')
+    check_learn(m, e, g, ('ppo',), 8)

@@ -20,6 +20,7 @@ def oracle_config(m) -> Config:
         pmpo_pos_to_neg_weight=m.pmpo_pos_to_neg_weight, pmpo_reverse_kl=m.pmpo_reverse_kl,
         pmpo_kl_div_loss_weight=m.pmpo_kl_div_loss_weight,
         num_continuous_actions=getattr(m, 'num_continuous_actions', 0), head_mlp_recipe=getattr(m, 'head_mlp_recipe', 'pre_rms'),
+        reward_encoder_type=getattr(m, 'reward_encoder_type', 'hl_gauss'),
     )
 
 
@@ -92,13 +93,15 @@ def golden_model(weights='weights.npz'):
     from dreamer4_amd import DynamicsWorldModel
     kw = golden_config_kwargs(weights)
     renc, venc = dict(num_bins=kw.pop('reward_num_bins')), dict(num_bins=kw.pop('value_num_bins'))
+    kw.pop('cfg_note', None)
     if 'reward_range' in kw:
         renc['reward_range'] = tuple(kw.pop('reward_range'))
     if 'value_range' in kw:
         venc['reward_range'] = tuple(kw.pop('value_range'))
     kw['num_discrete_actions'] = tuple(kw['num_discrete_actions']) if isinstance(kw['num_discrete_actions'], (tuple, list)) else kw['num_discrete_actions']
-    if 'head_mlp_recipe' in kw:
-        kw['head_mlp_recipe'] = str(kw['head_mlp_recipe'])
+    for key in ('head_mlp_recipe', 'reward_encoder_type'):
+        if key in kw:
+            kw[key] = str(kw[key])
     kw = {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in kw.items()}
     m = DynamicsWorldModel(**kw, reward_encoder_kwargs=renc, value_encoder_kwargs=venc)
     _, W = golden_oracle(weights)
