@@ -89,6 +89,7 @@ SYMBOLS = {
     'd4_engine_cache_import': (_I, [_P, _P, _I, _I, _P]),
     'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'd4_decoder_forward': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'd4_encoder_forward': (_I, [_P, _P, _I, _I, _P, _P]),
     'd4_euler_step': (_I, [_P, _P, _L, _F, _F, _P]),
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),
     'd4_learn': (_I, [_P, C.POINTER(LearnIO), _P]),

@@ -456,6 +456,37 @@ int decoder_pack_tokens(float* tokens, float* compact, const float* pos, const f
     D4_LAUNCH_CHECK();
     return 0;
 }
+// encoder: tokens[f][s] = s < P ? img[f][s] : latent_tokens[s - P] (the learned latent tokens are the trunk's special tokens, D4:4361-4376);
+// the latent rows also go to the row-compacted copy
+__global__ void encoder_pack_kernel(float* tokens, float* compact, const float* img, const float* lt, int frames, int P, int n, int D) {
+    const int S = P + n;
+    const int64_t tot = (int64_t)frames * S * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int s = (int)((i / D) % S);
+        const int64_t f = i / ((int64_t)D * S);
+        float v;
+        if (s < P) v = img[(f * P + s) * D + d];
+        else { v = lt[(int64_t)(s - P) * D + d]; compact[(f * n + (s - P)) * D + d] = v; }
+        tokens[i] = v;
+    }
+}
+int encoder_pack_tokens(float* tokens, float* compact, const float* img, const float* latent_tokens, int frames, int P, int n, int D, hipStream_t s) {
+    const int64_t tot = (int64_t)frames * (P + n) * D;
+    if (tot == 0) return 0;
+    hipLaunchKernelGGL(encoder_pack_kernel, grid1d(tot), dim3(256), 0, s, tokens, compact, img, latent_tokens, frames, P, n, D);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void tanh_kernel(const float* x, float* y, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
+}
+int tanh_rows(const float* x, float* y, int64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(tanh_kernel, grid1d(n), dim3(256), 0, s, x, y, n);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
 // out[(h, w)][0..1] = (linspace(-1, 1, nh)[h], linspace(-1, 1, nw)[w]), remaining columns of the row zero   D4:3617-3620
 __global__ void coord_grid_kernel(float* out, int nh, int nw, int ld) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

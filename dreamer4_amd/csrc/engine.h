@@ -70,7 +70,9 @@ struct d4_engine {
     hipStream_t capture_stream = nullptr;             // use graphs when batch * tokens_per_frame <= this (launch-bound regime)
 
     // ---- decoder mode (video tokenizer's decoder, D4:3490-3682): tokens per frame = [P patches | n latent tokens]
-    bool decoder = false;
+    bool decoder = false, encoder = false;
+    const float *ptt_w = nullptr, *ptt_b = nullptr, *ptt_ln = nullptr, *latent_tokens = nullptr, *e2l_w = nullptr;    // encoder mode
+    float* enc_out = nullptr;
     int P = 0, dim_patch = 0, nph = 0, npw = 0;
     int keep_lo = 1, keep_hi = 1;          // token rows of a frame the final stage needs (dynamics: the spatial tokens; decoder: the patches)
     const float *ld_w = nullptr, *time_embed = nullptr, *npt_w = nullptr, *npt_b = nullptr, *npt_ln = nullptr, *t2p_w = nullptr, *t2p_b = nullptr, *final_norm = nullptr;

@@ -73,13 +73,21 @@ int engine_layout(d4_engine* e, bool assign) {
         e->bf16_cap = (size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096;
         e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * sizeof(uint16_t)));
     }
-    const size_t KR = e->decoder ? (size_t)e->P : (size_t)ns + 1;        // token rows per frame the final stage keeps (compact copies)
+    const size_t KR = e->decoder ? (size_t)e->P : (e->encoder ? (size_t)n : (size_t)ns + 1);        // token rows per frame the final stage keeps (compact copies)
+    const size_t KQ = e->encoder ? (size_t)n : 1;                        // special tokens per frame that cross-attend (D4:3227-3238)
     e->slabs = fl((size_t)e->nslab * M * D);
     e->xpool = fl(M * D);
     e->cslabs = fl((size_t)e->nslab * Fr * KR * D);
     e->xfc = fl(Fr * KR * D);
     e->xpool_c = fl(Fr * KR * D);
     e->att_c = fl(Fr * KR * hd);
+    if (e->encoder) {
+        const size_t P = e->P, dp = e->dim_patch;
+        e->t2p_wf = fl((size_t)dl * D);
+        e->dec_in = fl(Fr * P * dp);
+        e->img_tok = fl(Fr * P * D);
+        e->enc_out = fl(Fr * (size_t)n * dl);
+    }
     if (e->decoder) {
         const size_t P = e->P, dp = e->dim_patch;
         e->pos_emb = fl(P * D);
@@ -100,9 +108,9 @@ int engine_layout(d4_engine* e, bool assign) {
     e->pool_kv = fl((size_t)e->nslab * M * 2 * hp);
     e->pool_att = fl(M * hp);
     e->pool_u = fl(M * (size_t)e->php * D);
-    e->cq = fl(Fr * e->ldcq);
+    e->cq = fl(Fr * KQ * e->ldcq);
     e->ckv = fl(M * 2 * hd);
-    e->catt = fl(Fr * hd);
+    e->catt = fl(Fr * KQ * hd);
     e->lat_in = fl(Fr * n * dl);
     e->lkv = fl(Fr * n * 2 * hd);
     e->latt = fl(Fr * ns * hd);
@@ -245,7 +253,7 @@ int engine_resolve(d4_engine* e) {
     const int D = e->D, h = c.attn_heads;
     e->layer_attn.assign(c.depth, AttnW{});
     e->layer_ff.assign(c.depth, FfW{});
-    const std::string tp = e->decoder ? "decoder.transformer." : "transformer.";
+    const std::string tp = e->decoder ? "decoder.transformer." : (e->encoder ? "encoder_transformer." : "transformer.");
     for (int l = 0; l < c.depth; ++l) {
         r.attn(e->layer_attn[l], tp + keyf("layers.%d.2.fn.", l), D, D, h, false, true, c.attn_dim_head);
         r.ff(e->layer_ff[l], tp + keyf("layers.%d.3.fn.", l), D, e->inner);
@@ -272,8 +280,19 @@ int engine_resolve(d4_engine* e) {
         r.mlp(e->posmlp, "decoder.to_decoder_pos_emb.");
         return r.rc;
     }
-    r.attn(e->cross, "transformer.final_special_cross_attn.fn.", D, D, h, true, false, c.attn_dim_head);
-    r.ff(e->sff, "transformer.final_special_ff.fn.", D, e->inner);
+    r.attn(e->cross, tp + "final_special_cross_attn.fn.", D, D, h, true, false, c.attn_dim_head);
+    r.ff(e->sff, tp + "final_special_ff.fn.", D, e->inner);
+    if (e->encoder) {
+        // VideoTokenizer pieces around the encoder trunk (D4:3838-3848, 3796, 3936)
+        const int dp = e->dim_patch;
+        e->ptt_w = r.get("patch_to_tokens.1.weight", (int64_t)D * dp);
+        e->ptt_b = r.get("patch_to_tokens.1.bias", D);
+        e->ptt_ln = r.get("patch_to_tokens.2.weight", D);
+        e->latent_tokens = r.get("latent_tokens", (int64_t)c.num_latent_tokens * D);
+        e->e2l_w = r.get("encoded_to_latents.weight", (int64_t)c.dim_latent * D);
+        e->final_norm = r.get((tp + "final_norm.weight").c_str(), D);
+        return r.rc;
+    }
     e->latent_norm = r.get("to_latent_pred.0.weight", D);
     e->latent_w = r.get("to_latent_pred.2.weight", (int64_t)c.dim_latent * D);
     if (c.num_spatial_tokens == c.num_latent_tokens) {
@@ -433,6 +452,13 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
     if ((rc = fold_attn_rows(e->cq_w + (size_t)hd * D, D, e->cross.to_gates, e->cross.norm, h, s))) return rc;
     if ((rc = fold_attn_rows(e->ckv_w, D, e->cross.to_k, e->cross.norm_ctx, hd, s))) return rc;
     if ((rc = fold_attn_rows(e->ckv_w + (size_t)hd * D, D, e->cross.to_v, e->cross.norm_ctx, hd, s))) return rc;
+    if (e->encoder) {
+        // final RMSNorm of the trunk folded into the latent bottleneck: W . diag(gamma), 1 / rms inside the GEMM   D4:3246, 4408
+        if ((rc = fold_rows(e->e2l_w, e->final_norm, e->t2p_wf, c.dim_latent, D, D, s))) return rc;
+        D4_HIP(hipStreamSynchronize(s));
+        e->prepared = true;
+        return 0;
+    }
 
     // learned-query pools: the query side is batch independent -> evaluate once        D4:2189, 2206
     const int dl = c.dim_latent, ns = c.num_spatial_tokens, n = c.num_latent_tokens;
@@ -574,18 +600,25 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
     // Denoise evaluations (no agent embedding wanted) drop the agent token altogether: it is the one special token, no
     // ordinary query may attend to it (D4:1781), time attention is per token column, and its own outputs are only read
     // by the heads of the clean step -> nothing consumed downstream depends on it.  S = tokens present per frame.
-    const int has_agent = need_agent ? 1 : 0;
-    const int D = e->D, hd = e->hd, h = c.attn_heads, S = need_agent ? e->S : e->S - 1;
+    const int has_agent = (need_agent && !e->encoder) ? 1 : 0;
+    const int D = e->D, hd = e->hd, h = c.attn_heads, S = (need_agent || e->encoder) ? e->S : e->S - 1;
     const int n = c.num_latent_tokens, dl = c.dim_latent, ns = c.num_spatial_tokens;
     const int Fr = B * Tq, M = Fr * S;
+    const bool denoise_only = !need_agent && !e->encoder && !e->decoder;        // dynamics evaluation whose last layer only feeds the spatial rows
     int rc;
 
     float* slab0 = e->slabs;
     auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
-    const int nkeep = e->decoder ? e->P : ns + has_agent, Mc = Fr * nkeep;          // rows the final stage reads
+    const int nkeep = e->decoder ? e->P : (e->encoder ? n : ns + has_agent), Mc = Fr * nkeep;          // rows the final stage reads
     auto cslab = [&](int j) { return e->cslabs + (size_t)j * Mc * D; };
     const bool same_len = ns == n;
-    if (e->decoder) {
+    if (e->encoder) {
+        // tokens = [patch tokens of the video | learned latent tokens] (D4:4307, 4361-4376); patch rows were laid out in e->dec_in
+        const int P = e->P, dp = e->dim_patch;
+        if ((rc = gemm_simple(e->dec_in, dp, e->ptt_w, dp, e->img_tok, D, Fr * P, D, dp, 0, e->ptt_b, nullptr, 0, s))) return rc;
+        if ((rc = layernorm_rows(e->img_tok, D, e->ptt_ln, nullptr, e->img_tok, D, Fr * P, D, 1e-5f, 0, s))) return rc;
+        if ((rc = encoder_pack_tokens(slab0, e->cslabs, e->img_tok, e->latent_tokens, Fr, P, n, D, s))) return rc;
+    } else if (e->decoder) {
         // tokens = [pos_emb + patch tokens of the noised video | latent tokens] (D4:3625-3654); `latents` here are the latent TOKENS
         // input row-major [Fr][n][dl]; the noised video's patch rows were laid out in e->dec_in by d4_decoder_forward
         const int P = e->P, dp = e->dim_patch;
@@ -662,8 +695,8 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
             sa.k_gamma = a.k_gamma;
             sa.out = e->att; sa.o_group_stride = (int64_t)S * hd; sa.o_item_stride = hd;
             sa.groups = Fr; sa.heads = h; sa.nq = S; sa.nk = S;
-            sa.softclamp = c.attn_softclamp_value; sa.mask_special = has_agent; sa.belief = 1;
-            if (!need_agent && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8) {
+            sa.softclamp = c.attn_softclamp_value; sa.mask_special = e->encoder ? n : has_agent; sa.belief = 1;
+            if (denoise_only && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8) {
                 sa.q_lo = 1; sa.q_hi = 1 + ns; sa.q_last = 0;
                 sa.out = e->att_c; sa.o_group_stride = (int64_t)nkeep * hd;
             }
@@ -671,7 +704,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         }
         // Denoise steps (no agent embedding wanted): nothing downstream reads the last layer's flow / register /
         // action rows, so its output projection and feedforward run on the compacted rows only.
-        const bool compact_tail = !need_agent && l == c.depth - 1 && !e->is_time[l] && c.depth >= 2 && S <= 16 && S >= 8;
+        const bool compact_tail = denoise_only && l == c.depth - 1 && !e->is_time[l] && c.depth >= 2 && S <= 16 && S >= 8;
         if (compact_tail) {
             if ((rc = gemm_simple(e->att_c, hd, a.to_out, hd, cslab(2 * l + 1), D, Mc, D, hd, 0, nullptr, e->xpool_c, D, s))) return rc;
             if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, cslab(2 * l + 1), D, cslab(2 * l + 2), D, Mc, s))) return rc;
@@ -682,7 +715,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, e->keep_hi - e->keep_lo, has_agent, s))) return rc;
         if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2), S, has_agent))) return rc;
         if (l != c.depth - 1) {
-            float* xc = (!need_agent && l == c.depth - 2 && !e->is_time[c.depth - 1] && S <= 16 && S >= 8) ? e->xpool_c : nullptr;
+            float* xc = (denoise_only && l == c.depth - 2 && !e->is_time[c.depth - 1] && S <= 16 && S >= 8) ? e->xpool_c : nullptr;
             if ((rc = pool_block(e, l, h2, e->xpool, 2 * l + 3, M, s, nullptr, xc, S, has_agent))) return rc;
             x_in = e->xpool;
         }
@@ -695,6 +728,30 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
     float* xfc = e->xfc;
     const float* last = slab(2 * c.depth);
     if ((rc = copy_rows(cslab(2 * c.depth), D, xfc, D, Mc, D, s))) return rc;
+    if (e->encoder) {
+        // the n latent (special) tokens of each frame cross-attend its P patch tokens, then their own feedforward (D4:3227-3238);
+        // xfc = compact latent rows [Fr][n][D]
+        const int P = e->P;
+        const float* spec = cslab(2 * c.depth);
+        if ((rc = gemm_simple(spec, D, e->cq_w, D, e->cq, e->ldcq, Mc, hd + h, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        if ((rc = gemm_simple(last, D, e->ckv_w, D, e->ckv, 2 * hd, M, 2 * hd, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        SmallAttnArgs sa{};
+        sa.dh = c.attn_dim_head;
+        sa.q = e->cq; sa.q_group_stride = (int64_t)n * e->ldcq; sa.q_item_stride = e->ldcq;
+        sa.k = e->ckv; sa.k_group_stride = (int64_t)S * 2 * hd; sa.k_item_stride = 2 * hd;
+        sa.v = e->ckv + hd; sa.v_group_stride = (int64_t)S * 2 * hd; sa.v_item_stride = 2 * hd;
+        sa.gate = e->cq + hd; sa.g_group_stride = (int64_t)n * e->ldcq; sa.g_item_stride = e->ldcq;
+        sa.k_gamma = e->cross.k_gamma;
+        sa.out = e->catt; sa.o_group_stride = (int64_t)n * hd; sa.o_item_stride = hd;
+        sa.groups = Fr; sa.heads = h; sa.nq = n; sa.nk = P;
+        if ((rc = small_attn(sa, s))) return rc;
+        if ((rc = gemm_simple(e->catt, hd, e->cross.to_out, hd, xfc, D, Mc, D, hd, 0, nullptr, spec, D, s))) return rc;
+        if ((rc = ff_block(e, e->ffp[c.depth], e->sff.out_b, xfc, D, xfc, D, Mc, s))) return rc;
+        if ((rc = pool_block(e, c.depth - 1, xfc, xfc, e->nslab, Mc, s, e->cslabs))) return rc;
+        // final RMSNorm (folded) -> encoded_to_latents -> tanh                                   D4:3246, 4408, 4417
+        if ((rc = gemm_simple(xfc, D, e->t2p_wf, D, e->enc_out, c.dim_latent, Mc, c.dim_latent, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        return tanh_rows(e->enc_out, e->enc_out, (int64_t)Mc * c.dim_latent, s);
+    }
     if (e->decoder) {
         // final attention pool on the patch rows, then final RMSNorm (folded) -> Linear(dim, channels * patch^2)   D4:3242-3246, 3555
         if ((rc = pool_block(e, c.depth - 1, xfc, xfc, e->nslab, Mc, s, e->cslabs))) return rc;
@@ -828,7 +885,8 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     D4_REQUIRE(c.dim % 4 == 0 && c.dim_latent % 4 == 0, "dim and dim_latent must be multiples of 4");
     D4_REQUIRE(c.depth >= 1 && c.time_block_every >= 1, "bad depth/time_block_every");
     D4_REQUIRE(c.num_discrete_action_types >= 0 && c.num_discrete_action_types <= D4_MAX_ACTION_TYPES, "too many action types");
-    const bool decoder = c.mode == D4_MODE_DECODER;
+    const bool encoder = c.mode == D4_MODE_ENCODER;
+    const bool decoder = c.mode == D4_MODE_DECODER || encoder;          // (shared geometry checks below; e->decoder is set for the decoder only)
     D4_REQUIRE(c.mode == D4_MODE_DYNAMICS || decoder, "unknown engine mode %d", c.mode);
     D4_REQUIRE(c.num_latent_tokens <= 64 && (decoder || c.num_spatial_tokens <= 64), "at most 64 latent / spatial tokens");
     if (decoder) {
@@ -836,7 +894,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
         D4_REQUIRE(c.patch_size >= 1 && c.channels >= 1 && c.image_height % c.patch_size == 0 && c.image_width % c.patch_size == 0 && c.image_height > 0 && c.image_width > 0,
                    "decoder mode: image %d x %d must be a positive multiple of the patch size %d", c.image_height, c.image_width, c.patch_size);
         D4_REQUIRE((c.channels * c.patch_size * c.patch_size) % 4 == 0, "decoder mode: channels * patch_size^2 must be a multiple of 4");
-        D4_REQUIRE(c.decoder_flow_steps >= 1, "decoder mode: decoder_flow_steps >= 1 (the flow decoder is the reference's default, D4:3875)");
+        D4_REQUIRE(encoder || c.decoder_flow_steps >= 1, "decoder mode: decoder_flow_steps >= 1 (the flow decoder is the reference's default, D4:3875)");
         D4_REQUIRE(c.num_discrete_action_types == 0 && c.num_continuous_actions == 0 && c.matmul_bf16 == 0, "decoder mode: no actions / bf16");
         D4_REQUIRE(c.decoder_pos_mlp_depth >= 0 && c.decoder_pos_mlp_depth <= 6, "decoder_pos_mlp_depth out of range");
     }
@@ -847,13 +905,15 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->D = c.dim;
     e->S = 1 + c.num_spatial_tokens + c.num_register_tokens + ((c.num_discrete_action_types > 0 || c.num_continuous_actions > 0) ? 1 : 0) + 1;   // no action token without an action space
     e->keep_lo = 1; e->keep_hi = 1 + c.num_spatial_tokens;
-    e->decoder = decoder;
+    e->decoder = decoder && !encoder;
+    e->encoder = encoder;
     if (decoder) {
         e->nph = c.image_height / c.patch_size; e->npw = c.image_width / c.patch_size;
         e->P = e->nph * e->npw;
         e->dim_patch = c.channels * c.patch_size * c.patch_size;
         e->S = e->P + c.num_latent_tokens;                     // [patches | latent tokens]; the last latent token is the trunk's one special token
         e->keep_lo = 0; e->keep_hi = e->P;
+        if (encoder) { e->keep_lo = e->P; e->keep_hi = e->P + c.num_latent_tokens; }       // the latent (special) tokens are the encoder's output rows
         D4_REQUIRE(e->S - 1 <= 160, "decoder mode: %d tokens per frame exceed the wide attention kernel's 160", e->S - 1);
     }
     D4_REQUIRE((decoder || e->S <= 64) && 2 * c.depth + 1 <= 64, "tokens per frame / pooled hiddens exceed 64");
@@ -890,7 +950,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth, c.head_mlp_recipe);
-    d4::mlp_dims(e->posmlp, 2, 2 * c.dim, c.dim, decoder ? c.decoder_pos_mlp_depth : 0, c.head_mlp_recipe);      // D4:3526-3532
+    d4::mlp_dims(e->posmlp, 2, 2 * c.dim, c.dim, (decoder && !encoder) ? c.decoder_pos_mlp_depth : 0, c.head_mlp_recipe);      // D4:3526-3532
     if (const char* gm = getenv("D4_GRAPH_MAX_ROWS")) e->graph_max_rows = atoi(gm);     // 0 disables graph replay
     d4::engine_layout(e, false);
     *out = e;
@@ -978,7 +1038,7 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
                   const int64_t* prev_actions, const float* prev_cont, const int64_t* tasks, int batch, int frames,
                   int use_cache, int commit_cache, float* pred, float* agent_embed, void* stream) {
     D4_REQUIRE(e && latents && signal_levels, "null argument");
-    D4_REQUIRE(!e->decoder, "d4_wm_forward needs a dynamics engine");
+    D4_REQUIRE(!e->decoder && !e->encoder, "d4_wm_forward needs a dynamics engine");
     hipStream_t s = static_cast<hipStream_t>(stream);
     int sl, rc;
     if ((rc = step_log2_of(step_size, &sl))) return rc;
@@ -1019,6 +1079,19 @@ int d4_decoder_forward(d4_engine* e, const float* latents, const float* noised_v
     return d4::patches_to_video(e->dec_out, pred_video, batch, c.channels, frames, e->nph, e->npw, c.patch_size, s);
 }
 
+int d4_encoder_forward(d4_engine* e, const float* video, int batch, int frames, float* latents, void* stream) {
+    D4_REQUIRE(e && video && latents, "null argument");
+    D4_REQUIRE(e->encoder, "d4_encoder_forward needs an engine created with mode = D4_MODE_ENCODER");
+    D4_REQUIRE(batch >= 1 && batch <= e->maxB && frames >= 1 && frames <= e->maxTq, "batch / frames exceed the encoder engine's capacity (%d x %d)", e->maxB, e->maxTq);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const d4_config& c = e->c;
+    int rc;
+    if ((rc = d4::video_to_patches(video, e->dec_in, batch, c.channels, frames, e->nph, e->npw, c.patch_size, s))) return rc;
+    if ((rc = d4::engine_forward(e, nullptr, batch, frames, 0, 0, nullptr, false, s))) return rc;
+    const int nl = c.num_latent_tokens * c.dim_latent;
+    return d4::copy_rows(e->enc_out, nl, latents, nl, batch * frames, nl, s);
+}
+
 int d4_euler_step(float* x, const float* pred, int64_t n, float one_minus_t, float dt, void* stream) {
     D4_REQUIRE(x && pred && n >= 0 && n < (int64_t)1 << 31, "euler_step: bad arguments");
     return d4::euler_step(x, (int)n, pred, (int)n, 1, (int)n, one_minus_t, dt, static_cast<hipStream_t>(stream));
@@ -1026,7 +1099,7 @@ int d4_euler_step(float* x, const float* pred, int64_t n, float one_minus_t, flo
 
 int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
     D4_REQUIRE(e && io, "null argument");
-    D4_REQUIRE(!e->decoder, "d4_rollout needs a dynamics engine");
+    D4_REQUIRE(!e->decoder && !e->encoder, "d4_rollout needs a dynamics engine");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const d4_config& c = e->c;
     const int B = io->batch, T = io->time_steps, P = io->prompt_frames, K = io->num_steps;

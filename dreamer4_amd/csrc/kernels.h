@@ -197,6 +197,8 @@ int video_to_patches(const float* video, float* patches, int B, int C, int T, in
 int patches_to_video(const float* patches, float* video, int B, int C, int T, int nh, int nw, int ps, hipStream_t s);
 int decoder_pack_tokens(float* tokens, float* compact, const float* pos, const float* img, const float* lat, int frames, int P, int n_lat, int n_total, int D, hipStream_t s);
 int coord_grid(float* out, int nh, int nw, int ld, hipStream_t s);
+int encoder_pack_tokens(float* tokens, float* compact, const float* img, const float* latent_tokens, int frames, int P, int n, int D, hipStream_t s);
+int tanh_rows(const float* x, float* y, int64_t n, hipStream_t s);
 int cunembed_gather(const float* U, float* w, int nc, int mtp, int d, hipStream_t s);
 int cunembed_scatter_grad(const float* g, float* dU, int nc, int mtp, int d, hipStream_t s);
 

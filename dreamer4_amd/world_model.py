@@ -678,8 +678,17 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         Extra keyword-only arguments: `noise` injects the four per-frame random draws
         (`latent`, `context` (F,B,n,dl) normal; `gumbel_u` (F,B,A), `bern_u` (F,B) uniform) for
         parity runs; otherwise they are drawn on the device from `generator`."""
+        assert not (prompt is not None and prompt_latents is not None), 'cannot pass in both prompt video and prompt latents'
         if prompt is not None:
-            raise NotImplementedError('video prompts need the VideoTokenizer encoder, which is out of scope (SURVEY.md 8f-2)')
+            # a video (or image) prompt goes through the tokenizer's encoder                               dreamer4.py:6376-6387
+            assert self.video_tokenizer is not None, 'a video prompt needs a video_tokenizer'
+            tokenizer = self.video_tokenizer
+            if prompt.ndim == 4:
+                prompt = prompt.unsqueeze(2)
+            if prompt.shape[1] != tokenizer.channels:
+                assert prompt.shape[1] == 1
+                prompt = prompt.expand(-1, tokenizer.channels, -1, -1, -1)
+            prompt_latents = tokenizer.tokenize(prompt)
         return_decoded_video = (self.video_tokenizer is not None) if return_decoded_video is None else return_decoded_video      # dreamer4.py:6695
         if return_decoded_video and self.video_tokenizer is None:
             raise AssertionError('return_decoded_video=True needs a video_tokenizer')

@@ -34,6 +34,7 @@ extern "C" {
 #define D4_MAX_ACTION_TYPES 8
 #define D4_MODE_DYNAMICS 0
 #define D4_MODE_DECODER 1
+#define D4_MODE_ENCODER 2
 #define D4_MLP_PRE_RMS 0        /* RMSNorm -> Linear -> SiLU                        (x_mlps_pytorch create_mlp: recipe unpinned) */
 #define D4_MLP_POST_LAYER 1     /* Linear -> LayerNorm -> SiLU, bare last Linear */
 
@@ -60,8 +61,8 @@ typedef struct d4_config {
     float delight_temperature, pmpo_pos_to_neg_weight, pmpo_kl_div_loss_weight;
     int32_t pmpo_reverse_kl;
     float hl_gauss_sigma_to_bin_ratio, hl_gauss_eps, value_min, value_max;
-    /* mode D4_MODE_DECODER: the engine is the video tokenizer's decoder (VideoDecoderNetwork, D4:3490-3682) instead of the dynamics
-     * model — the same trunk kernels over [patches | latent tokens] per frame; constructor arguments of VideoTokenizer (D4:3686-3764). */
+    /* mode D4_MODE_DECODER / D4_MODE_ENCODER: the engine is the video tokenizer's decoder (VideoDecoderNetwork, D4:3490-3682) or its
+     * encoder (encoder_transformer, D4:3912-3933) instead of the dynamics model — the same trunk kernels over [patches | latent tokens] per frame; constructor arguments of VideoTokenizer (D4:3686-3764). */
     int32_t mode;
     int32_t patch_size, channels, image_height, image_width, decoder_flow_steps, decoder_pos_mlp_depth;
     /* capacities the workspace is sized for */
@@ -130,6 +131,9 @@ int d4_wm_forward(d4_engine* e, const float* latents, const int32_t* signal_leve
  * steps (D4:4226-4230) is d4_euler_step. */
 int d4_decoder_forward(d4_engine* e, const float* latents, const float* noised_video, int time_index, int batch, int frames,
                        float* pred_video, void* stream);
+/* VideoTokenizer.tokenize (D4:4107-4113 -> forward(return_latents=True) in eval mode, D4:4239-4433) on an engine created with
+ * mode = D4_MODE_ENCODER (depth = encoder_depth): video [batch][channels][frames][H][W] -> latents [batch][frames][n][dl] in (-1, 1). */
+int d4_encoder_forward(d4_engine* e, const float* video, int batch, int frames, float* latents, void* stream);
 /* x += (pred - x) / one_minus_t * dt, elementwise over n floats: the flow-matching Euler step of generate (D4:6567-6580) and of
  * VideoTokenizer.decode (D4:4226-4230). */
 int d4_euler_step(float* x, const float* pred, int64_t n, float one_minus_t, float dt, void* stream);

@@ -27,6 +27,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   continuous.npz   continuous (Beta) actions: a mixed discrete + continuous model (weights_continuous.npz: rollout, ppo / spo / pmpo
                    losses and gradients) and a continuous-only one (weights_contonly.npz: tempered rollout, env-wrapper chained calls)
   symexp.npz       reward_encoder_type='symexp_two_hot' (weights_symexp.npz): rollout, ppo losses and gradients
+  encode.npz       VideoTokenizer.tokenize of reference tokenizers (weights_encode*.npz = the encoder half) + generate(prompt=video)
   decode.npz       VideoTokenizer.decode of a reference tokenizer (weights_decode.npz = the decoder half of its state_dict): two flow steps
 """
 from __future__ import annotations
@@ -325,6 +326,72 @@ def gen_decode():
     print('decode video', tuple(video.shape), 'abs max', float(video.abs().max()))
 
 
+CFG_ENCODE = dict(dim=32, dim_latent=8, patch_size=4, image_height=16, image_width=24, num_latent_tokens=6, encoder_depth=3, decoder_depth=1,
+                  time_block_every=2, attn_heads=2, attn_dim_head=64, channels=3)
+CFG_ENCODE_WIDE = dict(dim=32, dim_latent=4, patch_size=4, image_height=32, image_width=40, num_latent_tokens=5, encoder_depth=2, decoder_depth=1,
+                       time_block_every=2, attn_heads=1, attn_dim_head=64, channels=1)
+CFG_ENCODE_DYN = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                      num_discrete_actions=(4,), num_tasks=0, reward_num_bins=11, value_num_bins=11, reward_range=(-3., 3.), value_range=(-4., 4.),
+                      multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1)
+
+
+def _reference_tokenizer(D4, cfgd, seed):
+    torch.manual_seed(seed)
+    tok = D4.VideoTokenizer(**cfgd, lpips_loss_weight=0.).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in tok.named_parameters():
+            if p.ndim == 1 and ('norm' in k or k.endswith('.0.weight')):
+                p.copy_(1. + torch.randn(p.shape, generator=g) * 0.1)
+            if k.endswith('gamma'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        tok.latent_tokens.mul_(30.)                     # init std 1e-2: make the learned tokens matter
+    return tok, g
+
+
+ENCODER_KEYS = ('latent_tokens', 'patch_to_tokens.', 'encoder_transformer.', 'encoded_to_latents.')
+
+
+def gen_encode():
+    """encode.npz / weights_encode*.npz: VideoTokenizer.tokenize (D4:4107-4113 -> eval forward(return_latents=True), D4:4239-4433) of the
+    reference tokenizer — the encoder half of its state_dict, a video and its latents; one tokenizer with a time layer (30 tokens per
+    frame), one with 80 patches per frame (the latent tokens' cross attention over > 64 keys); and DynamicsWorldModel.generate with a
+    video prompt (D4:6376-6387) on the first."""
+    D4 = load_reference()
+    out = {}
+    tok, g = _reference_tokenizer(D4, CFG_ENCODE, 61)
+    save_weights('weights_encode.npz', {k: v.detach().clone().float() for k, v in tok.state_dict().items() if k.startswith(ENCODER_KEYS)}, CFG_ENCODE)
+    video = torch.rand(2, 3, 4, 16, 24, generator=g)
+    with torch.no_grad():
+        out['video'], out['latents'] = npy(video), npy(tok.tokenize(video))
+        image = torch.rand(3, 3, 16, 24, generator=g)
+        out['image'], out['image_latents'] = npy(image), npy(tok.tokenize(image))
+    tokw, g = _reference_tokenizer(D4, CFG_ENCODE_WIDE, 63)
+    save_weights('weights_encode_wide.npz', {k: v.detach().clone().float() for k, v in tokw.state_dict().items() if k.startswith(ENCODER_KEYS)}, CFG_ENCODE_WIDE)
+    videow = torch.rand(2, 1, 3, 32, 40, generator=g)
+    with torch.no_grad():
+        out['wide_video'], out['wide_latents'] = npy(videow), npy(tokw.tokenize(videow))
+    # a dynamics model prompted with a video: the prompt frames are tokenized, then teacher-forced (D4:6376-6395)
+    cfg = Config(**CFG_ENCODE_DYN)
+    m = build_reference_model(cfg, seed=65)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)
+    save_weights('weights_encode_dyn.npz', weights_of(m), CFG_ENCODE_DYN)
+    m.video_tokenizer = tok
+    nz = make_noise(cfg, 5, 2, 967)
+    pa = torch.randint(0, 4, (2, 2, 1), generator=g)
+    pr = torch.randn(2, 2, generator=g)
+    with injected(nz):
+        e = m.generate(5, batch_size=2, prompt=video[:, :, :2], prompt_discrete_actions=pa, prompt_rewards=pr,
+                       return_for_policy_optimization=True, return_decoded_video=False)
+    exp_dict('prompt_', e, out); noise_dict('prompt_', nz, out)
+    out['prompt_actions_in'], out['prompt_rewards_in'] = npy(pa), npy(pr)
+    out['prompt_margin'] = np.array(min_margin(e, nz, cfg))
+    np.savez(os.path.join(OUT, 'encode.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('encode latents', out['latents'].shape, 'abs max', float(np.abs(out['latents']).max()), 'std', float(out['latents'].std()),
+          'wide', out['wide_latents'].shape, float(out['wide_latents'].std()), 'prompt margin', out['prompt_margin'], 'lens', out['prompt_lens'])
+
+
 CFG_SYMEXP = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
                   num_discrete_actions=(4,), num_tasks=0, reward_num_bins=41, value_num_bins=31, reward_range=(-3., 3.), value_range=(-4., 4.),
                   multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1, reward_encoder_type='symexp_two_hot')
@@ -351,7 +418,7 @@ def gen_symexp():
     print('symexp margin', out['cached_margin'], 'lens', out['cached_lens'], 'values', out['cached_values'][0])
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp)
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode)
 
 
 def main():

@@ -264,7 +264,7 @@ class TrunkCache:
     token_count: int = 0
 
 
-def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='transformer.', trace: dict | None = None):
+def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='transformer.', trace: dict | None = None, num_special=1):
     """AxialSpaceTimeTransformer.forward D4:2927-3267 (defaults: value residual, attn pools,
     final special cross-attn; the final RMSNorm is applied when the weights hold one — the dynamics model builds its trunk
     with final_norm=False, the tokenizer's decoder with the default True).  tokens (b, t, s, d).  When a non-empty cache is
@@ -277,7 +277,7 @@ def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='tr
         tokens = tokens[:, -1:]
         t = 1
 
-    space_mask = special_token_mask(s, 1)
+    space_mask = special_token_mask(s, num_special)
     rot = rotary_freqs(cfg, t, token_count, W.get(pre + 'time_rotary.inv_freq'))
 
     vres = rmsnorm(tokens, W[pre + 'to_value_residual.0.weight']) @ W[pre + 'to_value_residual.1.weight'].t()
@@ -315,12 +315,12 @@ def transformer(cfg: Config, W, tokens, cache: TrunkCache | None = None, pre='tr
                 trace[f'pool_out_{i}'] = tokens
 
     # agent token cross-attends the non-special tokens of its frame   D4:3227-3238
-    non_special, special = tokens[:, :, :-1], tokens[:, :, -1:]
+    non_special, special = tokens[:, :, :-num_special], tokens[:, :, -num_special:]
     cp = pre + 'final_special_cross_attn.fn.'
-    q = special.reshape(b * t, 1, d)
-    ctx = non_special.reshape(b * t, s - 1, d)
+    q = special.reshape(b * t, num_special, d)
+    ctx = non_special.reshape(b * t, s - num_special, d)
     out, _ = attention(W, cp, q, heads=h, dim_head=dh, context=ctx, belief=True, has_ctx_norm=True)
-    special = special + out.reshape(b, t, 1, d)
+    special = special + out.reshape(b, t, num_special, d)
     special = special + feedforward(W, pre + 'final_special_ff.fn.', special)
     tokens = torch.cat((non_special, special), dim=2)
 
@@ -776,6 +776,13 @@ class TokenizerConfig:
     decoder_pos_mlp_depth: int = 2
     decoder_flow_steps: int = 1
     head_mlp_recipe: str = 'pre_rms'
+    encoder_depth: int = 4
+
+    def encoder_trunk(self) -> Config:
+        """The encoder's AxialSpaceTimeTransformer (D4:3912-3933): the num_latent_tokens latent tokens are the special tokens."""
+        return Config(dim=self.dim, dim_latent=self.dim_latent, num_latent_tokens=self.num_latent_tokens, depth=self.encoder_depth,
+                      time_block_every=self.time_block_every, attn_heads=self.attn_heads, attn_dim_head=self.attn_dim_head,
+                      attn_softclamp_value=self.attn_softclamp_value)
 
     def trunk(self) -> Config:
         """The decoder's AxialSpaceTimeTransformer (D4:3582-3594: constructor defaults, i.e. ONE special token — the last latent
@@ -805,6 +812,22 @@ def tokenizer_decode_step(tc: TokenizerConfig, W, latents, noised_video, time_in
     patches = tokens[:, :, :nh * nw] @ W['decoder.tokens_to_patch.0.weight'].t() + W['decoder.tokens_to_patch.0.bias']
     # 'b t h w (p1 p2 c) -> b c t (h p1) (w p2)'                                                                   D4:3556
     return patches.reshape(b, t, nh, nw, p, p, c).permute(0, 6, 1, 2, 4, 3, 5).reshape(b, c, t, nh * p, nw * p)
+
+
+def tokenizer_tokenize(tc: TokenizerConfig, W, video):
+    """VideoTokenizer.tokenize = forward(video, return_latents=True) in eval mode (no patch masking)  D4:4107-4113, 4239-4433.
+    video (b, c, t, H, W) -> latents (b, t, n, dl) in (-1, 1)."""
+    b, c, t, H, Wd = video.shape
+    p = tc.patch_size
+    nh, nw = H // p, Wd // p
+    x = video.reshape(b, c, t, nh, p, nw, p).permute(0, 2, 3, 5, 4, 6, 1).reshape(b, t, nh * nw, p * p * c)     # D4:3838-3844
+    x = x @ W['patch_to_tokens.1.weight'].t() + W['patch_to_tokens.1.bias']
+    x = layernorm(x, W['patch_to_tokens.2.weight'], 0.)
+    lat = W['latent_tokens'].expand(b, t, -1, -1)
+    tokens = torch.cat((x, lat), dim=2)                                                                          # [patches | latents]  D4:4376
+    tokens, _ = transformer(tc.encoder_trunk(), W, tokens, None, pre='encoder_transformer.', num_special=tc.num_latent_tokens)
+    z = tokens[:, :, nh * nw:] @ W['encoded_to_latents.weight'].t()
+    return z.tanh()
 
 
 def tokenizer_decode(tc: TokenizerConfig, W, latents, noise):

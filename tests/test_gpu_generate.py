@@ -270,7 +270,7 @@ def test_invalid_arguments_raise(GM):
     m, _ = GM
     with pytest.raises(AssertionError):
         m.generate(2, num_steps=3)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match='video_tokenizer'):         # a video prompt without a tokenizer
         m.generate(2, prompt=torch.zeros(1, 3, 8, 8))
     from dreamer4_amd._lib import D4Error
     with pytest.raises(D4Error, match='step_size_embed'):        # the reference hits an IndexError in nn.Embedding here
@@ -533,3 +533,26 @@ def test_config4_env_wrapper_pattern_at_full_size_vs_oracle():
         close(e.latents[:, -1], ref['latents'][:, -1], atol=5e-4); close(e.rewards[:, -1], ref['rewards'][:, -1], atol=2e-3)
         assert not bool(e.terminals.any())
     print(f'\ncfg4 full size, 50 chained env steps: worst latent deviation from the oracle {worst:.2e}')
+
+
+def test_config1_plumbing_shape_vs_oracle():
+    """BASELINE config 1 exactly: dim 128, depth 2 (time_block_every = 1 so that the two layers cache), the default
+    8 heads x 64 (inner width 512 > dim), 4 latent tokens x 32, 4 discrete actions, horizon 8 (9 frames), batch 4; then the learner."""
+    from dreamer4_amd import DynamicsWorldModel
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=128, dim_latent=32, num_latent_tokens=4, depth=2, num_discrete_actions=4, time_block_every=1))
+    cfg, W = oracle_config(m), oracle_weights(m)
+    assert cfg.attn_heads == 8 and cfg.attn_dim_head == 64 and all(cfg.is_time)
+    B, T = 4, 9
+    nz = make_noise(cfg, T, B, 21)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz)
+    m = m.cuda()
+    e = m.generate(T, batch_size=B, return_for_policy_optimization=True, noise=nz)
+    assert e.latents.shape[1] == ref['latents'].shape[1]
+    close(e.latents, ref['latents']); close(e.values, ref['values']); close(e.rewards, ref['rewards']); close(e.log_probs.discrete, ref['log_probs'])
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions']) and torch.equal(e.lens.cpu(), ref['lens'])
+    heads = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
+    Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
+    pl_o, vl_o = restate.learn_losses(cfg, Wg, ref, 'ppo')
+    pl, vl = m.learn_from_experience(e, objective='ppo')
+    close(pl, pl_o, atol=2e-5); close(vl, vl_o, atol=2e-5)

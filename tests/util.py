@@ -88,7 +88,7 @@ def golden_oracle(weights='weights.npz'):
     return cfg, W
 
 
-def golden_model(weights='weights.npz'):
+def golden_model(weights='weights.npz', **extra):
     """Product model carrying the fixture weights (loaded by reference state_dict key)."""
     from dreamer4_amd import DynamicsWorldModel
     kw = golden_config_kwargs(weights)
@@ -103,7 +103,7 @@ def golden_model(weights='weights.npz'):
         if key in kw:
             kw[key] = str(kw[key])
     kw = {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in kw.items()}
-    m = DynamicsWorldModel(**kw, reward_encoder_kwargs=renc, value_encoder_kwargs=venc)
+    m = DynamicsWorldModel(**kw, reward_encoder_kwargs=renc, value_encoder_kwargs=venc, **extra)
     _, W = golden_oracle(weights)
     own = dict(m.named_parameters())
     missing = [k for k, p in own.items() if p.numel() > 0 and k not in W and k != 'reward_learned_embed']
