@@ -8,7 +8,7 @@ rm -f $D4_GEMM_TUNE_CACHE
 # 1. plain bench (the driver's command), then the driver-style torchrun launch with the 1-rank RCCL group forced
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 D4_FORCE_PG=1 NCCL_DEBUG=INFO python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_bench_rccl1.json 2> gpurun_out/${TAG}_bench_rccl1.err
-grep -i "NCCL INFO\|RCCL" gpurun_out/${TAG}_bench_rccl1.err | grep -i "init\|comm\|version\|Using\|Channel" | head -30 > gpurun_out/${TAG}_rccl_init.log
+cat gpurun_out/${TAG}_bench_rccl1.err gpurun_out/${TAG}_bench_rccl1.json | grep -i "NCCL INFO" | grep -i "init\|comm\|version\|Using\|Channel" | head -30 > gpurun_out/${TAG}_rccl_init.log
 # 2. kernel trace + stats of the same command
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_profiled.json 2> /dev/null
