@@ -503,11 +503,162 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     }
 }
 
+// Few token rows (BASELINE config 4's decode regime: one trajectory = 11 rows): one BLOCK per token row, its four waves split the L
+// hiddens (l = w, w + 4, ...) so every wave has all of its loads in flight at once — with one wave per row the kernel is L
+// dependent memory round trips long (12 us at L = 13).  The partial mixes are folded through LDS in wave order (fixed).  Chosen by
+// M alone (pool_mix below), so a given shape always takes the same arithmetic path.
+template <int ITER>
+__global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
+    constexpr int PH = 4, LMAX = 64;
+    __shared__ float ps[LMAX * PH];
+    __shared__ float gsh[PH];
+    __shared__ f32x4 accs[4][PH][ITER * 64];              // [wave][head][D / 4]
+    const int L = p.L, D = p.D, nf4 = D / 4;
+    const int m = blockIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hh = lane >> 4;
+    // every global load of the first round (4 hiddens per wave: all of them up to L = 16) is issued before anything is computed:
+    // query, key rows, hidden rows, and for the gating wave the gate weights (and x when it is not the last hidden)
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
+    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + lane * 4);
+    auto load_keys = [&](int l0, f32x4 (&kv)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + 4 * j;
+            kv[j] = l < L ? *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto load_hid = [&](int l0, f32x4 (&v)[4][ITER]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + 4 * j;
+            const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)(l < L ? l : 0) * p.M + m) * D);
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                const int c4 = lane + 64 * i;
+                v[j][i] = (l < L && c4 < nf4) ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    const bool x_is_last_hidden = p.x == p.hid + (int64_t)(L - 1) * p.M * D && p.ldx == D;
+    const bool gating_wave = w == (x_is_last_hidden ? ((L - 1) & 3) : 0);          // l = w (mod 4): the wave that meets hidden L - 1
+    f32x4 kv[4], v[4][ITER], gwv[PH][ITER], xv[ITER];
+    load_keys(w, kv);
+    load_hid(w, v);
+    if (gating_wave) {
+        const f32x4* gw = reinterpret_cast<const f32x4*>(p.gate_w);
+        const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+#pragma unroll
+            for (int h = 0; h < PH; ++h) gwv[h][i] = c4 < nf4 ? gw[h * nf4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            xv[i] = (!x_is_last_hidden && c4 < nf4) ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g4[e] = (g4[e] + 1.f) * 8.f;
+    for (int l0 = w; l0 < L; l0 += 16) {                  // scores of 4 key rows of this wave per round
+        if (l0 != w) load_keys(l0, kv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + 4 * j;
+            const float nrm = sqrtf(row_sum16(kv[j][0] * kv[j][0] + kv[j][1] * kv[j][1] + kv[j][2] * kv[j][2] + kv[j][3] * kv[j][3]));
+            const float inv = 1.f / fmaxf(nrm, 1e-12f);
+            const float sc = row_sum16(q4[0] * (kv[j][0] * inv * g4[0]) + q4[1] * (kv[j][1] * inv * g4[1]) +
+                                       q4[2] * (kv[j][2] * inv * g4[2]) + q4[3] * (kv[j][3] * inv * g4[3])) * 0.125f;
+            if (l < L && (lane & 15) == 0) ps[l * PH + hh] = sc;
+        }
+    }
+    __syncthreads();
+    // softmax over l per head, once (wave 0): entry idx = l * 4 + h sits in lane idx & 63, so a lane's entries share its head
+    // (lane & 3) and the per-head max / sum are butterflies over lane bits 2..5.  ps <- exp(s - max) / sum.
+    if (w == 0) {
+        float sc[4], mm = -FLT_MAX;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = lane + 64 * j;
+            sc[j] = idx < L * PH ? ps[idx] : -FLT_MAX;
+            mm = fmaxf(mm, sc[j]);
+        }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sc[j] = lane + 64 * j < L * PH ? expf(sc[j] - mm) : 0.f; d += sc[j]; }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) d += __shfl_xor(d, o);
+        const float inv = 1.f / d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < L * PH) ps[lane + 64 * j] = sc[j] * inv;
+    }
+    __syncthreads();
+    f32x4 acc[PH][ITER];
+#pragma unroll
+    for (int h = 0; h < PH; ++h)
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto gate_logits = [&](const f32x4 (&r)[ITER], float rstd) {       // gate_h = sigmoid(RMSNorm(x) . gate_w[h])
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) d += r[i][0] * gwv[h][i][0] + r[i][1] * gwv[h][i][1] + r[i][2] * gwv[h][i][2] + r[i][3] * gwv[h][i][3];
+            d = wave_sum(d) * rstd;
+            if (lane == 0) gsh[h] = d;
+        }
+    };
+    for (int l0 = w; l0 < L; l0 += 16) {
+        if (l0 != w) load_hid(l0, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + 4 * j;
+            if (l >= L) break;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) ss += v[j][i][0] * v[j][i][0] + v[j][i][1] * v[j][i][1] + v[j][i][2] * v[j][i][2] + v[j][i][3] * v[j][i][3];
+            const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
+#pragma unroll
+            for (int h = 0; h < PH; ++h) {
+                const float wt = ps[l * PH + h] * rstd;
+#pragma unroll
+                for (int i = 0; i < ITER; ++i) acc[h][i] += v[j][i] * wt;
+            }
+            if (l == L - 1 && x_is_last_hidden) gate_logits(v[j], rstd);
+        }
+    }
+    if (!x_is_last_hidden && w == 0) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+        gate_logits(xv, rsqrtf(wave_sum(ss) / (float)D + p.eps));
+    }
+#pragma unroll
+    for (int h = 0; h < PH; ++h)
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) accs[w][h][lane + 64 * i] = acc[h][i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < PH * ITER * 64; idx += 256) {
+        const int h = idx / (ITER * 64), c4 = idx % (ITER * 64);
+        if (c4 >= nf4) continue;
+        const f32x4 sum = ((accs[0][h][c4] + accs[1][h][c4]) + accs[2][h][c4]) + accs[3][h][c4];
+        reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = sum * sigmoidf(gsh[h]);
+    }
+}
+
 int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.heads == 4, "pool_mix: 4 pool heads expected (AttentionPool default, D4:2147)");
     D4_REQUIRE(p.L >= 1 && p.L <= 64 && p.D % 4 == 0 && p.D <= 1024, "pool_mix: L=%d D=%d out of range", p.L, p.D);
     if (p.M == 0) return 0;
     dim3 grid(cdiv(p.M, 4)), block(256);
+    static const bool rows_on = !(getenv("D4_POOL_MIX_ROWS") && atoi(getenv("D4_POOL_MIX_ROWS")) == 0);
+    if (p.M <= 64 && p.D <= 512 && rows_on) {            // few rows: one block per row (by M alone)
+        if (p.D <= 256) hipLaunchKernelGGL(pool_mix_rows_kernel<1>, dim3(p.M), block, 0, stream, p);
+        else hipLaunchKernelGGL(pool_mix_rows_kernel<2>, dim3(p.M), block, 0, stream, p);
+        D4_LAUNCH_CHECK();
+        return 0;
+    }
     if (p.D <= 256) hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p);
     else if (p.D <= 512) hipLaunchKernelGGL(pool_mix_kernel<2>, grid, block, 0, stream, p);
     else hipLaunchKernelGGL(pool_mix_kernel<4>, grid, block, 0, stream, p);

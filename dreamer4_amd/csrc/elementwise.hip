@@ -200,7 +200,7 @@ __global__ void assemble_kernel(AssembleArgs p) {
         float v;
         if (s == 0) {
             const int half = D / 2;
-            v = d < half ? p.signal_embed[(int64_t)p.signal_levels[f] * half + d]
+            v = d < half ? p.signal_embed[(int64_t)(p.signal_levels ? p.signal_levels[f] : p.signal_uniform) * half + d]
                          : p.step_embed[(int64_t)p.step_log2 * half + (d - half)];
         } else if (s <= p.ns) {
             v = p.space[(f * p.ns + (s - 1)) * D + d];

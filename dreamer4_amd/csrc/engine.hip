@@ -339,6 +339,7 @@ int engine_resolve(d4_engine* e) {
 // The trunk's GEMMs run on the bf16 MFMA kernel when the engine was created with matmul_bf16: engine_forward sets the thread's
 // active engine, and every GEMM issued below it swaps its weight pointer for the bf16 mirror made at prepare time.
 static thread_local d4_engine* t_bf16 = nullptr;
+static thread_local int t_sig_uniform = -1;    // >= 0: every frame of the next engine_forward is at this signal level (decode loop: no fill kernel)
 static thread_local int t_keep_lo = 1;         // first token row of a frame the compacted copies keep (set by engine_forward)
 
 static int mirror_weight(d4_engine* e, const float* src, size_t n, hipStream_t s) {
@@ -377,6 +378,14 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
                        int flags, const float* bias, const float* R, int ldr, hipStream_t s) {
     GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, RMS_EPS};
     return engine_gemm(g, s);
+}
+
+// Two independent projections of equal K: one launch when both are few-row problems (fp32 engine), else one after the other.
+static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
+    if (!t_bf16 && gemm_skinny_pair_applicable(a, b)) return gemm_skinny_pair(a, b, s);
+    int rc;
+    if ((rc = engine_gemm(a, s))) return rc;
+    return engine_gemm(b, s);
 }
 
 static int gemm_c2(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags,
@@ -544,10 +553,11 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     int rc;
     const bool mix_path = c.pool_heads == 4 && D <= 1024;
     // (mix path: the head-gate logits are computed inside pool_mix; hp = 256 columns are exactly two / four tile columns)
-    if ((rc = gemm_simple(x, D, e->pq_w[p], D, e->pool_q, e->ldpq, M, mix_path ? hp : hp + e->php, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    const GemmArgs gq{x, D, e->pq_w[p], D, e->pool_q, e->ldpq, nullptr, nullptr, 0, M, mix_path ? hp : hp + e->php, D, GEMM_RMS_ROWSCALE, RMS_EPS};
     if (mix_path) {
         // keys only: [L*M][hp]; values come from ONE per-head projection of the softmax-weighted normalised hiddens
-        if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, hp, L * M, hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        const GemmArgs gk{hiddens, D, e->pkv_w[p], D, e->pool_kv, hp, nullptr, nullptr, 0, L * M, hp, D, GEMM_RMS_ROWSCALE, RMS_EPS};
+        if ((rc = gemm_two(gq, gk, s))) return rc;
         PoolMixArgs pm{};
         pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
@@ -556,7 +566,8 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         gv.batch = c.pool_heads; gv.strideA = D; gv.strideW = (int64_t)64 * D; gv.strideC = 64;
         if ((rc = engine_gemm(gv, s))) return rc;
     } else {
-    if ((rc = gemm_simple(hiddens, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+    const GemmArgs gkv{hiddens, D, e->pkv_w[p], D, e->pool_kv, 2 * hp, nullptr, nullptr, 0, L * M, 2 * hp, D, GEMM_RMS_ROWSCALE, RMS_EPS};
+    if ((rc = gemm_two(gq, gkv, s))) return rc;
     SmallAttnArgs sa{};
     sa.q = e->pool_q; sa.q_group_stride = e->ldpq; sa.q_item_stride = 0;
     sa.k = e->pool_kv; sa.k_group_stride = 2 * hp; sa.k_item_stride = (int64_t)M * 2 * hp;
@@ -653,7 +664,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         a.tokens = slab0; a.space = e->space; a.signal_embed = e->signal_embed; a.step_embed = e->step_embed;
         a.registers = e->registers; a.agent_embed = e->agent_learned; a.task_embed = e->task_embed;
         a.action_embed = e->action_embed; a.action_learned = e->action_learned;
-        a.signal_levels = e->sig; a.prev_actions = e->na > 0 ? e->pact : nullptr; a.tasks = tasks;
+        a.signal_levels = t_sig_uniform >= 0 ? nullptr : e->sig; a.signal_uniform = t_sig_uniform; a.prev_actions = e->na > 0 ? e->pact : nullptr; a.tasks = tasks;
         a.prev_cont = e->nc > 0 ? e->pcont : nullptr; a.cont_embed = e->cont_embed; a.nc = e->nc;
         a.action_offsets = e->action_offsets;
         a.B = B; a.Tq = Tq; a.S = S; a.D = D; a.ns = ns; a.nr = c.num_register_tokens; a.na = e->na; a.step_log2 = step_log2;
@@ -762,8 +773,11 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         const float* agent_in = last + (size_t)(S - 1) * D;
         float* agent_rows = xfc + (size_t)ns * D;
         const int lda = S * D, ldc = nkeep * D;
-        if ((rc = gemm_simple(agent_in, lda, e->cq_w, D, e->cq, e->ldcq, Fr, hd + h, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
-        if ((rc = gemm_simple(last, D, e->ckv_w, D, e->ckv, 2 * hd, M, 2 * hd, D, GEMM_RMS_ROWSCALE, nullptr, nullptr, 0, s))) return rc;
+        {
+            const GemmArgs gq{agent_in, lda, e->cq_w, D, e->cq, e->ldcq, nullptr, nullptr, 0, Fr, hd + h, D, GEMM_RMS_ROWSCALE, RMS_EPS};
+            const GemmArgs gkv{last, D, e->ckv_w, D, e->ckv, 2 * hd, nullptr, nullptr, 0, M, 2 * hd, D, GEMM_RMS_ROWSCALE, RMS_EPS};
+            if ((rc = gemm_two(gq, gkv, s))) return rc;
+        }
         SmallAttnArgs sa{};
         sa.dh = c.attn_dim_head;
         sa.q = e->cq; sa.q_group_stride = e->ldcq; sa.q_item_stride = 0;
@@ -1159,8 +1173,10 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                     int crc = 0;
                     for (int step = 0; step <= K && !crc; ++step) {
                         const int sig_val = step * step_size < c.max_steps - 1 ? step * step_size : c.max_steps - 1;
-                        if ((crc = d4::fill_sig(e->sig, B, sig_val, cs))) break;
-                        if ((crc = d4::engine_forward(e, e->x_lat, B, 1, t0, sl, tasks, step == K, cs, e->fstate))) break;
+                        d4::t_sig_uniform = sig_val;
+                        crc = d4::engine_forward(e, e->x_lat, B, 1, t0, sl, tasks, step == K, cs, e->fstate);
+                        d4::t_sig_uniform = -1;
+                        if (crc) break;
                         if (step == K) break;
                         const float tt = (float)sig_val / (float)c.max_steps;
                         crc = d4::euler_step(e->x_lat, n_el, e->pred, n_el, B, n_el, 1.f - tt, (float)step_size / (float)c.max_steps, cs);
@@ -1178,8 +1194,10 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
             } else {
                 for (int step = 0; step <= K; ++step) {
                     const int sig_val = step * step_size < c.max_steps - 1 ? step * step_size : c.max_steps - 1;
-                    if ((rc = d4::fill_sig(e->sig, B, sig_val, s))) return rc;
-                    if ((rc = d4::engine_forward(e, e->x_lat, B, 1, t0, sl, tasks, step == K, s, e->fstate))) return rc;
+                    d4::t_sig_uniform = sig_val;
+                    rc = d4::engine_forward(e, e->x_lat, B, 1, t0, sl, tasks, step == K, s, e->fstate);
+                    d4::t_sig_uniform = -1;
+                    if (rc) return rc;
                     if (step == K) break;
                     const float tt = (float)sig_val / (float)c.max_steps;
                     if ((rc = d4::euler_step(e->x_lat, n_el, e->pred, n_el, B, n_el, 1.f - tt, (float)step_size / (float)c.max_steps, s))) return rc;

@@ -50,6 +50,8 @@ void gemm2_config_tile(int c, int* bm, int* bn);
 int gemm2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 bool gemm_skinny_applicable(const GemmArgs& p);            // M <= 16 rows: VALU kernel that streams W once (gemm_skinny.hip)
 int gemm_skinny(const GemmArgs& p, hipStream_t stream);
+bool gemm_skinny_pair_applicable(const GemmArgs& a, const GemmArgs& b);   // two few-row GEMMs of equal K in one launch
+int gemm_skinny_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream);
 int gemm_profile_enable(int on);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
@@ -137,7 +139,8 @@ struct AssembleArgs {
     const float* task_embed;       // [num_tasks][D] or null
     const float* action_embed;     // [total_actions][D]
     const float* action_learned;   // [D]
-    const int32_t* signal_levels;  // [B*Tq]
+    const int32_t* signal_levels;  // [B*Tq], or null: every frame is at signal_uniform
+    int signal_uniform = 0;
     const int64_t* prev_actions;   // [B*Tq][na] (-1 in slot 0 => zero token) or null (=> zero token)
     const float* prev_cont;        // [B*Tq][nc] continuous actions (NaN in slot 0 => zero token when na == 0) or null
     const float* cont_embed;       // [nc][D]  action_embedder.continuous_action_embed.weight
