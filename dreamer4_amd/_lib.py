@@ -89,6 +89,12 @@ SYMBOLS = {
     'd4_engine_cache_import': (_I, [_P, _P, _I, _I, _P]),
     'd4_wm_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'd4_decoder_forward': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'd4_ff_workspace_bytes': (C.c_size_t, [_I, _I, _I]),
+    'd4_ff_forward': (_I, [_P] * 6 + [_I, _I, _I, _P, _P, C.c_size_t, _P]),
+    'd4_ff_backward': (_I, [_P] * 6 + [_I, _I, _I] + [_P] * 6 + [_P, C.c_size_t, _P]),
+    'd4_attn_workspace_bytes': (C.c_size_t, [_I] * 5),
+    'd4_space_attn_forward': (_I, [_P] * 11 + [_I] * 5 + [_F, _I, _I, _P, _P, C.c_size_t, _P]),
+    'd4_space_attn_backward': (_I, [_P] * 12 + [_I] * 5 + [_F, _I, _I] + [_P] * 11 + [_P, C.c_size_t, _P]),
     'd4_encoder_forward': (_I, [_P, _P, _I, _I, _P, _P]),
     'd4_euler_step': (_I, [_P, _P, _L, _F, _F, _P]),
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),

@@ -1,0 +1,411 @@
+// Trunk backward, first slice (SURVEY.md 8f-3 groundwork): the FeedForward block (D4:2079-2116) and the space-attention block
+// (Attention.forward D4:1968-2075 in its self-attention form: RMSNorm, q/k/v, learned value-residual mix, K-head-RMSNorm, soft clamp,
+// special-token mask, belief projection, head gates, to_out) as forward + backward operators on the REFERENCE parameter layout, so they
+// can be checked directly against autograd of the oracle's restatement (tests/test_gpu_backward.py).
+//
+// The matrix work is the engine's fp32 MFMA GEMM (transposed-operand forms for dX / dW); what is new here is the attention-core
+// backward kernel (one block per (frame, head), everything for <= 32 tokens in LDS) and the SiLU-GLU / RMSNorm backward glue.
+// Nothing here is called by the imagination path; the dynamics training branch (D4:7297-7431) is the consumer to come.
+#include "common.h"
+#include "kernels.h"
+#include "../../include/d4hip.h"
+#include <float.h>
+
+namespace d4 {
+
+static constexpr float RMS_EPS = 1.1920928955078125e-07f;   // torch.finfo(float32).eps (nn.RMSNorm eps=None)
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------ SiLU-GLU glue
+// hidden layout [rows][2 * Ip]: value half at column 0, gate half at column Ip (Ip = inner rounded up to 4; pad columns are zero)
+__global__ void swiglu_fwd_kernel(const float* h, float* u, int rows, int I, int Ip) {
+    const int64_t tot = (int64_t)rows * Ip;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Ip);
+        const int64_t r = i / Ip;
+        const float a = h[r * 2 * Ip + c], g = h[r * 2 * Ip + Ip + c];
+        u[i] = c < I ? a * g * sigm(g) : 0.f;
+    }
+}
+// dh = [du * silu(g) | du * a * silu'(g)]
+__global__ void swiglu_bwd_kernel(const float* h, const float* du, float* dh, int rows, int I, int Ip) {
+    const int64_t tot = (int64_t)rows * Ip;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Ip);
+        const int64_t r = i / Ip;
+        const float a = h[r * 2 * Ip + c], g = h[r * 2 * Ip + Ip + c], d = du[i];
+        const float s = sigm(g);
+        dh[r * 2 * Ip + c] = c < I ? d * g * s : 0.f;
+        dh[r * 2 * Ip + Ip + c] = c < I ? d * a * s * (1.f + g * (1.f - s)) : 0.f;
+    }
+}
+static dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)); }
+
+static int gemm_b(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias, int M, int N, int K, int flags, hipStream_t s) {
+    GemmArgs g{A, lda, W, ldw, C, ldc, bias, nullptr, 0, M, N, K, flags, 0.f};
+    return gemm(g, s);
+}
+
+struct FfWs {            // workspace carve-up (floats); all leading dimensions are multiples of 4
+    float *xn, *w1p, *b1p, *w2p, *h, *u, *du, *dh, *dxn, *tg, *dw1p, *dw2p;
+    size_t total;
+};
+static FfWs ff_ws(float* base, int R, int D, int I) {
+    const size_t Ip = (size_t)(I + 3) / 4 * 4;
+    FfWs w{};
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+    w.xn = take((size_t)R * D); w.w1p = take(2 * Ip * D); w.b1p = take(2 * Ip); w.w2p = take((size_t)D * Ip);
+    w.h = take((size_t)R * 2 * Ip); w.u = take((size_t)R * Ip); w.du = take((size_t)R * Ip); w.dh = take((size_t)R * 2 * Ip);
+    w.dxn = take((size_t)R * D); w.tg = take((size_t)R * D); w.dw1p = take(2 * Ip * D); w.dw2p = take((size_t)D * Ip);
+    w.total = off;
+    return w;
+}
+
+// padded copies of proj_in ([a rows | pad | g rows | pad]), its bias, and proj_out (columns padded), then the forward up to u
+static int ff_recompute(const FfWs& w, const float* x, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+                        int R, int D, int I, hipStream_t s) {
+    const int Ip = (I + 3) / 4 * 4;
+    int rc;
+    D4_HIP(hipMemsetAsync(w.w1p, 0, sizeof(float) * 2 * Ip * D, s));
+    D4_HIP(hipMemsetAsync(w.b1p, 0, sizeof(float) * 2 * Ip, s));
+    D4_HIP(hipMemcpyAsync(w.w1p, w_in, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.w1p + (size_t)Ip * D, w_in + (size_t)I * D, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.b1p, b_in, sizeof(float) * I, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.b1p + Ip, b_in + I, sizeof(float) * I, hipMemcpyDeviceToDevice, s));
+    if ((rc = pad_cols(w_out, w.w2p, D, I, Ip, s))) return rc;
+    if ((rc = rmsnorm_rows(x, D, norm_w, w.xn, D, R, D, RMS_EPS, s))) return rc;
+    if ((rc = gemm_b(w.xn, D, w.w1p, D, w.h, 2 * Ip, w.b1p, R, 2 * Ip, D, 0, s))) return rc;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, grid_for((int64_t)R * Ip), dim3(256), 0, s, w.h, w.u, R, I, Ip);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ attention core backward
+// One block (4 waves) per (frame, head); S <= 32 tokens, head dim DH <= 64 (lanes >= DH idle).  Rows of proj: q @ 0, k @ hd, v @ 2hd,
+// gate logit @ 3hd + head, mix logit @ 3hd + hp4 + head  (hd = heads * DH, hp4 = heads rounded up to 4).
+struct AttnBwdArgs {
+    const float* proj; int ldp;        // [F*S][ldp] forward projections (mix logits include their bias)
+    const float* rv;                   // [F*S][hd] value residual or null
+    const float* gamma;                // [heads][DH]
+    const float* d_o3;                 // [F*S][hd] gradient of the gated attention output (before to_out); null: forward only
+    float* o3;                         // [F*S][hd] out: gated attention output (recomputed forward)
+    float* dproj;                      // [F*S][ldp] out: gradients of the projections (same columns)
+    float* d_rv;                       // [F*S][hd] out (when rv)
+    float* dgamma_part;                // [F][hd] out: per-frame partial of d gamma
+    int F, S, heads, hp4;
+    float softclamp; int num_special, belief;
+};
+
+constexpr int AB_S = 32, AB_LD = 65;
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
+    __shared__ float qs[AB_S * AB_LD], kn[AB_S * AB_LD], kh[AB_S * AB_LD], vm[AB_S * AB_LD], dO[AB_S * AB_LD], dvm[AB_S * AB_LD];     // 6 x 8.3 KB
+    __shared__ float P[AB_S * (AB_S + 1)], dsm[AB_S * (AB_S + 1)];
+    __shared__ float kinv[AB_S], vinv[AB_S], mxs[AB_S], gts[AB_S];
+    __shared__ float gpart[4][64];
+    const int S = p.S, hd = p.heads * DH;
+    const int f = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool on = lane < DH;
+    const int64_t row0 = (int64_t)f * S;
+    const float sc = on ? (p.gamma[h * DH + lane] + 1.f) * sqrtf((float)DH) : 0.f;
+    const float scale = rsqrtf((float)DH);
+    const bool bwd = p.d_o3 != nullptr;
+
+    // ---- phase A: per token j: value mix, key normalisation
+    for (int j = w; j < S; j += 4) {
+        const float* pr = p.proj + (row0 + j) * p.ldp;
+        const float qv = on ? pr[h * DH + lane] : 0.f, kv = on ? pr[hd + h * DH + lane] : 0.f;
+        float vv = on ? pr[2 * hd + h * DH + lane] : 0.f;
+        float mx = 0.f;
+        if (p.rv) {
+            mx = sigm(pr[3 * hd + p.hp4 + h]);
+            const float r = on ? p.rv[(row0 + j) * hd + h * DH + lane] : 0.f;
+            vv = vv + mx * (r - vv);
+        }
+        const float ki = 1.f / fmaxf(sqrtf(wave_sum(kv * kv)), 1e-12f);
+        const float vi = 1.f / fmaxf(sqrtf(wave_sum(vv * vv)), 1e-12f);
+        qs[j * AB_LD + lane] = qv; kh[j * AB_LD + lane] = kv * ki; kn[j * AB_LD + lane] = kv * ki * sc;
+        vm[j * AB_LD + lane] = vv;
+        if (lane == 0) { kinv[j] = ki; vinv[j] = vi; mxs[j] = mx; gts[j] = sigm(pr[3 * hd + h]); }
+    }
+    __syncthreads();
+
+    // ---- phase B: per query i (lane = key j for the score row, lane = feature for the vectors)
+    const int first_special = S - p.num_special;
+    for (int i = w; i < S; i += 4) {
+        float dot = 0.f;
+        if (lane < S) {
+#pragma unroll 8
+            for (int d = 0; d < DH; ++d) dot += qs[i * AB_LD + d] * kn[lane * AB_LD + d];
+        }
+        const float sim = dot * scale;
+        float th = 0.f, simc = sim;
+        if (p.softclamp > 0.f) { th = tanhf(sim / p.softclamp); simc = th * p.softclamp; }
+        const bool visible = lane < S && !(i < first_special && lane >= first_special);
+        simc = visible ? simc : -FLT_MAX;
+        float m = simc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e = visible ? expf(simc - m) : 0.f;
+        const float pij = e / wave_sum(e);
+        // o_i = sum_j P_ij vm_j
+        float o = 0.f;
+        for (int j = 0; j < S; ++j) o += __shfl(pij, j) * vm[j * AB_LD + lane];
+        const float vni = vm[i * AB_LD + lane] * vinv[i];
+        const float sdot = p.belief ? wave_sum(o * vni) : 0.f;
+        const float o2 = o - sdot * vni;
+        const float gt = gts[i];
+        if (on) p.o3[(row0 + i) * hd + h * DH + lane] = o2 * gt;
+        if (!bwd) continue;
+        const float d3 = on ? p.d_o3[(row0 + i) * hd + h * DH + lane] : 0.f;
+        const float dgl = wave_sum(d3 * o2) * gt * (1.f - gt);
+        if (lane == 0) p.dproj[(row0 + i) * p.ldp + 3 * hd + h] = dgl;
+        const float d2 = d3 * gt;
+        float dOi = d2, dvdir = 0.f;
+        if (p.belief) {
+            const float c2 = wave_sum(d2 * vni);
+            dOi = d2 - c2 * vni;
+            const float dvn = -(sdot * d2 + c2 * o);
+            dvdir = (dvn - wave_sum(dvn * vni) * vni) * vinv[i];
+        }
+        dO[i * AB_LD + lane] = dOi;
+        dvm[i * AB_LD + lane] = dvdir;
+        // dP_ij = dO_i . vm_j  (lane = j)
+        float dp = 0.f;
+        if (lane < S) {
+#pragma unroll 8
+            for (int d = 0; d < DH; ++d) dp += dO[i * AB_LD + d] * vm[lane * AB_LD + d];
+        }
+        const float rowdot = wave_sum(pij * dp);
+        float dsim = pij * (dp - rowdot);
+        if (p.softclamp > 0.f) dsim *= 1.f - th * th;
+        dsim *= scale;
+        if (lane < S) { P[i * (AB_S + 1) + lane] = pij; dsm[i * (AB_S + 1) + lane] = dsim; }
+        // dq_i = sum_j dsim_ij kn_j
+        float dq = 0.f;
+        for (int j = 0; j < S; ++j) dq += __shfl(dsim, j) * kn[j * AB_LD + lane];
+        if (on) p.dproj[(row0 + i) * p.ldp + h * DH + lane] = dq;
+    }
+    if (!bwd) return;
+    __syncthreads();
+
+    // ---- phase C: per key / value token j (lane = feature)
+    float gacc = 0.f;
+    for (int j = w; j < S; j += 4) {
+        float dkn = 0.f, dv = dvm[j * AB_LD + lane];
+        for (int i = 0; i < S; ++i) {
+            dkn += dsm[i * (AB_S + 1) + j] * qs[i * AB_LD + lane];
+            dv += P[i * (AB_S + 1) + j] * dO[i * AB_LD + lane];
+        }
+        const float khj = kh[j * AB_LD + lane];
+        gacc += dkn * khj;
+        const float dkh = dkn * sc;
+        const float dk = (dkh - wave_sum(dkh * khj) * khj) * kinv[j];
+        float* dr = p.dproj + (row0 + j) * p.ldp;
+        if (on) dr[hd + h * DH + lane] = dk;
+        if (p.rv) {
+            const float mx = mxs[j];
+            const float* pr = p.proj + (row0 + j) * p.ldp;
+            const float vraw = on ? pr[2 * hd + h * DH + lane] : 0.f;
+            const float r = on ? p.rv[(row0 + j) * hd + h * DH + lane] : 0.f;
+            const float dmx = wave_sum(dv * (r - vraw));
+            if (on) { dr[2 * hd + h * DH + lane] = dv * (1.f - mx); p.d_rv[(row0 + j) * hd + h * DH + lane] = dv * mx; }
+            if (lane == 0) dr[3 * hd + p.hp4 + h] = dmx * mx * (1.f - mx);
+        } else {
+            if (on) dr[2 * hd + h * DH + lane] = dv;
+            if (lane == 0) dr[3 * hd + p.hp4 + h] = 0.f;
+        }
+    }
+    gpart[w][lane] = gacc;
+    __syncthreads();
+    if (w == 0 && on) p.dgamma_part[(int64_t)f * hd + h * DH + lane] = (((gpart[0][lane] + gpart[1][lane]) + gpart[2][lane]) + gpart[3][lane]) * sqrtf((float)DH);
+}
+
+static int attn_core(const AttnBwdArgs& a, int dh, hipStream_t s) {
+    if (a.F * a.heads == 0) return 0;
+    if (dh == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(a.F * a.heads), dim3(256), 0, s, a);
+    else if (dh == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(a.F * a.heads), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(a.F * a.heads), dim3(256), 0, s, a);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void zero_pad_cols_kernel(float* x, int rows, int ld, int c0, int c1) {
+    const int n = c1 - c0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * n; i += (int64_t)gridDim.x * blockDim.x)
+        x[(i / n) * ld + c0 + (int)(i % n)] = 0.f;
+}
+
+struct AttnWs {
+    float *xn, *wcat, *bcat, *proj, *dproj, *d_o3, *o3, *dwcat, *tg, *dxn, *gpart;
+    size_t total;
+    int P, hp4;
+};
+static AttnWs attn_ws(float* base, int R, int F, int D, int heads, int dh) {
+    AttnWs w{};
+    const int hd = heads * dh;
+    w.hp4 = (heads + 3) / 4 * 4;
+    w.P = 3 * hd + 2 * w.hp4;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+    w.xn = take((size_t)R * D); w.wcat = take((size_t)w.P * D); w.bcat = take(w.P); w.proj = take((size_t)R * w.P); w.dproj = take((size_t)R * w.P);
+    w.d_o3 = take((size_t)R * hd); w.o3 = take((size_t)R * hd); w.dwcat = take((size_t)w.P * D); w.tg = take((size_t)R * D); w.dxn = take((size_t)R * D);
+    w.gpart = take((size_t)F * hd);
+    w.total = off;
+    return w;
+}
+
+struct AttnParams { const float *norm_w, *wq, *wk, *wv, *wo, *wg, *wm, *bm, *gamma; };
+
+// concatenated projection [q | k | v | gates (hp4) | mix (hp4)] and the forward up to the projections
+static int attn_project(const AttnWs& w, const float* x, const AttnParams& prm, int R, int D, int heads, int dh, bool has_rv, hipStream_t s) {
+    const int hd = heads * dh;
+    int rc;
+    D4_HIP(hipMemsetAsync(w.wcat, 0, sizeof(float) * (size_t)w.P * D, s));
+    D4_HIP(hipMemsetAsync(w.bcat, 0, sizeof(float) * w.P, s));
+    const size_t blk = sizeof(float) * (size_t)hd * D;
+    D4_HIP(hipMemcpyAsync(w.wcat, prm.wq, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.wcat + (size_t)hd * D, prm.wk, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.wcat + (size_t)2 * hd * D, prm.wv, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.wcat + (size_t)3 * hd * D, prm.wg, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+    if (has_rv) {
+        D4_HIP(hipMemcpyAsync(w.wcat + (size_t)(3 * hd + w.hp4) * D, prm.wm, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+        D4_HIP(hipMemcpyAsync(w.bcat + 3 * hd + w.hp4, prm.bm, sizeof(float) * heads, hipMemcpyDeviceToDevice, s));
+    }
+    if ((rc = rmsnorm_rows(x, D, prm.norm_w, w.xn, D, R, D, RMS_EPS, s))) return rc;
+    return gemm_b(w.xn, D, w.wcat, D, w.proj, w.P, w.bcat, R, w.P, D, 0, s);
+}
+
+}  // namespace d4
+
+using namespace d4;
+
+extern "C" {
+
+size_t d4_ff_workspace_bytes(int rows, int dim, int inner) { return ff_ws(nullptr, rows, dim, inner).total * sizeof(float); }
+
+int d4_ff_forward(const float* x, const float* norm_w, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                  int rows, int dim, int inner, float* y, float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(x && norm_w && w_in && b_in && w_out && b_out && y && workspace, "d4_ff_forward: null argument");
+    D4_REQUIRE(dim % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "d4_ff_forward: dim must be a multiple of 4 and the workspace 256-byte aligned");
+    D4_REQUIRE(workspace_bytes >= d4_ff_workspace_bytes(rows, dim, inner), "d4_ff_forward: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows == 0) return 0;
+    const FfWs w = ff_ws(workspace, rows, dim, inner);
+    const int Ip = (inner + 3) / 4 * 4;
+    int rc;
+    if ((rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, rows, dim, inner, s))) return rc;
+    return gemm_b(w.u, Ip, w.w2p, Ip, y, dim, b_out, rows, dim, Ip, 0, s);
+}
+
+int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+                   int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
+                   float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(x && dy && norm_w && w_in && b_in && w_out && dx && d_norm_w && d_w_in && d_b_in && d_w_out && d_b_out && workspace, "d4_ff_backward: null argument");
+    D4_REQUIRE(dim % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "d4_ff_backward: dim must be a multiple of 4 and the workspace 256-byte aligned");
+    D4_REQUIRE(workspace_bytes >= d4_ff_workspace_bytes(rows, dim, inner), "d4_ff_backward: workspace too small");
+    D4_REQUIRE(rows >= 1, "d4_ff_backward: no rows");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = rows, D = dim, I = inner, Ip = (inner + 3) / 4 * 4;
+    const FfWs w = ff_ws(workspace, R, D, I);
+    int rc;
+    if ((rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, R, D, I, s))) return rc;
+    // y = u W2^T + b2
+    if ((rc = colsum(dy, D, R, D, d_b_out, s))) return rc;
+    if ((rc = gemm_b(dy, D, w.u, Ip, w.dw2p, Ip, nullptr, D, Ip, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;     // dW2 = dy^T u
+    if ((rc = copy_rows(w.dw2p, Ip, d_w_out, I, D, I, s))) return rc;
+    if ((rc = gemm_b(dy, D, w.w2p, Ip, w.du, Ip, nullptr, R, Ip, D, GEMM_TRANS_B, s))) return rc;                       // du = dy W2
+    hipLaunchKernelGGL(swiglu_bwd_kernel, grid_for((int64_t)R * Ip), dim3(256), 0, s, w.h, w.du, w.dh, R, I, Ip);
+    D4_LAUNCH_CHECK();
+    // h = xn W1^T + b1
+    if ((rc = colsum(w.dh, 2 * Ip, R, I, d_b_in, s))) return rc;
+    if ((rc = colsum(w.dh + Ip, 2 * Ip, R, I, d_b_in + I, s))) return rc;
+    if ((rc = gemm_b(w.dh, 2 * Ip, w.xn, D, w.dw1p, D, nullptr, 2 * Ip, D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;   // dW1 = dh^T xn
+    D4_HIP(hipMemcpyAsync(d_w_in, w.dw1p, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(d_w_in + (size_t)I * D, w.dw1p + (size_t)Ip * D, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
+    if ((rc = gemm_b(w.dh, 2 * Ip, w.w1p, D, w.dxn, D, nullptr, R, D, 2 * Ip, GEMM_TRANS_B, s))) return rc;            // dxn = dh W1
+    // xn = rmsnorm(x) * gamma
+    if ((rc = rmsnorm_bwd(x, w.dxn, norm_w, w.tg, dx, R, D, RMS_EPS, s))) return rc;
+    return colsum(w.tg, D, R, D, d_norm_w, s);
+}
+
+size_t d4_attn_workspace_bytes(int frames, int tokens, int dim, int heads, int dim_head) {
+    return attn_ws(nullptr, frames * tokens, frames, dim, heads, dim_head).total * sizeof(float);
+}
+
+static int attn_check(int frames, int tokens, int dim, int heads, int dim_head, const float* workspace, size_t workspace_bytes) {
+    D4_REQUIRE(tokens >= 1 && tokens <= AB_S, "space attention backward: %d tokens per frame (max %d)", tokens, AB_S);
+    D4_REQUIRE(dim_head == 16 || dim_head == 32 || dim_head == 64, "space attention backward: head dim %d (16, 32 or 64)", dim_head);
+    D4_REQUIRE(dim % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "space attention: dim must be a multiple of 4 and the workspace 256-byte aligned");
+    D4_REQUIRE(workspace_bytes >= d4_attn_workspace_bytes(frames, tokens, dim, heads, dim_head), "space attention: workspace too small");
+    return 0;
+}
+
+int d4_space_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
+                          const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                          int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
+                          float* y, float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(x && norm_w && wq && wk && wv && wo && w_gates && k_gamma && y && workspace, "d4_space_attn_forward: null argument");
+    D4_REQUIRE(!residual_values || (w_mix && b_mix), "d4_space_attn_forward: residual values need the mix projection");
+    int rc;
+    if ((rc = attn_check(frames, tokens, dim, heads, dim_head, workspace, workspace_bytes))) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = frames * tokens, hd = heads * dim_head;
+    if (R == 0) return 0;
+    const AttnWs w = attn_ws(workspace, R, frames, dim, heads, dim_head);
+    const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
+    if ((rc = attn_project(w, x, prm, R, dim, heads, dim_head, residual_values != nullptr, s))) return rc;
+    AttnBwdArgs a{w.proj, w.P, residual_values, k_gamma, nullptr, w.o3, nullptr, nullptr, nullptr, frames, tokens, heads, w.hp4, softclamp, num_special, belief};
+    if ((rc = attn_core(a, dim_head, s))) return rc;
+    return gemm_b(w.o3, hd, wo, hd, y, dim, nullptr, R, dim, hd, 0, s);
+}
+
+int d4_space_attn_backward(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                           const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                           int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
+                           float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(x && dy && norm_w && wq && wk && wv && wo && w_gates && k_gamma && workspace, "d4_space_attn_backward: null argument");
+    D4_REQUIRE(dx && d_norm_w && d_wq && d_wk && d_wv && d_wo && d_w_gates && d_k_gamma, "d4_space_attn_backward: null gradient output");
+    D4_REQUIRE(!residual_values || (w_mix && b_mix && d_residual_values && d_w_mix && d_b_mix), "d4_space_attn_backward: residual values need the mix projection and its gradients");
+    int rc;
+    if ((rc = attn_check(frames, tokens, dim, heads, dim_head, workspace, workspace_bytes))) return rc;
+    D4_REQUIRE(frames >= 1, "d4_space_attn_backward: no frames");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = frames * tokens, D = dim, hd = heads * dim_head;
+    const bool has_rv = residual_values != nullptr;
+    const AttnWs w = attn_ws(workspace, R, frames, D, heads, dim_head);
+    const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
+    if ((rc = attn_project(w, x, prm, R, D, heads, dim_head, has_rv, s))) return rc;
+    // out = o3 Wo^T
+    if ((rc = gemm_b(dy, D, wo, hd, w.d_o3, hd, nullptr, R, hd, D, GEMM_TRANS_B, s))) return rc;                        // d_o3 = dy Wo
+    AttnBwdArgs a{w.proj, w.P, residual_values, k_gamma, w.d_o3, w.o3, w.dproj, d_residual_values, w.gpart, frames, tokens, heads, w.hp4, softclamp, num_special, belief};
+    if ((rc = attn_core(a, dim_head, s))) return rc;
+    if (w.hp4 > heads) {           // the pad columns of the gate / mix logits carry no gradient
+        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + heads, 3 * hd + w.hp4);
+        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
+        D4_LAUNCH_CHECK();
+    }
+    if ((rc = gemm_b(dy, D, w.o3, hd, d_wo, hd, nullptr, D, hd, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;          // dWo = dy^T o3
+    if ((rc = colsum(w.gpart, hd, frames, hd, d_k_gamma, s))) return rc;
+    // projections: dW = dproj^T xn, dxn = dproj Wcat
+    if ((rc = gemm_b(w.dproj, w.P, w.xn, D, w.dwcat, D, nullptr, w.P, D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    const size_t blk = sizeof(float) * (size_t)hd * D;
+    D4_HIP(hipMemcpyAsync(d_wq, w.dwcat, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(d_wk, w.dwcat + (size_t)hd * D, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(d_wv, w.dwcat + (size_t)2 * hd * D, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(d_w_gates, w.dwcat + (size_t)3 * hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+    if (has_rv) {
+        D4_HIP(hipMemcpyAsync(d_w_mix, w.dwcat + (size_t)(3 * hd + w.hp4) * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+        if ((rc = colsum(w.dproj + 3 * hd + w.hp4, w.P, R, heads, d_b_mix, s))) return rc;
+    }
+    if ((rc = gemm_b(w.dproj, w.P, w.wcat, D, w.dxn, D, nullptr, R, D, w.P, GEMM_TRANS_B, s))) return rc;
+    if ((rc = rmsnorm_bwd(x, w.dxn, norm_w, w.tg, dx, R, D, RMS_EPS, s))) return rc;
+    return colsum(w.tg, D, R, D, d_norm_w, s);
+}
+
+}  // extern "C"

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int ld, in
         out[c] = t;
     }
 }
-static int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s) {
+int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s) {
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 16)), dim3(1024), 0, s, x, ld, rows, cols, out);
     D4_LAUNCH_CHECK();
     return 0;
@@ -363,6 +363,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* x, const 
         tg[(int64_t)r * d + c] = g * v * rstd;
         if (dx) dx[(int64_t)r * d + c] = rstd * (gamma[c] * g - v * rstd * rstd * dot);
     }
+}
+
+int rmsnorm_bwd(const float* x, const float* dxhat, const float* gamma, float* tg, float* dx, int rows, int d, float eps, hipStream_t s) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, dxhat, gamma, tg, dx, rows, d, eps);
+    D4_LAUNCH_CHECK();
+    return 0;
 }
 
 // Backward through a = silu(y), y = LayerNorm(z) * g + b (one wave per row, z recomputed into zhat):

@@ -249,6 +249,31 @@ int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, 
 /* the bf16 MFMA kernel alone: A fp32 [M][lda] (rounded to bf16 on the way in), Wb bf16 [N][ldw] (raw 16-bit patterns), C fp32 */
 int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
+/* ---- trunk backward, first slice (SURVEY.md 8f-3 groundwork; not on the imagination path) ----
+ * FeedForward block (dreamer4.py:2079-2116) on the reference parameter layout: y = proj_out(a * silu(g)) with [a | g] = proj_in(RMSNorm(x));
+ * x / y / dy / dx [rows][dim], norm_w [dim], w_in [2*inner][dim], b_in [2*inner], w_out [dim][inner], b_out [dim].  The backward
+ * recomputes the forward intermediates (nothing is saved between the two calls).  workspace: 256-byte aligned device memory. */
+size_t d4_ff_workspace_bytes(int rows, int dim, int inner);
+int d4_ff_forward(const float* x, const float* norm_w, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
+                  int rows, int dim, int inner, float* y, float* workspace, size_t workspace_bytes, void* stream);
+int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+                   int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
+                   float* workspace, size_t workspace_bytes, void* stream);
+/* Space attention block (Attention.forward, dreamer4.py:1968-2075, self attention within a frame): x / y [frames*tokens][dim],
+ * residual_values [frames*tokens][heads*dim_head] or null (then w_mix / b_mix and their gradients are unused), wq / wk / wv
+ * [heads*dim_head][dim], wo [dim][heads*dim_head], w_gates / w_mix [heads][dim], b_mix [heads], k_gamma [heads][dim_head];
+ * tokens <= 32 per frame, dim_head 16 / 32 / 64; num_special trailing tokens are hidden from the ordinary queries (dreamer4.py:1769-1783). */
+size_t d4_attn_workspace_bytes(int frames, int tokens, int dim, int heads, int dim_head);
+int d4_space_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
+                          const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                          int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
+                          float* y, float* workspace, size_t workspace_bytes, void* stream);
+int d4_space_attn_backward(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                           const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                           int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
+                           float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                           float* workspace, size_t workspace_bytes, void* stream);
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
                float eps, void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,

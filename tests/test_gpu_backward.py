@@ -1,0 +1,138 @@
+"""GPU: the first slice of the trunk backward (SURVEY.md 8f-3 groundwork) — FeedForward and within-frame Attention blocks as
+forward + backward HIP operators (include/d4hip.h d4_ff_* / d4_space_attn_*), checked against autograd of the oracle's restatement
+(oracle/restate.py feedforward / attention, evaluated in float64).  Tolerance: 2e-4 of each tensor's scale (fp32 MFMA accumulation
+over up to a few thousand rows)."""
+import pytest
+import torch
+
+from dreamer4_amd import trunk_ops
+from oracle import restate
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, name, tol=2e-4):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(b.abs().max().item(), 1e-6)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f'{name}: max abs diff {err:.3e} vs scale {scale:.3e}'
+
+
+def _ff_params(D, inner, g):
+    r = lambda *s, k=1.: torch.randn(*s, generator=g) * k
+    return {'norm.weight': 1. + r(D, k=.1), 'proj_in.weight': r(2 * inner, D, k=D ** -.5), 'proj_in.bias': r(2 * inner, k=.3),
+            'proj_out.weight': r(D, inner, k=inner ** -.5), 'proj_out.bias': r(D, k=.3)}
+
+
+@pytest.mark.parametrize('lead,D,inner', [((37,), 64, 170), ((3, 100), 512, 1365), ((1,), 32, 85)])
+def test_feedforward_forward_and_backward_vs_oracle_autograd(lead, D, inner):
+    g = torch.Generator().manual_seed(3)
+    W = _ff_params(D, inner, g)
+    x = torch.randn(*lead, D, generator=g) * 1.5
+    dy = torch.randn(*lead, D, generator=g)
+    Wd = {k: v.double().requires_grad_() for k, v in W.items()}
+    xd = x.double().requires_grad_()
+    ref = restate.feedforward(Wd, '', xd)
+    ref.backward(dy.double())
+    Wg = {k: v.cuda().requires_grad_() for k, v in W.items()}
+    xg = x.cuda().requires_grad_()
+    y = trunk_ops.feedforward(xg, Wg['norm.weight'], Wg['proj_in.weight'], Wg['proj_in.bias'], Wg['proj_out.weight'], Wg['proj_out.bias'])
+    close(y, ref, 'y')
+    y.backward(dy.cuda())
+    close(xg.grad, xd.grad, 'dx')
+    for k in W:
+        close(Wg[k].grad, Wd[k].grad, 'd ' + k)
+
+
+def _attn_params(D, heads, dh, g):
+    r = lambda *s, k=1.: torch.randn(*s, generator=g) * k
+    hd = heads * dh
+    return {'norm.weight': 1. + r(D, k=.1), 'to_q.weight': r(hd, D, k=3. * D ** -.5), 'to_k.weight': r(hd, D, k=D ** -.5), 'to_v.weight': r(hd, D, k=D ** -.5),
+            'to_out.weight': r(D, hd, k=hd ** -.5), 'to_gates.0.weight': r(heads, D, k=D ** -.5), 'k_heads_rmsnorm.gamma': r(heads, dh, k=.3),
+            'to_learned_value_residual_mix.0.weight': r(heads, D, k=D ** -.5), 'to_learned_value_residual_mix.0.bias': r(heads, k=.5)}
+
+
+@pytest.mark.parametrize('F_,S,D,heads,dh,has_rv,ns,clamp,belief', [
+    (5, 9, 64, 2, 64, True, 1, 50., True),            # the dynamics trunk's form (value residual, one special token)
+    (3, 30, 128, 3, 32, False, 6, 50., True),         # first layer (no residual), tokenizer-encoder-like special block, heads not a multiple of 4
+    (4, 12, 64, 5, 16, True, 0, 2., False),           # tight soft clamp, no belief projection, no special tokens
+    (130, 15, 512, 8, 64, True, 1, 50., True),        # BASELINE cfg 2 geometry (15 tokens per frame, 8 x 64 heads)
+])
+def test_space_attention_forward_and_backward_vs_oracle_autograd(F_, S, D, heads, dh, has_rv, ns, clamp, belief):
+    g = torch.Generator().manual_seed(7)
+    W = _attn_params(D, heads, dh, g)
+    x = torch.randn(F_, S, D, generator=g) * 1.5
+    rv = torch.randn(F_, S, heads, dh, generator=g) if has_rv else None
+    dy = torch.randn(F_, S, D, generator=g)
+    Wd = {k: v.double().requires_grad_() for k, v in W.items()}
+    xd = x.double().requires_grad_()
+    rvd = rv.double().requires_grad_() if has_rv else None
+    mask = restate.special_token_mask(S, ns) if ns > 0 else None
+    ref, _ = restate.attention(Wd, '', xd, heads=heads, dim_head=dh, residual_values=rvd, softclamp_value=clamp, mask=mask, belief=belief)
+    ref.backward(dy.double())
+    Wg = {k: v.cuda().requires_grad_() for k, v in W.items()}
+    xg = x.cuda().requires_grad_()
+    rvg = rv.cuda().requires_grad_() if has_rv else None
+    y = trunk_ops.space_attention(xg, Wg['norm.weight'], Wg['to_q.weight'], Wg['to_k.weight'], Wg['to_v.weight'], Wg['to_out.weight'],
+                                  Wg['to_gates.0.weight'], Wg['k_heads_rmsnorm.gamma'], residual_values=rvg,
+                                  mix_weight=Wg['to_learned_value_residual_mix.0.weight'] if has_rv else None,
+                                  mix_bias=Wg['to_learned_value_residual_mix.0.bias'] if has_rv else None,
+                                  softclamp_value=clamp, num_special=ns, belief=belief)
+    close(y, ref, 'y')
+    y.backward(dy.cuda())
+    close(xg.grad, xd.grad, 'dx')
+    if has_rv:
+        close(rvg.grad, rvd.grad, 'd residual_values')
+    for k in W:
+        if 'value_residual_mix' in k and not has_rv:
+            continue
+        close(Wg[k].grad, Wd[k].grad, 'd ' + k)
+
+
+def test_blocks_compose_with_torch_autograd():
+    """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
+    g = torch.Generator().manual_seed(11)
+    D, heads, dh, inner = 64, 2, 32, 170
+    Wa, Wf = _attn_params(D, heads, dh, g), _ff_params(D, inner, g)
+    x = torch.randn(6, 10, D, generator=g)
+    rv = torch.randn(6, 10, heads, dh, generator=g)
+
+    def run(x, rv, Wa, Wf, dev):
+        if dev == 'cuda':
+            a = trunk_ops.space_attention(x, Wa['norm.weight'], Wa['to_q.weight'], Wa['to_k.weight'], Wa['to_v.weight'], Wa['to_out.weight'],
+                                          Wa['to_gates.0.weight'], Wa['k_heads_rmsnorm.gamma'], residual_values=rv,
+                                          mix_weight=Wa['to_learned_value_residual_mix.0.weight'], mix_bias=Wa['to_learned_value_residual_mix.0.bias'])
+            h = x + a
+            y = h + trunk_ops.feedforward(h, Wf['norm.weight'], Wf['proj_in.weight'], Wf['proj_in.bias'], Wf['proj_out.weight'], Wf['proj_out.bias'])
+        else:
+            a, _ = restate.attention(Wa, '', x, heads=heads, dim_head=dh, residual_values=rv, softclamp_value=50., mask=restate.special_token_mask(10, 1))
+            h = x + a
+            y = h + restate.feedforward(Wf, '', h)
+        return (y.tanh() ** 2).mean()
+
+    leaf = lambda t, dev: (t.double() if dev == 'cpu' else t.cuda()).requires_grad_()
+    outs = {}
+    for dev in ('cpu', 'cuda'):
+        xa, rva = leaf(x, dev), leaf(rv, dev)
+        Wal, Wfl = {k: leaf(v, dev) for k, v in Wa.items()}, {k: leaf(v, dev) for k, v in Wf.items()}
+        loss = run(xa, rva, Wal, Wfl, dev)
+        loss.backward()
+        outs[dev] = (loss, xa.grad, rva.grad, Wal, Wfl)
+    close(outs['cuda'][0], outs['cpu'][0], 'loss', tol=1e-5)
+    close(outs['cuda'][1], outs['cpu'][1], 'dx'); close(outs['cuda'][2], outs['cpu'][2], 'd rv')
+    for k in Wa:
+        close(outs['cuda'][3][k].grad, outs['cpu'][3][k].grad, 'attn d ' + k)
+    for k in Wf:
+        close(outs['cuda'][4][k].grad, outs['cpu'][4][k].grad, 'ff d ' + k)
+
+
+def test_argument_errors_are_loud():
+    from dreamer4_amd._lib import D4Error
+    W = _attn_params(64, 2, 64, torch.Generator().manual_seed(0))
+    Wg = {k: v.cuda() for k, v in W.items()}
+    with pytest.raises(D4Error, match='tokens per frame'):
+        trunk_ops.space_attention(torch.zeros(1, 40, 64, device='cuda'), Wg['norm.weight'], Wg['to_q.weight'], Wg['to_k.weight'], Wg['to_v.weight'],
+                                  Wg['to_out.weight'], Wg['to_gates.0.weight'], Wg['k_heads_rmsnorm.gamma'])
+    with pytest.raises(D4Error, match='no CPU fallback'):
+        trunk_ops.feedforward(torch.zeros(2, 64), *[v for v in _ff_params(64, 170, torch.Generator().manual_seed(0)).values()])
