@@ -94,8 +94,13 @@ struct AttnBwdArgs {
     float* dproj;                      // [F*S][ldp] out: gradients of the projections (same columns)
     float* d_rv;                       // [F*S][hd] out (when rv)
     float* dgamma_part;                // [F][hd] out: per-frame partial of d gamma
-    int F, S, heads, hp4;
+    int F, S, heads, hp4;              // F groups of S items
     float softclamp; int num_special, belief;
+    // row of item j of group g = (g / g_inner) * g_outer_stride + (g % g_inner) + j * item_stride:
+    //   within-frame attention: g_inner 1, g_outer_stride S, item_stride 1;  time attention over [B][T][S] rows: g_inner S, g_outer_stride T * S, item_stride S
+    int g_inner = 1; int64_t g_outer_stride = 0, item_stride = 1;
+    int causal = 0;                    // item i sees items j <= i
+    const float* inv_freq = nullptr;   // [DH / 2] rotary frequencies applied to q and k at position j (time attention), or null
 };
 
 constexpr int AB_S = 32, AB_LD = 65;
@@ -109,25 +114,45 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
     const int f = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool on = lane < DH;
-    const int64_t row0 = (int64_t)f * S;
+    const int64_t row0 = (int64_t)(f / p.g_inner) * p.g_outer_stride + (f % p.g_inner);
+    const int64_t ist = p.item_stride;
     const float sc = on ? (p.gamma[h * DH + lane] + 1.f) * sqrtf((float)DH) : 0.f;
     const float scale = rsqrtf((float)DH);
     const bool bwd = p.d_o3 != nullptr;
 
+    // rotary (D4:1626-1659): t * cos + rotate_half(t) * sin with rotate_half(t)[d] = d < DH/2 ? -t[d + DH/2] : t[d - DH/2]; the partner
+    // feature is lane ^ (DH/2).  rot_t is the transpose (backward): y * cos + rotate_half^T(y * sin), rotate_half^T(z)[d] = d < DH/2 ? z[d + DH/2] : -z[d - DH/2]
+    const float freq = (p.inv_freq && on) ? p.inv_freq[lane & (DH / 2 - 1)] : 0.f;
+    const bool lo_half = lane < DH / 2;
+    auto rot = [&](float t, int pos) {
+        if (!p.inv_freq) return t;
+        float sn, cs;
+        sincosf(freq * (float)pos, &sn, &cs);
+        const float partner = __shfl(t, lane ^ (DH / 2));
+        return on ? t * cs + (lo_half ? -partner : partner) * sn : 0.f;
+    };
+    auto rot_t = [&](float y, int pos) {
+        if (!p.inv_freq) return y;
+        float sn, cs;
+        sincosf(freq * (float)pos, &sn, &cs);
+        const float partner = __shfl(y * sn, lane ^ (DH / 2));
+        return on ? y * cs + (lo_half ? partner : -partner) : 0.f;
+    };
+
     // ---- phase A: per token j: value mix, key normalisation
     for (int j = w; j < S; j += 4) {
-        const float* pr = p.proj + (row0 + j) * p.ldp;
+        const float* pr = p.proj + (row0 + j * ist) * p.ldp;
         const float qv = on ? pr[h * DH + lane] : 0.f, kv = on ? pr[hd + h * DH + lane] : 0.f;
         float vv = on ? pr[2 * hd + h * DH + lane] : 0.f;
         float mx = 0.f;
         if (p.rv) {
             mx = sigm(pr[3 * hd + p.hp4 + h]);
-            const float r = on ? p.rv[(row0 + j) * hd + h * DH + lane] : 0.f;
+            const float r = on ? p.rv[(row0 + j * ist) * hd + h * DH + lane] : 0.f;
             vv = vv + mx * (r - vv);
         }
         const float ki = 1.f / fmaxf(sqrtf(wave_sum(kv * kv)), 1e-12f);
         const float vi = 1.f / fmaxf(sqrtf(wave_sum(vv * vv)), 1e-12f);
-        qs[j * AB_LD + lane] = qv; kh[j * AB_LD + lane] = kv * ki; kn[j * AB_LD + lane] = kv * ki * sc;
+        qs[j * AB_LD + lane] = rot(qv, j); kh[j * AB_LD + lane] = kv * ki; kn[j * AB_LD + lane] = rot(kv * ki * sc, j);
         vm[j * AB_LD + lane] = vv;
         if (lane == 0) { kinv[j] = ki; vinv[j] = vi; mxs[j] = mx; gts[j] = sigm(pr[3 * hd + h]); }
     }
@@ -144,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
         const float sim = dot * scale;
         float th = 0.f, simc = sim;
         if (p.softclamp > 0.f) { th = tanhf(sim / p.softclamp); simc = th * p.softclamp; }
-        const bool visible = lane < S && !(i < first_special && lane >= first_special);
+        const bool visible = lane < S && !(i < first_special && lane >= first_special) && !(p.causal && lane > i);
         simc = visible ? simc : -FLT_MAX;
         float m = simc;
 #pragma unroll
@@ -158,11 +183,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
         const float sdot = p.belief ? wave_sum(o * vni) : 0.f;
         const float o2 = o - sdot * vni;
         const float gt = gts[i];
-        if (on) p.o3[(row0 + i) * hd + h * DH + lane] = o2 * gt;
+        if (on) p.o3[(row0 + i * ist) * hd + h * DH + lane] = o2 * gt;
         if (!bwd) continue;
-        const float d3 = on ? p.d_o3[(row0 + i) * hd + h * DH + lane] : 0.f;
+        const float d3 = on ? p.d_o3[(row0 + i * ist) * hd + h * DH + lane] : 0.f;
         const float dgl = wave_sum(d3 * o2) * gt * (1.f - gt);
-        if (lane == 0) p.dproj[(row0 + i) * p.ldp + 3 * hd + h] = dgl;
+        if (lane == 0) p.dproj[(row0 + i * ist) * p.ldp + 3 * hd + h] = dgl;
         const float d2 = d3 * gt;
         float dOi = d2, dvdir = 0.f;
         if (p.belief) {
@@ -187,7 +212,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
         // dq_i = sum_j dsim_ij kn_j
         float dq = 0.f;
         for (int j = 0; j < S; ++j) dq += __shfl(dsim, j) * kn[j * AB_LD + lane];
-        if (on) p.dproj[(row0 + i) * p.ldp + h * DH + lane] = dq;
+        dq = rot_t(dq, i);
+        if (on) p.dproj[(row0 + i * ist) * p.ldp + h * DH + lane] = dq;
     }
     if (!bwd) return;
     __syncthreads();
@@ -200,19 +226,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
             dkn += dsm[i * (AB_S + 1) + j] * qs[i * AB_LD + lane];
             dv += P[i * (AB_S + 1) + j] * dO[i * AB_LD + lane];
         }
+        dkn = rot_t(dkn, j);
         const float khj = kh[j * AB_LD + lane];
         gacc += dkn * khj;
         const float dkh = dkn * sc;
         const float dk = (dkh - wave_sum(dkh * khj) * khj) * kinv[j];
-        float* dr = p.dproj + (row0 + j) * p.ldp;
+        float* dr = p.dproj + (row0 + j * ist) * p.ldp;
         if (on) dr[hd + h * DH + lane] = dk;
         if (p.rv) {
             const float mx = mxs[j];
-            const float* pr = p.proj + (row0 + j) * p.ldp;
+            const float* pr = p.proj + (row0 + j * ist) * p.ldp;
             const float vraw = on ? pr[2 * hd + h * DH + lane] : 0.f;
-            const float r = on ? p.rv[(row0 + j) * hd + h * DH + lane] : 0.f;
+            const float r = on ? p.rv[(row0 + j * ist) * hd + h * DH + lane] : 0.f;
             const float dmx = wave_sum(dv * (r - vraw));
-            if (on) { dr[2 * hd + h * DH + lane] = dv * (1.f - mx); p.d_rv[(row0 + j) * hd + h * DH + lane] = dv * mx; }
+            if (on) { dr[2 * hd + h * DH + lane] = dv * (1.f - mx); p.d_rv[(row0 + j * ist) * hd + h * DH + lane] = dv * mx; }
             if (lane == 0) dr[3 * hd + p.hp4 + h] = dmx * mx * (1.f - mx);
         } else {
             if (on) dr[2 * hd + h * DH + lane] = dv;
@@ -336,31 +363,101 @@ size_t d4_attn_workspace_bytes(int frames, int tokens, int dim, int heads, int d
     return attn_ws(nullptr, frames * tokens, frames, dim, heads, dim_head).total * sizeof(float);
 }
 
-static int attn_check(int frames, int tokens, int dim, int heads, int dim_head, const float* workspace, size_t workspace_bytes) {
-    D4_REQUIRE(tokens >= 1 && tokens <= AB_S, "space attention backward: %d tokens per frame (max %d)", tokens, AB_S);
-    D4_REQUIRE(dim_head == 16 || dim_head == 32 || dim_head == 64, "space attention backward: head dim %d (16, 32 or 64)", dim_head);
-    D4_REQUIRE(dim % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "space attention: dim must be a multiple of 4 and the workspace 256-byte aligned");
-    D4_REQUIRE(workspace_bytes >= d4_attn_workspace_bytes(frames, tokens, dim, heads, dim_head), "space attention: workspace too small");
+}  // extern "C"
+
+namespace {
+
+struct AttnGeom {                  // how the rows of x group into attention problems (see AttnBwdArgs)
+    int groups, items, g_inner; int64_t g_outer_stride, item_stride;
+    int causal, num_special; const float* inv_freq;
+};
+
+int attn_check(int rows, const AttnGeom& g, int dim, int heads, int dim_head, const float* workspace, size_t workspace_bytes) {
+    D4_REQUIRE(g.items >= 1 && g.items <= AB_S, "attention block: %d items per group (max %d)", g.items, AB_S);
+    D4_REQUIRE(dim_head == 16 || dim_head == 32 || dim_head == 64, "attention block: head dim %d (16, 32 or 64)", dim_head);
+    D4_REQUIRE(dim % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "attention block: dim must be a multiple of 4 and the workspace 256-byte aligned");
+    D4_REQUIRE(workspace_bytes >= attn_ws(nullptr, rows, g.groups, dim, heads, dim_head).total * sizeof(float), "attention block: workspace too small");
     return 0;
+}
+
+void set_geom(AttnBwdArgs& a, const AttnGeom& g) {
+    a.g_inner = g.g_inner; a.g_outer_stride = g.g_outer_stride; a.item_stride = g.item_stride; a.causal = g.causal; a.inv_freq = g.inv_freq;
+}
+
+int attn_block_forward(const float* x, const float* residual_values, const AttnParams& prm, int rows, const AttnGeom& g, int dim, int heads, int dim_head,
+                       float softclamp, int belief, float* y, float* workspace, size_t workspace_bytes, hipStream_t s) {
+    D4_REQUIRE(x && prm.norm_w && prm.wq && prm.wk && prm.wv && prm.wo && prm.wg && prm.gamma && y && workspace, "attention forward: null argument");
+    D4_REQUIRE(!residual_values || (prm.wm && prm.bm), "attention forward: residual values need the mix projection");
+    int rc;
+    if ((rc = attn_check(rows, g, dim, heads, dim_head, workspace, workspace_bytes))) return rc;
+    const int R = rows, hd = heads * dim_head;
+    if (R == 0) return 0;
+    const AttnWs w = attn_ws(workspace, R, g.groups, dim, heads, dim_head);
+    if ((rc = attn_project(w, x, prm, R, dim, heads, dim_head, residual_values != nullptr, s))) return rc;
+    AttnBwdArgs a{w.proj, w.P, residual_values, prm.gamma, nullptr, w.o3, nullptr, nullptr, nullptr, g.groups, g.items, heads, w.hp4, softclamp, g.num_special, belief};
+    set_geom(a, g);
+    if ((rc = attn_core(a, dim_head, s))) return rc;
+    return gemm_b(w.o3, hd, prm.wo, hd, y, dim, nullptr, R, dim, hd, 0, s);
+}
+
+struct AttnGrads { float *dx, *d_rv, *d_norm_w, *d_wq, *d_wk, *d_wv, *d_wo, *d_wg, *d_wm, *d_bm, *d_gamma; };
+
+int attn_block_backward(const float* x, const float* residual_values, const float* dy, const AttnParams& prm, int rows, const AttnGeom& g, int dim,
+                        int heads, int dim_head, float softclamp, int belief, const AttnGrads& o, float* workspace, size_t workspace_bytes, hipStream_t s) {
+    D4_REQUIRE(x && dy && prm.norm_w && prm.wq && prm.wk && prm.wv && prm.wo && prm.wg && prm.gamma && workspace, "attention backward: null argument");
+    D4_REQUIRE(o.dx && o.d_norm_w && o.d_wq && o.d_wk && o.d_wv && o.d_wo && o.d_wg && o.d_gamma, "attention backward: null gradient output");
+    D4_REQUIRE(!residual_values || (prm.wm && prm.bm && o.d_rv && o.d_wm && o.d_bm), "attention backward: residual values need the mix projection and its gradients");
+    int rc;
+    if ((rc = attn_check(rows, g, dim, heads, dim_head, workspace, workspace_bytes))) return rc;
+    D4_REQUIRE(rows >= 1, "attention backward: no rows");
+    const int R = rows, D = dim, hd = heads * dim_head;
+    const bool has_rv = residual_values != nullptr;
+    const AttnWs w = attn_ws(workspace, R, g.groups, D, heads, dim_head);
+    if ((rc = attn_project(w, x, prm, R, D, heads, dim_head, has_rv, s))) return rc;
+    // out = o3 Wo^T
+    if ((rc = gemm_b(dy, D, prm.wo, hd, w.d_o3, hd, nullptr, R, hd, D, GEMM_TRANS_B, s))) return rc;                    // d_o3 = dy Wo
+    AttnBwdArgs a{w.proj, w.P, residual_values, prm.gamma, w.d_o3, w.o3, w.dproj, o.d_rv, w.gpart, g.groups, g.items, heads, w.hp4, softclamp, g.num_special, belief};
+    set_geom(a, g);
+    if ((rc = attn_core(a, dim_head, s))) return rc;
+    if (w.hp4 > heads) {           // the pad columns of the gate / mix logits carry no gradient
+        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + heads, 3 * hd + w.hp4);
+        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
+        D4_LAUNCH_CHECK();
+    }
+    if ((rc = gemm_b(dy, D, w.o3, hd, o.d_wo, hd, nullptr, D, hd, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;        // dWo = dy^T o3
+    if ((rc = colsum(w.gpart, hd, g.groups, hd, o.d_gamma, s))) return rc;
+    // projections: dW = dproj^T xn, dxn = dproj Wcat
+    if ((rc = gemm_b(w.dproj, w.P, w.xn, D, w.dwcat, D, nullptr, w.P, D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    const size_t blk = sizeof(float) * (size_t)hd * D;
+    D4_HIP(hipMemcpyAsync(o.d_wq, w.dwcat, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(o.d_wk, w.dwcat + (size_t)hd * D, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(o.d_wv, w.dwcat + (size_t)2 * hd * D, blk, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(o.d_wg, w.dwcat + (size_t)3 * hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+    if (has_rv) {
+        D4_HIP(hipMemcpyAsync(o.d_wm, w.dwcat + (size_t)(3 * hd + w.hp4) * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+        if ((rc = colsum(w.dproj + 3 * hd + w.hp4, w.P, R, heads, o.d_bm, s))) return rc;
+    }
+    if ((rc = gemm_b(w.dproj, w.P, w.wcat, D, w.dxn, D, nullptr, R, D, w.P, GEMM_TRANS_B, s))) return rc;
+    if ((rc = rmsnorm_bwd(x, w.dxn, prm.norm_w, w.tg, o.dx, R, D, RMS_EPS, s))) return rc;
+    return colsum(w.tg, D, R, D, o.d_norm_w, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t d4_time_attn_workspace_bytes(int batch, int frames, int tokens, int dim, int heads, int dim_head) {
+    return attn_ws(nullptr, batch * frames * tokens, batch * tokens, dim, heads, dim_head).total * sizeof(float);
 }
 
 int d4_space_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
                           const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
                           int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
                           float* y, float* workspace, size_t workspace_bytes, void* stream) {
-    D4_REQUIRE(x && norm_w && wq && wk && wv && wo && w_gates && k_gamma && y && workspace, "d4_space_attn_forward: null argument");
-    D4_REQUIRE(!residual_values || (w_mix && b_mix), "d4_space_attn_forward: residual values need the mix projection");
-    int rc;
-    if ((rc = attn_check(frames, tokens, dim, heads, dim_head, workspace, workspace_bytes))) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int R = frames * tokens, hd = heads * dim_head;
-    if (R == 0) return 0;
-    const AttnWs w = attn_ws(workspace, R, frames, dim, heads, dim_head);
     const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
-    if ((rc = attn_project(w, x, prm, R, dim, heads, dim_head, residual_values != nullptr, s))) return rc;
-    AttnBwdArgs a{w.proj, w.P, residual_values, k_gamma, nullptr, w.o3, nullptr, nullptr, nullptr, frames, tokens, heads, w.hp4, softclamp, num_special, belief};
-    if ((rc = attn_core(a, dim_head, s))) return rc;
-    return gemm_b(w.o3, hd, wo, hd, y, dim, nullptr, R, dim, hd, 0, s);
+    const AttnGeom g{frames, tokens, 1, tokens, 1, 0, num_special, nullptr};
+    return attn_block_forward(x, residual_values, prm, frames * tokens, g, dim, heads, dim_head, softclamp, belief, y, workspace, workspace_bytes,
+                              static_cast<hipStream_t>(stream));
 }
 
 int d4_space_attn_backward(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
@@ -369,43 +466,36 @@ int d4_space_attn_backward(const float* x, const float* residual_values, const f
                            float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
                            float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
                            float* workspace, size_t workspace_bytes, void* stream) {
-    D4_REQUIRE(x && dy && norm_w && wq && wk && wv && wo && w_gates && k_gamma && workspace, "d4_space_attn_backward: null argument");
-    D4_REQUIRE(dx && d_norm_w && d_wq && d_wk && d_wv && d_wo && d_w_gates && d_k_gamma, "d4_space_attn_backward: null gradient output");
-    D4_REQUIRE(!residual_values || (w_mix && b_mix && d_residual_values && d_w_mix && d_b_mix), "d4_space_attn_backward: residual values need the mix projection and its gradients");
-    int rc;
-    if ((rc = attn_check(frames, tokens, dim, heads, dim_head, workspace, workspace_bytes))) return rc;
-    D4_REQUIRE(frames >= 1, "d4_space_attn_backward: no frames");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int R = frames * tokens, D = dim, hd = heads * dim_head;
-    const bool has_rv = residual_values != nullptr;
-    const AttnWs w = attn_ws(workspace, R, frames, D, heads, dim_head);
     const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
-    if ((rc = attn_project(w, x, prm, R, D, heads, dim_head, has_rv, s))) return rc;
-    // out = o3 Wo^T
-    if ((rc = gemm_b(dy, D, wo, hd, w.d_o3, hd, nullptr, R, hd, D, GEMM_TRANS_B, s))) return rc;                        // d_o3 = dy Wo
-    AttnBwdArgs a{w.proj, w.P, residual_values, k_gamma, w.d_o3, w.o3, w.dproj, d_residual_values, w.gpart, frames, tokens, heads, w.hp4, softclamp, num_special, belief};
-    if ((rc = attn_core(a, dim_head, s))) return rc;
-    if (w.hp4 > heads) {           // the pad columns of the gate / mix logits carry no gradient
-        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + heads, 3 * hd + w.hp4);
-        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
-        D4_LAUNCH_CHECK();
-    }
-    if ((rc = gemm_b(dy, D, w.o3, hd, d_wo, hd, nullptr, D, hd, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;          // dWo = dy^T o3
-    if ((rc = colsum(w.gpart, hd, frames, hd, d_k_gamma, s))) return rc;
-    // projections: dW = dproj^T xn, dxn = dproj Wcat
-    if ((rc = gemm_b(w.dproj, w.P, w.xn, D, w.dwcat, D, nullptr, w.P, D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
-    const size_t blk = sizeof(float) * (size_t)hd * D;
-    D4_HIP(hipMemcpyAsync(d_wq, w.dwcat, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(d_wk, w.dwcat + (size_t)hd * D, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(d_wv, w.dwcat + (size_t)2 * hd * D, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(d_w_gates, w.dwcat + (size_t)3 * hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
-    if (has_rv) {
-        D4_HIP(hipMemcpyAsync(d_w_mix, w.dwcat + (size_t)(3 * hd + w.hp4) * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
-        if ((rc = colsum(w.dproj + 3 * hd + w.hp4, w.P, R, heads, d_b_mix, s))) return rc;
-    }
-    if ((rc = gemm_b(w.dproj, w.P, w.wcat, D, w.dxn, D, nullptr, R, D, w.P, GEMM_TRANS_B, s))) return rc;
-    if ((rc = rmsnorm_bwd(x, w.dxn, norm_w, w.tg, dx, R, D, RMS_EPS, s))) return rc;
-    return colsum(w.tg, D, R, D, d_norm_w, s);
+    const AttnGeom g{frames, tokens, 1, tokens, 1, 0, num_special, nullptr};
+    const AttnGrads o{dx, d_residual_values, d_norm_w, d_wq, d_wk, d_wv, d_wo, d_w_gates, d_w_mix, d_b_mix, d_k_gamma};
+    return attn_block_backward(x, residual_values, dy, prm, frames * tokens, g, dim, heads, dim_head, softclamp, belief, o, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream));
+}
+
+int d4_time_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
+                         const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma, const float* inv_freq,
+                         int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
+                         float* y, float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(inv_freq, "d4_time_attn_forward: null rotary frequencies");
+    const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
+    const AttnGeom g{batch * tokens, frames, tokens, (int64_t)frames * tokens, tokens, 1, 0, inv_freq};
+    return attn_block_forward(x, residual_values, prm, batch * frames * tokens, g, dim, heads, dim_head, softclamp, belief, y, workspace, workspace_bytes,
+                              static_cast<hipStream_t>(stream));
+}
+
+int d4_time_attn_backward(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                          const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                          const float* inv_freq, int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
+                          float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                          float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                          float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(inv_freq, "d4_time_attn_backward: null rotary frequencies");
+    const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
+    const AttnGeom g{batch * tokens, frames, tokens, (int64_t)frames * tokens, tokens, 1, 0, inv_freq};
+    const AttnGrads o{dx, d_residual_values, d_norm_w, d_wq, d_wk, d_wv, d_wo, d_w_gates, d_w_mix, d_b_mix, d_k_gamma};
+    return attn_block_backward(x, residual_values, dy, prm, batch * frames * tokens, g, dim, heads, dim_head, softclamp, belief, o, workspace,
+                               workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

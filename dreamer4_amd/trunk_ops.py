@@ -122,3 +122,52 @@ def space_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma,
     but the first); `num_special` trailing tokens are hidden from ordinary queries (dreamer4.py:1769-1783)."""
     return _SpaceAttention.apply(x, residual_values, norm_weight, to_q, to_k, to_v, to_out, to_gates, mix_weight, mix_bias, k_gamma,
                                  softclamp_value, num_special, belief)
+
+
+class _TimeAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, belief):
+        x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq = _prep(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq)
+        assert x.ndim == 4, 'x must be (batch, frames, tokens, dim)'
+        B, T, S, D = x.shape
+        heads, dh = gamma.shape
+        assert wq.shape == (heads * dh, D) and wo.shape == (D, heads * dh) and wg.shape == (heads, D) and inv_freq.shape == (dh // 2,)
+        assert rv is None or rv.shape == (B, T, S, heads, dh)
+        lib = _lib.load()
+        nbytes = lib.d4_time_attn_workspace_bytes(B, T, S, D, heads, dh)
+        ws, wp = _workspace(nbytes, x.device)
+        y = torch.empty_like(x)
+        _lib.check(lib.d4_time_attn_forward(_lib.ptr(x), _lib.ptr(rv), _lib.ptr(norm_w), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(wo),
+                                            _lib.ptr(wg), _lib.ptr(wm), _lib.ptr(bm), _lib.ptr(gamma), _lib.ptr(inv_freq), B, T, S, D, heads, dh,
+                                            float(softclamp or 0.), int(bool(belief)), _lib.ptr(y), wp, nbytes, _stream(x)))
+        ctx.save_for_backward(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq)
+        ctx.cfg = (float(softclamp or 0.), int(bool(belief)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq = ctx.saved_tensors
+        (dy,) = _prep(dy)
+        B, T, S, D = x.shape
+        heads, dh = gamma.shape
+        lib = _lib.load()
+        nbytes = lib.d4_time_attn_workspace_bytes(B, T, S, D, heads, dh)
+        ws, wp = _workspace(nbytes, x.device)
+        e = torch.empty_like
+        dx, dn, dq, dk, dv, do, dg, dgam = e(x), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
+        drv, dwm, dbm = (e(rv), e(wm), e(bm)) if rv is not None else (None, None, None)
+        _lib.check(lib.d4_time_attn_backward(
+            _lib.ptr(x), _lib.ptr(rv), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(wo), _lib.ptr(wg),
+            _lib.ptr(wm), _lib.ptr(bm), _lib.ptr(gamma), _lib.ptr(inv_freq), B, T, S, D, heads, dh, *ctx.cfg,
+            _lib.ptr(dx), _lib.ptr(drv), _lib.ptr(dn), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(do), _lib.ptr(dg), _lib.ptr(dwm), _lib.ptr(dbm),
+            _lib.ptr(dgam), wp, nbytes, _stream(x)))
+        return dx, drv, dn, dq, dk, dv, do, dg, dwm, dbm, dgam, None, None, None
+
+
+def time_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma, inv_freq, *, residual_values=None, mix_weight=None,
+                   mix_bias=None, softclamp_value=50., belief=True):
+    """The trunk's time layers (dreamer4.py:3176-3215): causal attention along time for every token column, rotary positions
+    (`inv_freq` = time_rotary.inv_freq), no KV cache (the training form).  x (batch, frames, tokens, dim), frames <= 32;
+    `residual_values` (batch, frames, tokens, heads, dim_head)."""
+    return _TimeAttention.apply(x, residual_values, norm_weight, to_q, to_k, to_v, to_out, to_gates, mix_weight, mix_bias, k_gamma, inv_freq,
+                                softclamp_value, belief)

@@ -274,6 +274,20 @@ int d4_space_attn_backward(const float* x, const float* residual_values, const f
                            float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
                            float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
                            float* workspace, size_t workspace_bytes, void* stream);
+/* Time attention block (the same Attention with rotary positions and a causal mask along time, one problem per token column,
+ * dreamer4.py:3176-3215 / 1626-1659): x / y [batch][frames][tokens][dim] row-major, frames <= 32 (no KV cache: the training form);
+ * inv_freq [dim_head / 2] = time_rotary.inv_freq. */
+size_t d4_time_attn_workspace_bytes(int batch, int frames, int tokens, int dim, int heads, int dim_head);
+int d4_time_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
+                         const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma, const float* inv_freq,
+                         int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
+                         float* y, float* workspace, size_t workspace_bytes, void* stream);
+int d4_time_attn_backward(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                          const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                          const float* inv_freq, int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
+                          float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                          float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                          float* workspace, size_t workspace_bytes, void* stream);
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
                float eps, void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,

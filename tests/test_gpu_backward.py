@@ -90,6 +90,42 @@ def test_space_attention_forward_and_backward_vs_oracle_autograd(F_, S, D, heads
         close(Wg[k].grad, Wd[k].grad, 'd ' + k)
 
 
+@pytest.mark.parametrize('B,T,S,D,heads,dh,has_rv,clamp', [(2, 7, 5, 64, 2, 64, True, 50.), (1, 32, 3, 64, 3, 32, False, 50.), (3, 16, 15, 128, 2, 16, True, 3.)])
+def test_time_attention_forward_and_backward_vs_oracle_autograd(B, T, S, D, heads, dh, has_rv, clamp):
+    from einops import rearrange
+    g = torch.Generator().manual_seed(9)
+    W = _attn_params(D, heads, dh, g)
+    x = torch.randn(B, T, S, D, generator=g) * 1.5
+    rv = torch.randn(B, T, S, heads, dh, generator=g) if has_rv else None
+    dy = torch.randn(B, T, S, D, generator=g)
+    inv_freq = 1.0 / (10000. ** (torch.arange(0, dh, 2).float() / dh))
+    Wd = {k: v.double().requires_grad_() for k, v in W.items()}
+    xd = x.double().requires_grad_()
+    rvd = rv.double().requires_grad_() if has_rv else None
+    # the reference runs the time layers on 'b t s d -> (b s) t d' (dreamer4.py:3178), causal, rotary positions 0..T-1
+    rot = restate.rotary_freqs(restate.Config(dim=D, dim_latent=4, num_latent_tokens=1, attn_dim_head=dh), T, 0, inv_freq.double())
+    ref, _ = restate.attention(Wd, '', rearrange(xd, 'b t s d -> (b s) t d'), heads=heads, dim_head=dh, rot=rot, causal=True,
+                               residual_values=rearrange(rvd, 'b t s h d -> (b s) t h d') if has_rv else None, softclamp_value=clamp)
+    ref = rearrange(ref, '(b s) t d -> b t s d', b=B)
+    ref.backward(dy.double())
+    Wg = {k: v.cuda().requires_grad_() for k, v in W.items()}
+    xg = x.cuda().requires_grad_()
+    rvg = rv.cuda().requires_grad_() if has_rv else None
+    y = trunk_ops.time_attention(xg, Wg['norm.weight'], Wg['to_q.weight'], Wg['to_k.weight'], Wg['to_v.weight'], Wg['to_out.weight'],
+                                 Wg['to_gates.0.weight'], Wg['k_heads_rmsnorm.gamma'], inv_freq.cuda(), residual_values=rvg,
+                                 mix_weight=Wg['to_learned_value_residual_mix.0.weight'] if has_rv else None,
+                                 mix_bias=Wg['to_learned_value_residual_mix.0.bias'] if has_rv else None, softclamp_value=clamp)
+    close(y, ref, 'y')
+    y.backward(dy.cuda())
+    close(xg.grad, xd.grad, 'dx')
+    if has_rv:
+        close(rvg.grad, rvd.grad, 'd residual_values')
+    for k in W:
+        if 'value_residual_mix' in k and not has_rv:
+            continue
+        close(Wg[k].grad, Wd[k].grad, 'd ' + k)
+
+
 def test_blocks_compose_with_torch_autograd():
     """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
     g = torch.Generator().manual_seed(11)
@@ -131,7 +167,7 @@ def test_argument_errors_are_loud():
     from dreamer4_amd._lib import D4Error
     W = _attn_params(64, 2, 64, torch.Generator().manual_seed(0))
     Wg = {k: v.cuda() for k, v in W.items()}
-    with pytest.raises(D4Error, match='tokens per frame'):
+    with pytest.raises(D4Error, match='items per group'):
         trunk_ops.space_attention(torch.zeros(1, 40, 64, device='cuda'), Wg['norm.weight'], Wg['to_q.weight'], Wg['to_k.weight'], Wg['to_v.weight'],
                                   Wg['to_out.weight'], Wg['to_gates.0.weight'], Wg['k_heads_rmsnorm.gamma'])
     with pytest.raises(D4Error, match='no CPU fallback'):
