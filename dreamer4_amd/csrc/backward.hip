@@ -260,6 +260,140 @@ static int attn_core(const AttnBwdArgs& a, int dh, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ cross-attention core
+// The trunk's cross attentions (D4:1968-2075 with a context): the AttentionPool over the stack of layer hiddens (one query per token,
+// D4:2143-2177), the final special-token cross attention (D4:3227-3234) and the learned-query pools (D4:2179-2210).  No value residual,
+// no belief projection (the reference skips it when a context is given), optional soft clamp.  One block per (group, head); up to 64
+// queries and 64 keys in (dynamic) LDS.  projq rows: q @ 0, gate logit @ hd + head; projk rows: k @ 0, v @ hd.
+struct XAttnArgs {
+    const float* projq; int ldq;       // [G * nq][ldq], row g * nq + i
+    const float* projk; int ldk;       // key j of group g: row g * nk + j (group major) or j * G + g (item major: the stack of hiddens)
+    const float* gamma;
+    const float* d_o3;                 // [G * nq][hd] or null (forward only)
+    float* o3;                         // [G * nq][hd]
+    float* dprojq; float* dprojk;      // gradients, same layouts
+    float* dgamma_part;                // [G][hd]
+    int G, nq, nk, heads, item_major;
+    float softclamp;
+};
+
+constexpr int XA_N = 64;
+template <int DH>
+__global__ __launch_bounds__(256) void xattn_bwd_kernel(XAttnArgs p) {
+    extern __shared__ float xa_s[];
+    const int nq = p.nq, nk = p.nk, hd = p.heads * DH;
+    float* kn = xa_s;                           // [nk][65]
+    float* kh = kn + nk * AB_LD;
+    float* vs = kh + nk * AB_LD;
+    float* qs = vs + nk * AB_LD;                // [nq][65]
+    float* dO = qs + nq * AB_LD;
+    float* P = dO + nq * AB_LD;                 // [nq][65]
+    float* dsm = P + nq * AB_LD;
+    float* kinv = dsm + nq * AB_LD;             // [nk]
+    float* gts = kinv + nk;                     // [nq]
+    float* gpart = gts + nq;                    // [4][64]
+    const int g = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool on = lane < DH;
+    const float sc = on ? (p.gamma[h * DH + lane] + 1.f) * sqrtf((float)DH) : 0.f;
+    const float scale = rsqrtf((float)DH);
+    const bool bwd = p.d_o3 != nullptr;
+    auto krow = [&](int j) { return p.item_major ? (int64_t)j * p.G + g : (int64_t)g * nk + j; };
+
+    for (int j = w; j < nk; j += 4) {
+        const float* pr = p.projk + krow(j) * p.ldk;
+        const float kv = on ? pr[h * DH + lane] : 0.f, vv = on ? pr[hd + h * DH + lane] : 0.f;
+        const float ki = 1.f / fmaxf(sqrtf(wave_sum(kv * kv)), 1e-12f);
+        kh[j * AB_LD + lane] = kv * ki; kn[j * AB_LD + lane] = kv * ki * sc; vs[j * AB_LD + lane] = vv;
+        if (lane == 0) kinv[j] = ki;
+    }
+    for (int i = w; i < nq; i += 4) {
+        const float* pr = p.projq + ((int64_t)g * nq + i) * p.ldq;
+        qs[i * AB_LD + lane] = on ? pr[h * DH + lane] : 0.f;
+        if (lane == 0) gts[i] = sigm(pr[hd + h]);
+    }
+    __syncthreads();
+
+    for (int i = w; i < nq; i += 4) {
+        const int64_t qrow = (int64_t)g * nq + i;
+        float dot = 0.f;
+        if (lane < nk) {
+#pragma unroll 8
+            for (int d = 0; d < DH; ++d) dot += qs[i * AB_LD + d] * kn[lane * AB_LD + d];
+        }
+        const float sim = dot * scale;
+        float th = 0.f, simc = sim;
+        if (p.softclamp > 0.f) { th = tanhf(sim / p.softclamp); simc = th * p.softclamp; }
+        simc = lane < nk ? simc : -FLT_MAX;
+        float m = simc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e = lane < nk ? expf(simc - m) : 0.f;
+        const float pij = e / wave_sum(e);
+        float o = 0.f;
+        for (int j = 0; j < nk; ++j) o += __shfl(pij, j) * vs[j * AB_LD + lane];
+        const float gt = gts[i];
+        if (on) p.o3[qrow * hd + h * DH + lane] = o * gt;
+        if (!bwd) continue;
+        const float d3 = on ? p.d_o3[qrow * hd + h * DH + lane] : 0.f;
+        const float dgl = wave_sum(d3 * o) * gt * (1.f - gt);
+        if (lane == 0) p.dprojq[qrow * p.ldq + hd + h] = dgl;
+        const float dOi = d3 * gt;
+        dO[i * AB_LD + lane] = dOi;
+        float dp = 0.f;
+        if (lane < nk) {
+#pragma unroll 8
+            for (int d = 0; d < DH; ++d) dp += dO[i * AB_LD + d] * vs[lane * AB_LD + d];
+        }
+        const float rowdot = wave_sum(pij * dp);
+        float dsim = pij * (dp - rowdot);
+        if (p.softclamp > 0.f) dsim *= 1.f - th * th;
+        dsim *= scale;
+        if (lane < nk) { P[i * AB_LD + lane] = pij; dsm[i * AB_LD + lane] = dsim; }
+        float dq = 0.f;
+        for (int j = 0; j < nk; ++j) dq += __shfl(dsim, j) * kn[j * AB_LD + lane];
+        if (on) p.dprojq[qrow * p.ldq + h * DH + lane] = dq;
+    }
+    if (!bwd) return;
+    __syncthreads();
+
+    float gacc = 0.f;
+    for (int j = w; j < nk; j += 4) {
+        float dkn = 0.f, dv = 0.f;
+        for (int i = 0; i < nq; ++i) {
+            dkn += dsm[i * AB_LD + j] * qs[i * AB_LD + lane];
+            dv += P[i * AB_LD + j] * dO[i * AB_LD + lane];
+        }
+        const float khj = kh[j * AB_LD + lane];
+        gacc += dkn * khj;
+        const float dkh = dkn * sc;
+        const float dk = (dkh - wave_sum(dkh * khj) * khj) * kinv[j];
+        float* dr = p.dprojk + krow(j) * p.ldk;
+        if (on) { dr[h * DH + lane] = dk; dr[hd + h * DH + lane] = dv; }
+    }
+    gpart[w * 64 + lane] = gacc;
+    __syncthreads();
+    if (w == 0 && on) p.dgamma_part[(int64_t)g * hd + h * DH + lane] = (((gpart[lane] + gpart[64 + lane]) + gpart[128 + lane]) + gpart[192 + lane]) * sqrtf((float)DH);
+}
+
+static int xattn_core(const XAttnArgs& a, int dh, hipStream_t s) {
+    if (a.G * a.heads == 0) return 0;
+    const size_t lds = sizeof(float) * ((size_t)(3 * a.nk + 4 * a.nq) * AB_LD + a.nk + a.nq + 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int mx = (int)(sizeof(float) * ((size_t)7 * XA_N * AB_LD + 2 * XA_N + 256));
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+        attr_set = true;
+    }
+    if (dh == 64) hipLaunchKernelGGL(xattn_bwd_kernel<64>, dim3(a.G * a.heads), dim3(256), lds, s, a);
+    else if (dh == 32) hipLaunchKernelGGL(xattn_bwd_kernel<32>, dim3(a.G * a.heads), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(xattn_bwd_kernel<16>, dim3(a.G * a.heads), dim3(256), lds, s, a);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void zero_pad_cols_kernel(float* x, int rows, int ld, int c0, int c1) {
     const int n = c1 - c0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * n; i += (int64_t)gridDim.x * blockDim.x)
@@ -442,9 +576,117 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
     return colsum(w.tg, D, R, D, o.d_norm_w, s);
 }
 
+struct XWs {
+    float *qn, *cn, *wqg, *wkv, *projq, *projk, *dprojq, *dprojk, *d_o3, *o3, *dwqg, *dwkv, *tg, *dqn, *tgc, *dcn, *gpart;
+    size_t total; int Pq, Pk, hp4;
+};
+XWs x_ws(float* base, int Rq, int Rk, int G, int D, int Dc, int heads, int dh) {
+    XWs w{};
+    const int hd = heads * dh;
+    w.hp4 = (heads + 3) / 4 * 4; w.Pq = hd + w.hp4; w.Pk = 2 * hd;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
+    w.qn = take((size_t)Rq * D); w.cn = take((size_t)Rk * Dc); w.wqg = take((size_t)w.Pq * D); w.wkv = take((size_t)w.Pk * Dc);
+    w.projq = take((size_t)Rq * w.Pq); w.projk = take((size_t)Rk * w.Pk); w.dprojq = take((size_t)Rq * w.Pq); w.dprojk = take((size_t)Rk * w.Pk);
+    w.d_o3 = take((size_t)Rq * hd); w.o3 = take((size_t)Rq * hd); w.dwqg = take((size_t)w.Pq * D); w.dwkv = take((size_t)w.Pk * Dc);
+    w.tg = take((size_t)Rq * D); w.dqn = take((size_t)Rq * D); w.tgc = take((size_t)Rk * Dc); w.dcn = take((size_t)Rk * Dc); w.gpart = take((size_t)G * hd);
+    w.total = off;
+    return w;
+}
+
+struct XParams { const float *norm_w, *norm_ctx_w, *wq, *wk, *wv, *wo, *wg, *gamma; };
+
+int x_project(const XWs& w, const float* q_tokens, const float* ctx, const XParams& prm, int Rq, int Rk, int D, int Dc, int heads, int dh, hipStream_t s) {
+    const int hd = heads * dh;
+    int rc;
+    D4_HIP(hipMemsetAsync(w.wqg, 0, sizeof(float) * (size_t)w.Pq * D, s));
+    D4_HIP(hipMemcpyAsync(w.wqg, prm.wq, sizeof(float) * (size_t)hd * D, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.wqg + (size_t)hd * D, prm.wg, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.wkv, prm.wk, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(w.wkv + (size_t)hd * Dc, prm.wv, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
+    if ((rc = rmsnorm_rows(q_tokens, D, prm.norm_w, w.qn, D, Rq, D, RMS_EPS, s))) return rc;
+    if (prm.norm_ctx_w) { if ((rc = rmsnorm_rows(ctx, Dc, prm.norm_ctx_w, w.cn, Dc, Rk, Dc, RMS_EPS, s))) return rc; }
+    else if ((rc = copy_rows(ctx, Dc, w.cn, Dc, Rk, Dc, s))) return rc;
+    if ((rc = gemm_b(w.qn, D, w.wqg, D, w.projq, w.Pq, nullptr, Rq, w.Pq, D, 0, s))) return rc;
+    return gemm_b(w.cn, Dc, w.wkv, Dc, w.projk, w.Pk, nullptr, Rk, w.Pk, Dc, 0, s);
+}
+
+int x_check(int G, int nq, int nk, int D, int Dc, int heads, int dh, const float* workspace, size_t workspace_bytes) {
+    D4_REQUIRE(nq >= 1 && nq <= XA_N && nk >= 1 && nk <= XA_N, "cross attention block: %d queries / %d keys per group (max %d)", nq, nk, XA_N);
+    D4_REQUIRE(dh == 16 || dh == 32 || dh == 64, "cross attention block: head dim %d (16, 32 or 64)", dh);
+    D4_REQUIRE(D % 4 == 0 && Dc % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "cross attention block: dims must be multiples of 4 and the workspace 256-byte aligned");
+    D4_REQUIRE(workspace_bytes >= x_ws(nullptr, G * nq, G * nk, G, D, Dc, heads, dh).total * sizeof(float), "cross attention block: workspace too small");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t d4_cross_attn_workspace_bytes(int groups, int nq, int nk, int dim, int dim_ctx, int heads, int dim_head) {
+    return x_ws(nullptr, groups * nq, groups * nk, groups, dim, dim_ctx, heads, dim_head).total * sizeof(float);
+}
+
+int d4_cross_attn_forward(const float* q_tokens, const float* ctx, const float* norm_w, const float* norm_ctx_w, const float* wq, const float* wk,
+                          const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk, int ctx_item_major,
+                          int dim, int dim_ctx, int heads, int dim_head, float softclamp, float* y, float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(q_tokens && ctx && norm_w && wq && wk && wv && wo && w_gates && k_gamma && y && workspace, "d4_cross_attn_forward: null argument");
+    int rc;
+    if ((rc = x_check(groups, nq, nk, dim, dim_ctx, heads, dim_head, workspace, workspace_bytes))) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Rq = groups * nq, Rk = groups * nk, hd = heads * dim_head;
+    if (Rq == 0) return 0;
+    const XWs w = x_ws(workspace, Rq, Rk, groups, dim, dim_ctx, heads, dim_head);
+    const XParams prm{norm_w, norm_ctx_w, wq, wk, wv, wo, w_gates, k_gamma};
+    if ((rc = x_project(w, q_tokens, ctx, prm, Rq, Rk, dim, dim_ctx, heads, dim_head, s))) return rc;
+    XAttnArgs a{w.projq, w.Pq, w.projk, w.Pk, k_gamma, nullptr, w.o3, nullptr, nullptr, nullptr, groups, nq, nk, heads, ctx_item_major, softclamp};
+    if ((rc = xattn_core(a, dim_head, s))) return rc;
+    return gemm_b(w.o3, hd, wo, hd, y, dim, nullptr, Rq, dim, hd, 0, s);
+}
+
+int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,
+                           const float* wk, const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk,
+                           int ctx_item_major, int dim, int dim_ctx, int heads, int dim_head, float softclamp,
+                           float* d_q_tokens, float* d_ctx, float* d_norm_w, float* d_norm_ctx_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_k_gamma, float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(q_tokens && ctx && dy && norm_w && wq && wk && wv && wo && w_gates && k_gamma && workspace, "d4_cross_attn_backward: null argument");
+    D4_REQUIRE(d_q_tokens && d_ctx && d_norm_w && d_wq && d_wk && d_wv && d_wo && d_w_gates && d_k_gamma && (!norm_ctx_w || d_norm_ctx_w),
+               "d4_cross_attn_backward: null gradient output");
+    int rc;
+    if ((rc = x_check(groups, nq, nk, dim, dim_ctx, heads, dim_head, workspace, workspace_bytes))) return rc;
+    D4_REQUIRE(groups >= 1, "d4_cross_attn_backward: no groups");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Rq = groups * nq, Rk = groups * nk, D = dim, Dc = dim_ctx, hd = heads * dim_head;
+    const XWs w = x_ws(workspace, Rq, Rk, groups, D, Dc, heads, dim_head);
+    const XParams prm{norm_w, norm_ctx_w, wq, wk, wv, wo, w_gates, k_gamma};
+    if ((rc = x_project(w, q_tokens, ctx, prm, Rq, Rk, D, Dc, heads, dim_head, s))) return rc;
+    if ((rc = gemm_b(dy, D, wo, hd, w.d_o3, hd, nullptr, Rq, hd, D, GEMM_TRANS_B, s))) return rc;
+    XAttnArgs a{w.projq, w.Pq, w.projk, w.Pk, k_gamma, w.d_o3, w.o3, w.dprojq, w.dprojk, w.gpart, groups, nq, nk, heads, ctx_item_major, softclamp};
+    if ((rc = xattn_core(a, dim_head, s))) return rc;
+    if (w.hp4 > heads) {
+        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)Rq * (w.hp4 - heads)), dim3(256), 0, s, w.dprojq, Rq, w.Pq, hd + heads, w.Pq);
+        D4_LAUNCH_CHECK();
+    }
+    if ((rc = gemm_b(dy, D, w.o3, hd, d_wo, hd, nullptr, D, hd, Rq, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    if ((rc = colsum(w.gpart, hd, groups, hd, d_k_gamma, s))) return rc;
+    // query side
+    if ((rc = gemm_b(w.dprojq, w.Pq, w.qn, D, w.dwqg, D, nullptr, w.Pq, D, Rq, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    D4_HIP(hipMemcpyAsync(d_wq, w.dwqg, sizeof(float) * (size_t)hd * D, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(d_w_gates, w.dwqg + (size_t)hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+    if ((rc = gemm_b(w.dprojq, w.Pq, w.wqg, D, w.dqn, D, nullptr, Rq, D, w.Pq, GEMM_TRANS_B, s))) return rc;
+    if ((rc = rmsnorm_bwd(q_tokens, w.dqn, norm_w, w.tg, d_q_tokens, Rq, D, RMS_EPS, s))) return rc;
+    if ((rc = colsum(w.tg, D, Rq, D, d_norm_w, s))) return rc;
+    // context side
+    if ((rc = gemm_b(w.dprojk, w.Pk, w.cn, Dc, w.dwkv, Dc, nullptr, w.Pk, Dc, Rk, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    D4_HIP(hipMemcpyAsync(d_wk, w.dwkv, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
+    D4_HIP(hipMemcpyAsync(d_wv, w.dwkv + (size_t)hd * Dc, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
+    if (norm_ctx_w) {
+        if ((rc = gemm_b(w.dprojk, w.Pk, w.wkv, Dc, w.dcn, Dc, nullptr, Rk, Dc, w.Pk, GEMM_TRANS_B, s))) return rc;
+        if ((rc = rmsnorm_bwd(ctx, w.dcn, norm_ctx_w, w.tgc, d_ctx, Rk, Dc, RMS_EPS, s))) return rc;
+        return colsum(w.tgc, Dc, Rk, Dc, d_norm_ctx_w, s);
+    }
+    return gemm_b(w.dprojk, w.Pk, w.wkv, Dc, d_ctx, Dc, nullptr, Rk, Dc, w.Pk, GEMM_TRANS_B, s);
+}
 
 size_t d4_time_attn_workspace_bytes(int batch, int frames, int tokens, int dim, int heads, int dim_head) {
     return attn_ws(nullptr, batch * frames * tokens, batch * tokens, dim, heads, dim_head).total * sizeof(float);

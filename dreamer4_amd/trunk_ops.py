@@ -171,3 +171,117 @@ def time_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma, 
     `residual_values` (batch, frames, tokens, heads, dim_head)."""
     return _TimeAttention.apply(x, residual_values, norm_weight, to_q, to_k, to_v, to_out, to_gates, mix_weight, mix_bias, k_gamma, inv_freq,
                                 softclamp_value, belief)
+
+
+class _CrossAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma, item_major, softclamp):
+        q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma = _prep(q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma)
+        assert q_tokens.ndim == 3 and context.ndim == 3
+        G, nq, D = q_tokens.shape
+        nk, Dc = (context.shape[0], context.shape[2]) if item_major else (context.shape[1], context.shape[2])
+        assert (context.shape[1] if item_major else context.shape[0]) == G, 'context groups do not match the queries'
+        heads, dh = gamma.shape
+        assert wq.shape == (heads * dh, D) and wk.shape == (heads * dh, Dc) and wv.shape == (heads * dh, Dc) and wo.shape == (D, heads * dh)
+        lib = _lib.load()
+        nbytes = lib.d4_cross_attn_workspace_bytes(G, nq, nk, D, Dc, heads, dh)
+        ws, wp = _workspace(nbytes, q_tokens.device)
+        y = torch.empty_like(q_tokens)
+        _lib.check(lib.d4_cross_attn_forward(_lib.ptr(q_tokens), _lib.ptr(context), _lib.ptr(norm_w), _lib.ptr(norm_ctx_w), _lib.ptr(wq), _lib.ptr(wk),
+                                             _lib.ptr(wv), _lib.ptr(wo), _lib.ptr(wg), _lib.ptr(gamma), G, nq, nk, int(bool(item_major)), D, Dc, heads, dh,
+                                             float(softclamp or 0.), _lib.ptr(y), wp, nbytes, _stream(q_tokens)))
+        ctx_.save_for_backward(q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma)
+        ctx_.cfg = (G, nq, nk, int(bool(item_major)), D, Dc, heads, dh, float(softclamp or 0.))
+        return y
+
+    @staticmethod
+    def backward(ctx_, dy):
+        q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma = ctx_.saved_tensors
+        (dy,) = _prep(dy)
+        G, nq, nk, item_major, D, Dc, heads, dh, softclamp = ctx_.cfg
+        lib = _lib.load()
+        nbytes = lib.d4_cross_attn_workspace_bytes(G, nq, nk, D, Dc, heads, dh)
+        ws, wp = _workspace(nbytes, q_tokens.device)
+        e = torch.empty_like
+        dq_t, dc, dn, dq, dk, dv, do, dg, dgam = e(q_tokens), e(context), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
+        dnc = e(norm_ctx_w) if norm_ctx_w is not None else None
+        _lib.check(lib.d4_cross_attn_backward(
+            _lib.ptr(q_tokens), _lib.ptr(context), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(norm_ctx_w), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv),
+            _lib.ptr(wo), _lib.ptr(wg), _lib.ptr(gamma), G, nq, nk, item_major, D, Dc, heads, dh, softclamp,
+            _lib.ptr(dq_t), _lib.ptr(dc), _lib.ptr(dn), _lib.ptr(dnc), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(do), _lib.ptr(dg), _lib.ptr(dgam),
+            wp, nbytes, _stream(q_tokens)))
+        return dq_t, dc, dn, dnc, dq, dk, dv, do, dg, dgam, None, None
+
+
+def cross_attention(q_tokens, context, norm_weight, norm_context_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma, *,
+                    context_item_major=False, softclamp_value=None):
+    """Attention.forward with a context (dreamer4.py:1968-2075): q_tokens (groups, nq, dim); context (groups, nk, dim_ctx), or
+    (nk, groups, dim_ctx) with `context_item_major` (the stack of layer hiddens of the AttentionPool).  nq, nk <= 64."""
+    return _CrossAttention.apply(q_tokens, context, norm_weight, norm_context_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma,
+                                 context_item_major, softclamp_value)
+
+
+# ------------------------------------------------------------------------------------------------ the trunk, composed
+def _attn_w(W, pre):
+    return (W[pre + 'norm.weight'], W[pre + 'to_q.weight'], W[pre + 'to_k.weight'], W[pre + 'to_v.weight'], W[pre + 'to_out.weight'],
+            W[pre + 'to_gates.0.weight'], W[pre + 'k_heads_rmsnorm.gamma'])
+
+
+def _ff(W, pre, x):
+    return feedforward(x, W[pre + 'norm.weight'], W[pre + 'proj_in.weight'], W[pre + 'proj_in.bias'], W[pre + 'proj_out.weight'], W[pre + 'proj_out.bias'])
+
+
+def _pool(W, pre, x, hiddens):
+    """Residual(AttentionPool) (dreamer4.py:2143-2177 + 1869): one query per token over the stack of layer hiddens."""
+    shape = x.shape
+    ctx = torch.stack([h.reshape(-1, shape[-1]) for h in hiddens], dim=0)                 # (L, rows, D): item major
+    p = pre + 'fn.attn.'
+    nw, wq, wk, wv, wo, wg, gam = _attn_w(W, p)
+    out = cross_attention(x.reshape(-1, 1, shape[-1]), ctx, nw, W[p + 'norm_context.weight'], wq, wk, wv, wo, wg, gam, context_item_major=True)
+    return x + out.reshape(shape)
+
+
+def transformer(W, tokens, *, is_time, softclamp_value=50., num_special=1, pre='transformer.'):
+    """AxialSpaceTimeTransformer.forward (dreamer4.py:2927-3267, defaults: value residual, attention pools, final special cross
+    attention; final RMSNorm when the weights hold one) for training: no KV cache, every block a HIP forward + backward operator;
+    only the residual adds, reshapes and the two bare RMSNorm + Linear pieces (value residual projection, final norm) are torch ops.
+    W: the reference's trunk parameters by state_dict key (with the prefix `pre`); tokens (batch, frames, tokens, dim); is_time: per
+    layer.  Differentiable with respect to tokens and every parameter."""
+    from torch.nn import functional as F
+    b, t, s, d = tokens.shape
+    gamma0 = W[pre + 'layers.0.2.fn.k_heads_rmsnorm.gamma']
+    h, dh = gamma0.shape
+    eps = torch.finfo(torch.float32).eps
+    vres = F.linear(F.rms_norm(tokens, (d,), W[pre + 'to_value_residual.0.weight'], eps), W[pre + 'to_value_residual.1.weight'])
+    vres = vres.reshape(b, t, s, h, dh)
+    hiddens = [tokens]
+    depth = len(is_time)
+    for i, tl in enumerate(is_time):
+        ap = f'{pre}layers.{i}.2.fn.'
+        nw, wq, wk, wv, wo, wg, gam = _attn_w(W, ap)
+        mw, mb = W[ap + 'to_learned_value_residual_mix.0.weight'], W[ap + 'to_learned_value_residual_mix.0.bias']
+        if tl:
+            out = time_attention(tokens, nw, wq, wk, wv, wo, wg, gam, W[pre + 'time_rotary.inv_freq'], residual_values=vres, mix_weight=mw,
+                                 mix_bias=mb, softclamp_value=softclamp_value)
+        else:
+            out = space_attention(tokens.reshape(b * t, s, d), nw, wq, wk, wv, wo, wg, gam, residual_values=vres.reshape(b * t, s, h, dh),
+                                  mix_weight=mw, mix_bias=mb, softclamp_value=softclamp_value, num_special=num_special).reshape(b, t, s, d)
+        tokens = tokens + out
+        hiddens.append(tokens)
+        tokens = tokens + _ff(W, f'{pre}layers.{i}.3.fn.', tokens)
+        hiddens.append(tokens)
+        if i != depth - 1:
+            tokens = _pool(W, f'{pre}attn_pools.{i}.', tokens, hiddens)
+    # the special tokens cross-attend the ordinary tokens of their frame, then their own feedforward   dreamer4.py:3227-3238
+    non_special, special = tokens[:, :, :-num_special], tokens[:, :, -num_special:]
+    cp = pre + 'final_special_cross_attn.fn.'
+    nw, wq, wk, wv, wo, wg, gam = _attn_w(W, cp)
+    out = cross_attention(special.reshape(b * t, num_special, d), non_special.reshape(b * t, s - num_special, d), nw, W[cp + 'norm_context.weight'],
+                          wq, wk, wv, wo, wg, gam)
+    special = special + out.reshape(b, t, num_special, d)
+    special = special + _ff(W, pre + 'final_special_ff.fn.', special)
+    tokens = torch.cat((non_special, special), dim=2)
+    tokens = _pool(W, pre + 'final_attn_pool.', tokens, hiddens)
+    if pre + 'final_norm.weight' in W:
+        tokens = F.rms_norm(tokens, (d,), W[pre + 'final_norm.weight'], eps)
+    return tokens

@@ -288,6 +288,19 @@ int d4_time_attn_backward(const float* x, const float* residual_values, const fl
                           float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
                           float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
                           float* workspace, size_t workspace_bytes, void* stream);
+/* Cross-attention block (Attention.forward with a context: the AttentionPool over the layer hiddens dreamer4.py:2143-2177, the final
+ * special-token cross attention :3227-3234, the learned-query pools :2179-2210): q_tokens [groups*nq][dim], ctx [groups*nk][dim_ctx] with key
+ * j of group g at row g*nk + j, or at row j*groups + g when ctx_item_major (the stack of hiddens); norm_ctx_w may be null (context not
+ * normalised); wk / wv [heads*dim_head][dim_ctx]; nq, nk <= 64.  No value residual and no belief projection (as the reference with a context). */
+size_t d4_cross_attn_workspace_bytes(int groups, int nq, int nk, int dim, int dim_ctx, int heads, int dim_head);
+int d4_cross_attn_forward(const float* q_tokens, const float* ctx, const float* norm_w, const float* norm_ctx_w, const float* wq, const float* wk,
+                          const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk, int ctx_item_major,
+                          int dim, int dim_ctx, int heads, int dim_head, float softclamp, float* y, float* workspace, size_t workspace_bytes, void* stream);
+int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,
+                           const float* wk, const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk,
+                           int ctx_item_major, int dim, int dim_ctx, int heads, int dim_head, float softclamp,
+                           float* d_q_tokens, float* d_ctx, float* d_norm_w, float* d_norm_ctx_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_k_gamma, float* workspace, size_t workspace_bytes, void* stream);
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
                float eps, void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,

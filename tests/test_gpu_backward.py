@@ -126,6 +126,78 @@ def test_time_attention_forward_and_backward_vs_oracle_autograd(B, T, S, D, head
         close(Wg[k].grad, Wd[k].grad, 'd ' + k)
 
 
+@pytest.mark.parametrize('G,nq,nk,D,Dc,heads,dh,item_major,ctx_norm,clamp', [
+    (37, 1, 7, 64, 64, 4, 64, True, True, None),          # AttentionPool: one query per token row over the stack of 7 hiddens
+    (6, 3, 20, 64, 64, 2, 32, False, True, None),         # special tokens over the ordinary tokens of their frame
+    (5, 4, 64, 128, 8, 3, 16, False, True, 5.),           # learned-query pool shape: 64 keys of a narrow context, soft clamp
+    (9, 64, 5, 64, 32, 2, 64, False, False, None),        # many queries, context not normalised
+])
+def test_cross_attention_forward_and_backward_vs_oracle_autograd(G, nq, nk, D, Dc, heads, dh, item_major, ctx_norm, clamp):
+    g = torch.Generator().manual_seed(13)
+    r = lambda *s_, k=1.: torch.randn(*s_, generator=g) * k
+    hd = heads * dh
+    W = {'norm.weight': 1. + r(D, k=.1), 'norm_context.weight': 1. + r(Dc, k=.1), 'to_q.weight': r(hd, D, k=3. * D ** -.5), 'to_k.weight': r(hd, Dc, k=Dc ** -.5),
+         'to_v.weight': r(hd, Dc, k=Dc ** -.5), 'to_out.weight': r(D, hd, k=hd ** -.5), 'to_gates.0.weight': r(heads, D, k=D ** -.5),
+         'k_heads_rmsnorm.gamma': r(heads, dh, k=.3)}
+    q = r(G, nq, D, k=1.5)
+    c = r(G, nk, Dc, k=1.5)
+    dy = r(G, nq, D)
+    Wd = {k: v.double().requires_grad_() for k, v in W.items()}
+    qd, cd = q.double().requires_grad_(), c.double().requires_grad_()
+    ref, _ = restate.attention(Wd, '', qd, heads=heads, dim_head=dh, context=cd, belief=True, has_ctx_norm=ctx_norm, softclamp_value=clamp)
+    ref.backward(dy.double())
+    Wg = {k: v.cuda().requires_grad_() for k, v in W.items()}
+    qg = q.cuda().requires_grad_()
+    cg = c.cuda().requires_grad_()
+    cin = cg.transpose(0, 1).contiguous() if item_major else cg            # (nk, G, Dc) for the stack-of-hiddens layout
+    y = trunk_ops.cross_attention(qg, cin, Wg['norm.weight'], Wg['norm_context.weight'] if ctx_norm else None, Wg['to_q.weight'], Wg['to_k.weight'],
+                                  Wg['to_v.weight'], Wg['to_out.weight'], Wg['to_gates.0.weight'], Wg['k_heads_rmsnorm.gamma'],
+                                  context_item_major=item_major, softclamp_value=clamp)
+    close(y, ref, 'y')
+    y.backward(dy.cuda())
+    close(qg.grad, qd.grad, 'dq_tokens'); close(cg.grad, cd.grad, 'dcontext')
+    for k in W:
+        if k == 'norm_context.weight' and not ctx_norm:
+            continue
+        close(Wg[k].grad, Wd[k].grad, 'd ' + k)
+
+
+@pytest.mark.parametrize('kw,b,t', [(dict(dim=64, dim_latent=8, num_latent_tokens=4, depth=4, time_block_every=2, attn_heads=2, attn_dim_head=32, num_discrete_actions=4), 2, 5),
+                                    (dict(dim=128, dim_latent=16, num_latent_tokens=8, num_spatial_tokens=4, depth=5, time_block_every=4, attn_heads=2, attn_dim_head=64,
+                                          num_discrete_actions=4), 3, 4)])
+def test_trunk_forward_and_backward_vs_oracle_autograd(kw, b, t):
+    """The whole AxialSpaceTimeTransformer (dreamer4.py:2927-3267) as a composition of the HIP forward + backward blocks, against float64
+    autograd of the oracle's `transformer`: output, d tokens and the gradient of every trunk parameter."""
+    from dreamer4_amd import DynamicsWorldModel
+    from util import oracle_config, randomize_weights
+    torch.manual_seed(1)
+    m = randomize_weights(DynamicsWorldModel(**kw))
+    cfg = oracle_config(m)
+    W = {k: v.detach().clone() for k, v in m.state_dict().items() if k.startswith('transformer.')}
+    s = 1 + cfg.num_spatial_tokens + cfg.num_register_tokens + 1 + 1            # flow | spatial | registers | action | agent
+    g = torch.Generator().manual_seed(2)
+    tokens = torch.randn(b, t, s, cfg.dim, generator=g)
+    dy = torch.randn(b, t, s, cfg.dim, generator=g)
+    isf = lambda k: W[k].is_floating_point() and 'inv_freq' not in k
+    Wd = {k: (v.double().requires_grad_() if isf(k) else v.double()) for k, v in W.items()}
+    xd = tokens.double().requires_grad_()
+    ref, _ = restate.transformer(cfg, Wd, xd)
+    ref.backward(dy.double())
+    Wg = {k: (v.cuda().requires_grad_() if isf(k) else v.cuda()) for k, v in W.items()}
+    xg = tokens.cuda().requires_grad_()
+    y = trunk_ops.transformer(Wg, xg, is_time=cfg.is_time, softclamp_value=cfg.attn_softclamp_value)
+    close(y, ref, 'trunk output')
+    y.backward(dy.cuda())
+    close(xg.grad, xd.grad, 'd tokens', tol=5e-4)
+    checked = 0
+    for k in W:
+        if isf(k) and Wd[k].grad is not None:
+            assert Wg[k].grad is not None, k
+            close(Wg[k].grad, Wd[k].grad, 'd ' + k, tol=5e-4)
+            checked += 1
+    assert checked >= 20 * cfg.depth
+
+
 def test_blocks_compose_with_torch_autograd():
     """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
     g = torch.Generator().manual_seed(11)
