@@ -285,3 +285,94 @@ def transformer(W, tokens, *, is_time, softclamp_value=50., num_special=1, pre='
     if pre + 'final_norm.weight' in W:
         tokens = F.rms_norm(tokens, (d,), W[pre + 'final_norm.weight'], eps)
     return tokens
+
+
+# ------------------------------------------------------------------------------------------------ the dynamics model, training form
+def _lq_pool(W, pre, x):
+    """LearnedQueriesAttentionPool (dreamer4.py:2179-2210): x (..., n, d_ctx) -> (..., num_queries, dim)."""
+    lead = x.shape[:-2]
+    ctx = x.reshape(-1, *x.shape[-2:])
+    queries = W[pre + 'queries']
+    q = queries[None].expand(ctx.shape[0], -1, -1)
+    p = pre + 'attn.'
+    nw, wq, wk, wv, wo, wg, gam = _attn_w(W, p)
+    out = cross_attention(q, ctx, nw, W[p + 'norm_context.weight'], wq, wk, wv, wo, wg, gam)
+    return out.reshape(*lead, *out.shape[-2:])
+
+
+def world_model_prediction(W, noised_latents, signal_levels, step_sizes_log2, *, is_time, num_spatial_tokens, num_register_tokens,
+                           num_discrete_actions=(), discrete_actions=None, continuous_actions=None, tasks=None, softclamp_value=50.):
+    """DynamicsWorldModel's `get_prediction` (dreamer4.py:7156-7287) for training: noised latents (b, t, n, dl), signal_levels (b, t),
+    step_sizes_log2 (b,) -> (latent prediction (b, t, n, dl), agent embedding (b, t, dim)).  Token packing, embeddings and the bare
+    RMSNorm + Linear of the latent head are torch ops; the trunk and the learned-query pools are the HIP forward + backward blocks.
+    W: the model's parameters by reference state_dict key.  Actions are the ones paired with each frame's NEXT transition
+    (`shift_action_tokens=True`): (b, t, na) or (b, t-1, na); frame 0 gets a zero action token."""
+    from torch.nn import functional as F
+    b, t, n, dl = noised_latents.shape
+    d = W['signal_levels_embed.weight'].shape[1] * 2
+    eps = torch.finfo(torch.float32).eps
+    dev = noised_latents.device
+    has_actions = 'action_learned_embed' in W and (len(num_discrete_actions) > 0 or W.get('action_embedder.continuous_action_embed.weight', torch.empty(0)).numel() > 0)
+    if num_spatial_tokens == n:
+        space = F.linear(noised_latents, W['latents_to_spatial_tokens.weight'], W['latents_to_spatial_tokens.bias'])
+    else:
+        space = _lq_pool(W, 'latents_to_spatial_tokens.', noised_latents)
+    sig = W['signal_levels_embed.weight'][signal_levels]
+    stp = W['step_size_embed.weight'][step_sizes_log2][:, None].expand(b, t, -1)
+    flow_tok = torch.cat((sig, stp), dim=-1)[:, :, None]
+    regs = W['register_tokens'].expand(b, t, -1, -1) if num_register_tokens > 0 else noised_latents.new_zeros(b, t, 0, d)
+    agent = W['agent_learned_embed'].expand(b, -1, -1)
+    if tasks is not None:
+        agent = agent + W['task_embed.weight'][tasks][:, None]
+    agent = agent[:, None].expand(b, t, -1, -1)
+    parts = [flow_tok, space, regs]
+    if has_actions:
+        emb = None
+        if discrete_actions is not None and discrete_actions.shape[1] > 0:
+            offs = torch.tensor([0, *torch.tensor(num_discrete_actions).cumsum(0)[:-1].tolist()], device=dev)
+            emb = W['action_embedder.discrete_action_embed.weight'][discrete_actions + offs].sum(dim=-2)
+        if continuous_actions is not None and continuous_actions.shape[1] > 0:
+            c = (W['action_embedder.continuous_action_embed.weight'] * continuous_actions[..., None]).sum(dim=-2)
+            emb = c if emb is None else emb + c
+        if emb is None:
+            act = noised_latents.new_zeros(b, t, d)
+        else:
+            emb = emb + W['action_learned_embed']
+            if emb.shape[1] == t:
+                emb = emb[:, :-1]
+            act = F.pad(emb, (0, 0, 1, 0), value=0.)
+        parts.append(act[:, :, None])
+    parts.append(agent)
+    tokens = transformer(W, torch.cat(parts, dim=2), is_time=is_time, softclamp_value=softclamp_value)
+    space_out, agent_embed = tokens[:, :, 1:1 + num_spatial_tokens], tokens[:, :, -1]
+    x = F.rms_norm(space_out, (d,), W['to_latent_pred.0.weight'], eps)
+    if num_spatial_tokens != n:
+        x = _lq_pool(W, 'to_latent_pred.1.', x)
+    return F.linear(x, W['to_latent_pred.2.weight']), agent_embed
+
+
+def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, *, max_steps, **model):
+    """The flow and shortcut-consistency losses of the dynamics training forward (dreamer4.py:6990-7003, 7335-7431; x-space prediction,
+    ramp loss weight, no proprio / variable lengths / loss normalisers: the reference defaults).  `model`: the keyword arguments of
+    `world_model_prediction`.  Returns (flow_loss, shortcut_loss); backward runs through the HIP blocks."""
+    from torch.nn import functional as F
+    times = signal_levels.float() / max_steps
+    tt = times[:, :, None, None]
+    noised = noise.lerp(latents, tt)
+    pred, _ = world_model_prediction(W, noised, signal_levels, step_sizes_log2, **model)
+    flow_losses = F.mse_loss(pred, latents, reduction='none') * (0.9 * times + 0.1)[:, :, None, None]
+    if not shortcut_train:
+        return flow_losses.mean(), latents.new_zeros(())
+    with torch.no_grad():
+        half_log2 = step_sizes_log2 - 1
+        half = 2 ** half_log2
+        first, _ = world_model_prediction(W, noised, signal_levels, half_log2, **model)
+        first_flow = (first - noised) / (1. - tt)
+        denoised = noised + first_flow * (half[:, None, None, None] / max_steps)
+        sig2 = signal_levels + half[:, None]
+        second, _ = world_model_prediction(W, denoised, sig2, half_log2, **model)
+        second_flow = (second - denoised) / (1. - (sig2.float() / max_steps)[:, :, None, None])
+        target = (first_flow + second_flow) / 2
+    shortcut_pred = (pred - noised) / (1. - tt)
+    shortcut_losses = F.mse_loss(shortcut_pred, target, reduction='none') * (1. - tt) ** 2
+    return flow_losses.mean(), shortcut_losses.mean()

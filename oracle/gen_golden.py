@@ -28,6 +28,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
                    losses and gradients) and a continuous-only one (weights_contonly.npz: tempered rollout, env-wrapper chained calls)
   symexp.npz       reward_encoder_type='symexp_two_hot' (weights_symexp.npz): rollout, ppo losses and gradients
   encode.npz       VideoTokenizer.tokenize of reference tokenizers (weights_encode*.npz = the encoder half) + generate(prompt=video)
+  train.npz        flow + shortcut losses of the dynamics training forward and their gradients (weights_train.npz)
   decode.npz       VideoTokenizer.decode of a reference tokenizer (weights_decode.npz = the decoder half of its state_dict): two flow steps
 """
 from __future__ import annotations
@@ -392,6 +393,59 @@ def gen_encode():
           'wide', out['wide_latents'].shape, float(out['wide_latents'].std()), 'prompt margin', out['prompt_margin'], 'lens', out['prompt_lens'])
 
 
+CFG_TRAIN = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=3, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                 num_discrete_actions=(4,), num_tasks=0, reward_num_bins=11, value_num_bins=11, multi_token_pred_len=1, max_steps=16)
+
+
+def gen_train():
+    """train.npz / weights_train.npz: the flow and shortcut losses of DynamicsWorldModel.forward in training (D4:6956-7003, 7335-7431)
+    and the gradient of (flow + shortcut) with respect to every parameter on that path; the model's own random draws (shortcut coin,
+    step sizes, signal levels, noise — D4:6965-6977, 7000) are recorded as they are made, under `seed=`.  One shortcut batch, one plain
+    flow batch."""
+    D4 = load_reference()
+    cfg = Config(**CFG_TRAIN)
+    m = build_reference_model(cfg, seed=71)
+    W = weights_of(m)
+    save_weights('weights_train.npz', W, CFG_TRAIN)
+    g = torch.Generator().manual_seed(72)
+    B, T = 3, 4
+    lat = torch.randn(B, T, 6, 8, generator=g).clamp(-2, 2)
+    acts = torch.randint(0, 4, (B, T, 1), generator=g)
+    out = dict(latents=npy(lat), actions=npy(acts))
+    for name, prob in (('shortcut', 1.), ('plain', 0.)):
+        rec = {}
+        saved = (D4.randint, D4.randn_like, D4.sample_prob)
+
+        def rec_randint(*a, **k):
+            r = saved[0](*a, **k); rec.setdefault('randint', []).append(r.clone()); return r
+
+        def rec_randn_like(*a, **k):
+            r = saved[1](*a, **k); rec.setdefault('randn_like', []).append(r.clone()); return r
+
+        D4.randint, D4.randn_like = rec_randint, rec_randn_like
+        m.prob_shortcut_train = prob
+        try:
+            m.zero_grad()
+            total, losses = m(latents=lat, discrete_actions=acts, seed=5, return_all_losses=True, add_autoregressive_action_loss=False)
+        finally:
+            D4.randint, D4.randn_like, D4.sample_prob = saved
+        (losses.flow + losses.shortcut).backward()
+        if prob == 1.:
+            step_log2, sig_raw = rec['randint']
+            sig = sig_raw // (2 ** step_log2)[:, None] * (2 ** step_log2)[:, None]
+        else:
+            step_log2, sig = torch.zeros(B, dtype=torch.long), rec['randint'][0]
+        noise = rec['randn_like'][0][:, :, 0]                  # (b t 1 n d) -> (b t n d)
+        out[f'{name}_step_sizes_log2'], out[f'{name}_signal_levels'], out[f'{name}_noise'] = npy(step_log2), npy(sig), npy(noise)
+        out[f'{name}_flow_loss'], out[f'{name}_shortcut_loss'] = npy(losses.flow), npy(losses.shortcut)
+        ng = 0
+        for k, p in m.named_parameters():
+            if p.grad is not None and p.numel() > 0 and float(p.grad.abs().max()) > 0:
+                out[f'{name}_grad/{k}'] = npy(p.grad); ng += 1
+        print(name, 'flow', float(losses.flow), 'shortcut', float(losses.shortcut), 'step_log2', step_log2.tolist(), 'grads', ng)
+    np.savez(os.path.join(OUT, 'train.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+
+
 CFG_SYMEXP = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
                   num_discrete_actions=(4,), num_tasks=0, reward_num_bins=41, value_num_bins=31, reward_range=(-3., 3.), value_range=(-4., 4.),
                   multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1, reward_encoder_type='symexp_two_hot')
@@ -418,7 +472,7 @@ def gen_symexp():
     print('symexp margin', out['cached_margin'], 'lens', out['cached_lens'], 'values', out['cached_values'][0])
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode)
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train)
 
 
 def main():

@@ -366,7 +366,8 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
     """DynamicsWorldModel.forward(latent_is_noised=True, return_pred_only=True,
     return_intermediates=True)  D4:6792-7295.
 
-    latents (b, t, n, dl); signal_levels (b, t) int64; step_size python int (power of two).
+    latents (b, t, n, dl); signal_levels (b, t) int64; step_size python int (power of two), or an int64 tensor (b,) of
+    step_sizes_log2 (the training branch samples one per trajectory).
     Returns pred (b, t', n, dl), agent_embed (b, t', d), new cache, where t' = 1 when a
     non-empty cache was supplied (only the last frame is evaluated — per-frame modules are
     independent across frames, D4:7168/7251, so the dropped frames are never consumed)."""
@@ -383,9 +384,11 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
         space = latents @ W['latents_to_spatial_tokens.weight'].t() + W['latents_to_spatial_tokens.bias']
     else:
         space = lq_attn_pool(cfg, W, 'latents_to_spatial_tokens.', latents)         # b t ns d
-    step_log2 = int(math.log2(step_size))
     sig = W['signal_levels_embed.weight'][signal_levels]                             # b t d/2
-    stp = W['step_size_embed.weight'][step_log2].expand(b, t, -1)
+    if torch.is_tensor(step_size):                                                   # training: step_sizes_log2 (b,) per trajectory  D4:7183-7184
+        stp = W['step_size_embed.weight'][step_size][:, None].expand(b, t, -1)
+    else:
+        stp = W['step_size_embed.weight'][int(math.log2(step_size))].expand(b, t, -1)
     flow_tok = torch.cat((sig, stp), dim=-1)[:, :, None]
     regs = (W['register_tokens'] if cfg.num_register_tokens > 0 else latents.new_zeros(0, d)).expand(b, t, -1, -1)
     agent = W['agent_learned_embed'].expand(b, -1, -1)                               # b 1 d
@@ -410,6 +413,40 @@ def wm_forward(cfg: Config, W, latents, signal_levels, step_size, actions=None, 
         x = lq_attn_pool(cfg, W, 'to_latent_pred.1.', x)
     pred = x @ W['to_latent_pred.2.weight'].t()
     return pred, agent_embed, new_cache
+
+
+# ----------------------------------------------------------------------------- dynamics training losses (flow + shortcut)
+
+def ramp_weight(times, slope=0.9, intercept=0.1):
+    return slope * times + intercept                                                 # D4:897-899, eq. (8)
+
+
+def dynamics_flow_losses(cfg: Config, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=None, tasks=None,
+                         cont_actions=None):
+    """The flow and shortcut-consistency losses of DynamicsWorldModel.forward in training (D4:6990-7003, 7335-7431; x-space prediction,
+    the default `pred_orig_latent=True`; no proprio, no variable lengths, no loss normalisers — the dynamics model's defaults).
+    latents (b, t, n, dl) data, noise the same shape, signal_levels (b, t), step_sizes_log2 (b,) int64, shortcut_train: the coin of
+    D4:6965.  Returns (flow_loss, shortcut_loss)."""
+    times = signal_levels.float() / cfg.max_steps                                    # D4:5413
+    tt = times[:, :, None, None]
+    noised = noise.lerp(latents, tt)                                                 # D4:7003
+    pred = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks, cont_actions=cont_actions)[0]
+    flow_losses = F.mse_loss(pred, latents, reduction='none') * ramp_weight(times)[:, :, None, None]      # D4:7350, 7410-7414
+    if not shortcut_train:
+        return flow_losses.mean(), latents.new_zeros(())
+    with torch.no_grad():                                                            # D4:7313, 7356-7388
+        half_log2 = step_sizes_log2 - 1
+        half = 2 ** half_log2
+        first = wm_forward(cfg, W, noised, signal_levels, half_log2, actions=actions, tasks=tasks, cont_actions=cont_actions)[0]
+        first_flow = (first - noised) / (1. - tt)
+        denoised = noised + first_flow * (half[:, None, None, None] / cfg.max_steps)
+        sig2 = signal_levels + half[:, None]
+        second = wm_forward(cfg, W, denoised, sig2, half_log2, actions=actions, tasks=tasks, cont_actions=cont_actions)[0]
+        second_flow = (second - denoised) / (1. - (sig2.float() / cfg.max_steps)[:, :, None, None])
+        target = (first_flow + second_flow) / 2
+    shortcut_pred = (pred - noised) / (1. - tt)                                      # D4:7397-7398
+    shortcut_losses = F.mse_loss(shortcut_pred, target, reduction='none') * (1. - tt) ** 2
+    return flow_losses.mean(), shortcut_losses.mean()
 
 
 # ----------------------------------------------------------------------------- heads

@@ -198,6 +198,29 @@ def test_trunk_forward_and_backward_vs_oracle_autograd(kw, b, t):
     assert checked >= 20 * cfg.depth
 
 
+@pytest.mark.parametrize('name', ['shortcut', 'plain'])
+def test_dynamics_flow_and_shortcut_losses_vs_reference_fixture(name):
+    """train.npz (frozen from the reference's training forward under its own recorded draws): flow + shortcut losses through the HIP
+    trunk, and the gradient of their sum with respect to every parameter on the path."""
+    from util import golden_oracle, load_golden, t
+    g = load_golden('train.npz')
+    cfg, W = golden_oracle('weights_train.npz')
+    keys = [k[len(name) + 6:] for k in g if k.startswith(name + '_grad/')]
+    Wg = {k: (v.cuda().requires_grad_() if k in keys else v.cuda()) for k, v in W.items()}
+    cu = lambda a: t(a).cuda()
+    fl, sl = trunk_ops.dynamics_flow_losses(
+        Wg, cu(g['latents']), cu(g[name + '_noise']), cu(g[name + '_signal_levels']), cu(g[name + '_step_sizes_log2']), name == 'shortcut',
+        max_steps=cfg.max_steps, is_time=cfg.is_time, num_spatial_tokens=cfg.num_spatial_tokens, num_register_tokens=cfg.num_register_tokens,
+        num_discrete_actions=cfg.num_discrete_actions, discrete_actions=cu(g['actions']), softclamp_value=cfg.attn_softclamp_value)
+    close(fl, t(g[name + '_flow_loss']), 'flow loss', tol=1e-5)
+    assert abs(sl.item() - float(g[name + '_shortcut_loss'])) <= 1e-5 * max(float(g[name + '_shortcut_loss']), 1e-3)
+    (fl + sl).backward()
+    for k in keys:
+        assert Wg[k].grad is not None, k
+        close(Wg[k].grad, t(g[f'{name}_grad/{k}']), 'd ' + k, tol=1e-3)
+    assert len(keys) >= 90
+
+
 def test_blocks_compose_with_torch_autograd():
     """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
     g = torch.Generator().manual_seed(11)
