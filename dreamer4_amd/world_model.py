@@ -583,16 +583,29 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         in-place updates (`p.copy_()` under no_grad, optimiser steps, `load_state_dict`) are detected automatically."""
         self._trunk_version = None
 
-    # ------------------------------------------------------------------------------ forward (inference branch)
-    @torch.no_grad()
-    def forward(self, *, latents, signal_levels, step_sizes, discrete_actions=None, continuous_actions=None, tasks=None, time_cache=None,
-                latent_is_noised=True, return_pred_only=True, return_intermediates=True, commit_cache=True, **kwargs):
-        """Inference branch of DynamicsWorldModel.forward (dreamer4.py:6792-7295): latents are already noised,
-        returns (pred_flow, (agent_embed, next_time_cache)).  The training branch is out of scope."""
+    # ------------------------------------------------------------------------------ forward (inference branch / training branch)
+    def forward(self, *, latents, signal_levels=None, step_sizes=None, discrete_actions=None, continuous_actions=None, tasks=None, time_cache=None,
+                latent_is_noised=None, return_pred_only=None, return_intermediates=True, commit_cache=True, **kwargs):
+        """DynamicsWorldModel.forward (dreamer4.py:6792-7743).
+        Inference branch (`signal_levels` / `step_sizes` given, latents already noised): returns (pred_flow, (agent_embed, next_time_cache))
+        from the engine.  Training branch (neither given): samples the shortcut coin, step sizes, signal levels and noise as the
+        reference does (dreamer4.py:6956-7003) and returns the flow + shortcut loss (`return_all_losses=True`: `(total, (flow,
+        shortcut))`), differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py); the reward / terminal / action
+        multi-token-prediction losses are not implemented (passing rewards / terminals raises)."""
+        if signal_levels is None and step_sizes is None:
+            return self._training_forward(latents, discrete_actions, continuous_actions, tasks, **kwargs)
+        with torch.no_grad():
+            return self._inference_forward(latents, signal_levels, step_sizes, discrete_actions, continuous_actions, tasks, time_cache,
+                                           latent_is_noised, return_pred_only, commit_cache, kwargs)
+
+    def _inference_forward(self, latents, signal_levels, step_sizes, discrete_actions, continuous_actions, tasks, time_cache, latent_is_noised,
+                           return_pred_only, commit_cache, kwargs):
+        latent_is_noised = True if latent_is_noised is None else latent_is_noised
+        return_pred_only = True if return_pred_only is None else return_pred_only
         if kwargs:
             raise NotImplementedError(f'forward(): arguments {sorted(kwargs)} are outside the inference branch')
         if not (latent_is_noised and return_pred_only):
-            raise NotImplementedError('only forward(latent_is_noised=True, return_pred_only=True) is implemented')
+            raise NotImplementedError('with signal_levels / step_sizes only forward(latent_is_noised=True, return_pred_only=True) is implemented')
         B, T = latents.shape[:2]
         step = int(step_sizes if not torch.is_tensor(step_sizes) else step_sizes.flatten()[0].item())
         cached = time_cache.frames if time_cache is not None else 0
@@ -635,6 +648,52 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         tc = TimeCache(self, lib.d4_engine_cache_frames(self._engine), B, self._cache_serial)
         self._live_cache = tc
         return pred, (agent, tc)
+
+    def _training_forward(self, latents, discrete_actions, continuous_actions, tasks, *, return_all_losses=False, seed=None, generator=None,
+                          add_autoregressive_action_loss=False, prob_shortcut_train=None, draws=None, **kwargs):
+        """Training branch: flow loss (x-space, ramp weight) + shortcut consistency loss (dreamer4.py:6956-7003, 7335-7431, 7708-7711).
+        `draws` = dict(shortcut_train, step_sizes_log2, signal_levels, noise) injects the random draws (parity runs); otherwise they
+        come from `generator` (or a generator seeded with `seed`, as the reference's `seed=`)."""
+        from dreamer4_amd import trunk_ops
+        unsupported = {k: v for k, v in kwargs.items() if v is not None and k not in ('update_loss_ema',)}
+        if unsupported or add_autoregressive_action_loss:
+            raise NotImplementedError(f'training forward: {sorted(unsupported) or "the autoregressive action loss"} is not implemented '
+                                      '(flow + shortcut losses only; rewards / terminals / lens / proprio / video are outside the built slice)')
+        dev = self.device
+        lat = latents.to(dev).float()
+        if lat.ndim == 5:
+            assert lat.shape[2] == 1
+            lat = lat[:, :, 0]
+        B, T = lat.shape[:2]
+        assert lat.shape[2:] == tuple(self.latent_shape), f'latents must have shape {self.latent_shape}'
+        n_log2 = int(log2(self.max_steps))
+        if draws is None:
+            g = generator
+            if g is None and seed is not None:
+                g = torch.Generator(device=dev).manual_seed(seed)
+            prob = (1. - n_log2 ** -1.) if prob_shortcut_train is None else prob_shortcut_train           # dreamer4.py:4898
+            shortcut = bool(torch.rand(1, device=dev, generator=g).item() < prob)
+            if shortcut:                                                                                    # dreamer4.py:6967-6974, eq. (4)
+                step_log2 = torch.randint(1, n_log2, (B,), device=dev, generator=g)
+                nss = (2 ** step_log2)[:, None]
+                sig = torch.randint(0, self.max_steps, (B, T), device=dev, generator=g) // nss * nss
+            else:
+                step_log2 = torch.zeros(B, dtype=torch.long, device=dev)
+                sig = torch.randint(0, self.max_steps, (B, T), device=dev, generator=g)
+            noise = torch.randn(lat.shape, device=dev, generator=g)
+        else:
+            shortcut, step_log2, sig, noise = bool(draws['shortcut_train']), draws['step_sizes_log2'].to(dev).long(), draws['signal_levels'].to(dev).long(), draws['noise'].to(dev).float()
+        W = dict(self.named_parameters())
+        W.update({k: v for k, v in self.named_buffers() if k.endswith('inv_freq')})
+        is_time = [(i + 1) % self.time_block_every == 0 for i in range(self.depth)]
+        flow, short = trunk_ops.dynamics_flow_losses(
+            W, lat, noise, sig, step_log2, shortcut, max_steps=self.max_steps, is_time=is_time, num_spatial_tokens=self.num_spatial_tokens,
+            num_register_tokens=self.num_register_tokens, num_discrete_actions=tuple(self.num_discrete_actions),
+            discrete_actions=discrete_actions.to(dev).long() if discrete_actions is not None else None,
+            continuous_actions=continuous_actions.to(dev).float() if continuous_actions is not None else None,
+            tasks=tasks.to(dev).long() if tasks is not None else None, softclamp_value=self.attn_softclamp_value)
+        total = flow * 1. + short * 1.                  # latent_flow_loss_weight = shortcut_loss_weight = 1 (dreamer4.py:4719-4720)
+        return (total, (flow, short)) if return_all_losses else total
 
     # ------------------------------------------------------------------------------ generate
     @torch.no_grad()

@@ -221,6 +221,43 @@ def test_dynamics_flow_and_shortcut_losses_vs_reference_fixture(name):
     assert len(keys) >= 90
 
 
+def test_world_model_training_forward_matches_the_fixture_and_trains():
+    """DynamicsWorldModel.forward without signal levels = the training branch (dreamer4.py:6956-7003, 7335-7431, 7708): total loss against
+    the reference fixture with its draws injected, gradients on the mirror's own parameters, then a few AdamW steps on fresh draws
+    reduce the loss (the backward is usable, not just correct)."""
+    from util import golden_model, load_golden, t
+    g = load_golden('train.npz')
+    m = golden_model('weights_train.npz').cuda()
+    draws = dict(shortcut_train=True, step_sizes_log2=t(g['shortcut_step_sizes_log2']), signal_levels=t(g['shortcut_signal_levels']), noise=t(g['shortcut_noise']))
+    total, (fl, sl) = m(latents=t(g['latents']), discrete_actions=t(g['actions']), return_all_losses=True, draws=draws)
+    close(fl, t(g['shortcut_flow_loss']), 'flow', tol=1e-5)
+    close(total, t(g['shortcut_flow_loss']) + t(g['shortcut_shortcut_loss']), 'total', tol=1e-5)
+    total.backward()
+    own = dict(m.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('shortcut_grad/'):
+            close(own[k[14:]].grad, t(g[k]), 'd ' + k[14:], tol=1e-3); n += 1
+    assert n >= 90
+    with pytest.raises(NotImplementedError):
+        m(latents=t(g['latents']), rewards=torch.zeros(3, 4))
+    # a short optimisation on a fixed batch of "data" latents, fresh draws every step
+    trunk = [p for k, p in m.named_parameters() if p.grad is not None]
+    opt = torch.optim.AdamW(trunk, lr=3e-3, weight_decay=0.)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    lat = t(g['latents']).cuda()
+    first = last = None
+    for step in range(40):
+        opt.zero_grad(set_to_none=True)
+        loss = m(latents=lat, discrete_actions=t(g['actions']), generator=gen)
+        loss.backward()
+        opt.step()
+        m.invalidate_prepared()
+        last = loss.item()
+        first = first if first is not None else last
+    assert last < 0.7 * first, (first, last)
+
+
 def test_blocks_compose_with_torch_autograd():
     """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
     g = torch.Generator().manual_seed(11)
