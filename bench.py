@@ -129,6 +129,32 @@ def cfg4_env_latency(device, horizon=50):
     return out
 
 
+def train_flow_step(device, B=16, T=16, reps=4):
+    """SURVEY.md 8(f-3), secondary numbers: one dynamics TRAINING step at config 2's architecture — DynamicsWorldModel.forward without
+    signal levels (flow + shortcut losses, D4:6956-7003, 7335-7431) + backward through the HIP trunk blocks (dreamer4_amd/trunk_ops.py),
+    B x T frames of 15 tokens.  A first measured version (the blocks recompute their forward in the backward): no roofline is claimed."""
+    from dreamer4_amd import DynamicsWorldModel
+    from dreamer4_amd.synthetic import randomize_weights
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG2)).to(device)
+    g = torch.Generator(device=device).manual_seed(1)
+    lat = torch.randn(B, T, CFG2['num_latent_tokens'], CFG2['dim_latent'], device=device, generator=g).clamp(-2, 2)
+    acts = torch.randint(0, 4, (B, T, 1), device=device, generator=g)
+    out = {}
+    for name, prob in (('flow_only', 0.), ('with_shortcut', 1.)):
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps):
+                for p in m.parameters():
+                    p.grad = None
+                m(latents=lat, discrete_actions=acts, generator=g, prob_shortcut_train=prob).backward()
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+        out[f'{name}_ms_per_step'] = round(1e3 * dt, 2)
+        out[f'{name}_frames_per_sec'] = round(B * T / dt, 1)
+    out['workload'] = f'cfg2 architecture, training forward + backward, B={B} x T={T} frames x 15 tokens = {B * T * 15} token rows, fp32'
+    return out
+
+
 def cfg5_bf16(device, lib, B=128, frames=16, reps=2):
     """BASELINE config 5, secondary numbers: dim 1024 depth 12, 64 x 32 latents, 6 continuous (Beta) actions, B = 128 per GPU
     (1024 / 8), H = 15, trunk GEMMs on the bf16 MFMA path.  Rollout only (the learner is the same fp32 code as config 2)."""
@@ -291,6 +317,7 @@ def main():
         torch.cuda.empty_cache()
         out['cfg4_env_step'] = cfg4_env_latency(device)
         out['cfg5_bf16'] = cfg5_bf16(device, lib)
+        out['train_flow_step'] = train_flow_step(device)
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)

@@ -47,8 +47,29 @@ static int gemm_b(const float* A, int lda, const float* W, int ldw, float* C, in
     return gemm(g, s);
 }
 
+// Weight gradient dW[M][N] = A^T B with A [K][M], B [K][N] row-major and K = token rows (thousands to tens of thousands) while M x N is one
+// weight matrix (often only 64 tiles): split K over the grid's batch dimension into partial products, then one fixed-order reduce —
+// without it these GEMMs run on a quarter of the CUs and were half of a training step (tools/train_step_time.py).
+constexpr size_t DW_PART_FLOATS = (size_t)8 << 20;          // partial-product scratch per workspace (32 MB)
+static int gemm_dw(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* part, hipStream_t s) {
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    int S = (int)((1024 + tiles - 1) / tiles);
+    if (S > K / 256) S = K / 256;
+    if ((size_t)S * M * N > DW_PART_FLOATS) S = (int)(DW_PART_FLOATS / ((size_t)M * N));
+    if (S <= 1 || !part) return gemm_b(A, lda, B, ldb, C, ldc, nullptr, M, N, K, GEMM_TRANS_A | GEMM_TRANS_B, s);
+    const int ks = ((K + S - 1) / S + 31) / 32 * 32;        // k per slice
+    const int full = K / ks, rem = K - full * ks;
+    int rc;
+    GemmArgs g{A, lda, B, ldb, part, N, nullptr, nullptr, 0, M, N, ks, GEMM_TRANS_A | GEMM_TRANS_B, 0.f};
+    g.batch = full; g.strideA = (int64_t)ks * lda; g.strideW = (int64_t)ks * ldb; g.strideC = (int64_t)M * N;
+    if ((rc = gemm(g, s))) return rc;
+    if (rem > 0 && (rc = gemm_b(A + (int64_t)full * ks * lda, lda, B + (int64_t)full * ks * ldb, ldb, part + (int64_t)full * M * N, N, nullptr, M, N, rem,
+                                GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    return splitk_reduce(part, full + (rem > 0), M, N, nullptr, 0, C, ldc, s);
+}
+
 struct FfWs {            // workspace carve-up (floats); all leading dimensions are multiples of 4
-    float *xn, *w1p, *b1p, *w2p, *h, *u, *du, *dh, *dxn, *tg, *dw1p, *dw2p;
+    float *xn, *w1p, *b1p, *w2p, *h, *u, *du, *dh, *dxn, *tg, *dw1p, *dw2p, *part;
     size_t total;
 };
 static FfWs ff_ws(float* base, int R, int D, int I) {
@@ -59,6 +80,7 @@ static FfWs ff_ws(float* base, int R, int D, int I) {
     w.xn = take((size_t)R * D); w.w1p = take(2 * Ip * D); w.b1p = take(2 * Ip); w.w2p = take((size_t)D * Ip);
     w.h = take((size_t)R * 2 * Ip); w.u = take((size_t)R * Ip); w.du = take((size_t)R * Ip); w.dh = take((size_t)R * 2 * Ip);
     w.dxn = take((size_t)R * D); w.tg = take((size_t)R * D); w.dw1p = take(2 * Ip * D); w.dw2p = take((size_t)D * Ip);
+    w.part = take(DW_PART_FLOATS);
     w.total = off;
     return w;
 }
@@ -401,7 +423,7 @@ __global__ void zero_pad_cols_kernel(float* x, int rows, int ld, int c0, int c1)
 }
 
 struct AttnWs {
-    float *xn, *wcat, *bcat, *proj, *dproj, *d_o3, *o3, *dwcat, *tg, *dxn, *gpart;
+    float *xn, *wcat, *bcat, *proj, *dproj, *d_o3, *o3, *dwcat, *tg, *dxn, *gpart, *part;
     size_t total;
     int P, hp4;
 };
@@ -415,6 +437,7 @@ static AttnWs attn_ws(float* base, int R, int F, int D, int heads, int dh) {
     w.xn = take((size_t)R * D); w.wcat = take((size_t)w.P * D); w.bcat = take(w.P); w.proj = take((size_t)R * w.P); w.dproj = take((size_t)R * w.P);
     w.d_o3 = take((size_t)R * hd); w.o3 = take((size_t)R * hd); w.dwcat = take((size_t)w.P * D); w.tg = take((size_t)R * D); w.dxn = take((size_t)R * D);
     w.gpart = take((size_t)F * hd);
+    w.part = take(DW_PART_FLOATS);
     w.total = off;
     return w;
 }
@@ -476,7 +499,7 @@ int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const f
     if ((rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, R, D, I, s))) return rc;
     // y = u W2^T + b2
     if ((rc = colsum(dy, D, R, D, d_b_out, s))) return rc;
-    if ((rc = gemm_b(dy, D, w.u, Ip, w.dw2p, Ip, nullptr, D, Ip, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;     // dW2 = dy^T u
+    if ((rc = gemm_dw(dy, D, w.u, Ip, w.dw2p, Ip, D, Ip, R, w.part, s))) return rc;                                    // dW2 = dy^T u
     if ((rc = copy_rows(w.dw2p, Ip, d_w_out, I, D, I, s))) return rc;
     if ((rc = gemm_b(dy, D, w.w2p, Ip, w.du, Ip, nullptr, R, Ip, D, GEMM_TRANS_B, s))) return rc;                       // du = dy W2
     hipLaunchKernelGGL(swiglu_bwd_kernel, grid_for((int64_t)R * Ip), dim3(256), 0, s, w.h, w.du, w.dh, R, I, Ip);
@@ -484,7 +507,7 @@ int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const f
     // h = xn W1^T + b1
     if ((rc = colsum(w.dh, 2 * Ip, R, I, d_b_in, s))) return rc;
     if ((rc = colsum(w.dh + Ip, 2 * Ip, R, I, d_b_in + I, s))) return rc;
-    if ((rc = gemm_b(w.dh, 2 * Ip, w.xn, D, w.dw1p, D, nullptr, 2 * Ip, D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;   // dW1 = dh^T xn
+    if ((rc = gemm_dw(w.dh, 2 * Ip, w.xn, D, w.dw1p, D, 2 * Ip, D, R, w.part, s))) return rc;                          // dW1 = dh^T xn
     D4_HIP(hipMemcpyAsync(d_w_in, w.dw1p, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
     D4_HIP(hipMemcpyAsync(d_w_in + (size_t)I * D, w.dw1p + (size_t)Ip * D, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
     if ((rc = gemm_b(w.dh, 2 * Ip, w.w1p, D, w.dxn, D, nullptr, R, D, 2 * Ip, GEMM_TRANS_B, s))) return rc;            // dxn = dh W1
@@ -558,10 +581,10 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
         hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
         D4_LAUNCH_CHECK();
     }
-    if ((rc = gemm_b(dy, D, w.o3, hd, o.d_wo, hd, nullptr, D, hd, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;        // dWo = dy^T o3
+    if ((rc = gemm_dw(dy, D, w.o3, hd, o.d_wo, hd, D, hd, R, w.part, s))) return rc;                                     // dWo = dy^T o3
     if ((rc = colsum(w.gpart, hd, g.groups, hd, o.d_gamma, s))) return rc;
     // projections: dW = dproj^T xn, dxn = dproj Wcat
-    if ((rc = gemm_b(w.dproj, w.P, w.xn, D, w.dwcat, D, nullptr, w.P, D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dw(w.dproj, w.P, w.xn, D, w.dwcat, D, w.P, D, R, w.part, s))) return rc;
     const size_t blk = sizeof(float) * (size_t)hd * D;
     D4_HIP(hipMemcpyAsync(o.d_wq, w.dwcat, blk, hipMemcpyDeviceToDevice, s));
     D4_HIP(hipMemcpyAsync(o.d_wk, w.dwcat + (size_t)hd * D, blk, hipMemcpyDeviceToDevice, s));
@@ -577,7 +600,7 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
 }
 
 struct XWs {
-    float *qn, *cn, *wqg, *wkv, *projq, *projk, *dprojq, *dprojk, *d_o3, *o3, *dwqg, *dwkv, *tg, *dqn, *tgc, *dcn, *gpart;
+    float *qn, *cn, *wqg, *wkv, *projq, *projk, *dprojq, *dprojk, *d_o3, *o3, *dwqg, *dwkv, *tg, *dqn, *tgc, *dcn, *gpart, *part;
     size_t total; int Pq, Pk, hp4;
 };
 XWs x_ws(float* base, int Rq, int Rk, int G, int D, int Dc, int heads, int dh) {
@@ -590,6 +613,7 @@ XWs x_ws(float* base, int Rq, int Rk, int G, int D, int Dc, int heads, int dh) {
     w.projq = take((size_t)Rq * w.Pq); w.projk = take((size_t)Rk * w.Pk); w.dprojq = take((size_t)Rq * w.Pq); w.dprojk = take((size_t)Rk * w.Pk);
     w.d_o3 = take((size_t)Rq * hd); w.o3 = take((size_t)Rq * hd); w.dwqg = take((size_t)w.Pq * D); w.dwkv = take((size_t)w.Pk * Dc);
     w.tg = take((size_t)Rq * D); w.dqn = take((size_t)Rq * D); w.tgc = take((size_t)Rk * Dc); w.dcn = take((size_t)Rk * Dc); w.gpart = take((size_t)G * hd);
+    w.part = take(DW_PART_FLOATS);
     w.total = off;
     return w;
 }
@@ -667,17 +691,17 @@ int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float*
         hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)Rq * (w.hp4 - heads)), dim3(256), 0, s, w.dprojq, Rq, w.Pq, hd + heads, w.Pq);
         D4_LAUNCH_CHECK();
     }
-    if ((rc = gemm_b(dy, D, w.o3, hd, d_wo, hd, nullptr, D, hd, Rq, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dw(dy, D, w.o3, hd, d_wo, hd, D, hd, Rq, w.part, s))) return rc;
     if ((rc = colsum(w.gpart, hd, groups, hd, d_k_gamma, s))) return rc;
     // query side
-    if ((rc = gemm_b(w.dprojq, w.Pq, w.qn, D, w.dwqg, D, nullptr, w.Pq, D, Rq, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dw(w.dprojq, w.Pq, w.qn, D, w.dwqg, D, w.Pq, D, Rq, w.part, s))) return rc;
     D4_HIP(hipMemcpyAsync(d_wq, w.dwqg, sizeof(float) * (size_t)hd * D, hipMemcpyDeviceToDevice, s));
     D4_HIP(hipMemcpyAsync(d_w_gates, w.dwqg + (size_t)hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
     if ((rc = gemm_b(w.dprojq, w.Pq, w.wqg, D, w.dqn, D, nullptr, Rq, D, w.Pq, GEMM_TRANS_B, s))) return rc;
     if ((rc = rmsnorm_bwd(q_tokens, w.dqn, norm_w, w.tg, d_q_tokens, Rq, D, RMS_EPS, s))) return rc;
     if ((rc = colsum(w.tg, D, Rq, D, d_norm_w, s))) return rc;
     // context side
-    if ((rc = gemm_b(w.dprojk, w.Pk, w.cn, Dc, w.dwkv, Dc, nullptr, w.Pk, Dc, Rk, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dw(w.dprojk, w.Pk, w.cn, Dc, w.dwkv, Dc, w.Pk, Dc, Rk, w.part, s))) return rc;
     D4_HIP(hipMemcpyAsync(d_wk, w.dwkv, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
     D4_HIP(hipMemcpyAsync(d_wv, w.dwkv + (size_t)hd * Dc, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
     if (norm_ctx_w) {
