@@ -47,6 +47,40 @@ def test_gemm_bf16_kernel(M, N, K, flags):
     assert err <= tol, f'M{M} N{N} K{K} flags{flags}: err {err:.3e} > {tol:.3e}'
 
 
+@pytest.mark.parametrize('M,N,K,flags', [(3584, 512, 512, 0), (200, 300, 96, 1), (1920, 2752, 1024, 5), (1920, 1552, 1024, 1), (130, 64, 2752, 0)])
+def test_gemm_bf16_lds_dma_form_matches_the_register_staged_form(M, N, K, flags):
+    """The experimental LDS-DMA form (gemm_bf16_dma.hip, opt-in D4_BF16_DMA=1): every tile configuration walks k in the register-staged
+    form's order, so without the folded RMSNorm the two give the same bits; with it the 1/rms row sums are folded in a different
+    (fixed) order: 1e-6 relative."""
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    A = torch.randn(M, K, device='cuda', generator=g); Wb = torch.randn(N, K, device='cuda', generator=g).to(torch.bfloat16).contiguous()
+    b = torch.randn(N, device='cuda', generator=g)
+    swiglu = bool(flags & _lib.GEMM_SWIGLU)
+    R = None if swiglu else torch.randn(M, N, device='cuda', generator=g)
+    Nout = N // 2 if swiglu else N
+
+    def run(cfg):
+        out = torch.full((M, Nout), float('nan'), device='cuda')
+        lib.d4_gemm_force_config(cfg)
+        try:
+            _lib.check(lib.d4_gemm_bf16(_lib.ptr(A), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, 1.1920929e-07, stream()))
+            torch.cuda.synchronize()
+        finally:
+            lib.d4_gemm_force_config(-1)
+        return out
+
+    ref = run(200)
+    for c in range(5):
+        if swiglu and c == 2:
+            continue                                     # 64 x 128 with 32-column waves cannot pair values with gates
+        out = run(300 + c)
+        if flags & _lib.GEMM_RMS_ROWSCALE:
+            assert (out - ref).abs().max().item() <= 1e-6 * ref.abs().max().item(), c
+        else:
+            assert torch.equal(out, ref), c
+
+
 def _pair(kw, seed=0):
     torch.manual_seed(seed)
     a = randomize_weights(DynamicsWorldModel(**kw), seed=seed)
