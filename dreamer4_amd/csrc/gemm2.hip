@@ -313,13 +313,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
 // 128x64/s      4 x 1     32 x 64    128 x 64   32  3 x 24 KB    2 (8)    SiLU-GLU capable
 // 128x64/k16    4 x 2     32 x 32    128 x 64   16  4 x 12 KB    3 (24)
 // 128x128/k16   4 x 2     32 x 64    128 x 128  16  3 x 16 KB    3 (24)   SiLU-GLU capable
+// 32x64         2 x 2     16 x 32     32 x 64   32  3 x 12 KB    4 (16)   small GEMMs (< 2 blocks of 64 x 64 per CU): twice the blocks
+// 32x64/s       2 x 1     16 x 64     32 x 64   32  3 x 12 KB    4 (8)    SiLU-GLU capable
 // Measured on the engine's shapes (tools/gemm2_bench.py, profiles/r02_gemm_families.txt) and dropped: 128x128 with 4 or 8 waves and
 // 256x128 at either BK (one or two blocks per CU leave every barrier exposed: 1.3-3x slower on the N <= 512 shapes), 112x64 /
 // 128x64 with 4 waves, 64x64 with a 4-deep ring or at BK = 16 (never ahead of the forms above).  Waves per CU is what pays.
-enum { V2_64x64 = 0, V2_64x64_s, V2_128x64_8, V2_128x64_s, V2_128x64_k16, V2_128x128_k16, V2_N };
+enum { V2_64x64 = 0, V2_64x64_s, V2_128x64_8, V2_128x64_s, V2_128x64_k16, V2_128x128_k16, V2_32x64, V2_32x64_s, V2_32x32, V2_64x32, V2_N };
 static const char* const kV2Kernel[V2_N] = {"gemm2_kernel<2, 2, 2, 2, 3, 32", "gemm2_kernel<4, 1, 1, 4, 3, 32", "gemm2_kernel<4, 2, 2, 2, 3, 32", "gemm2_kernel<4, 1, 2, 4, 3, 32",
-                                            "gemm2_kernel<4, 2, 2, 2, 4, 16", "gemm2_kernel<4, 2, 2, 4, 3, 16"};
-static const int kV2BM[V2_N] = {64, 64, 128, 128, 128, 128}, kV2BN[V2_N] = {64, 64, 64, 64, 64, 128};
+                                            "gemm2_kernel<4, 2, 2, 2, 4, 16", "gemm2_kernel<4, 2, 2, 4, 3, 16", "gemm2_kernel<2, 2, 1, 2, 3, 32", "gemm2_kernel<2, 1, 1, 4, 3, 32", "gemm2_kernel<2, 2, 1, 1, 3, 32", "gemm2_kernel<4, 1, 1, 2, 3, 32"};
+static const int kV2BM[V2_N] = {64, 64, 128, 128, 128, 128, 32, 32, 32, 64}, kV2BN[V2_N] = {64, 64, 64, 64, 64, 128, 64, 64, 32, 32};
 
 int gemm2_configs() { return V2_N; }
 const char* gemm2_config_name(int c) { return c >= 0 && c < V2_N ? kV2Kernel[c] : ""; }
@@ -331,7 +333,7 @@ bool gemm2_applicable(const GemmArgs& p) {
 
 bool gemm2_config_valid(int c, const GemmArgs& p) {
     if (c < 0 || c >= V2_N || !gemm2_applicable(p)) return false;
-    if (p.flags & GEMM_SWIGLU) return c == V2_64x64_s || c == V2_128x64_s || c == V2_128x128_k16;
+    if (p.flags & GEMM_SWIGLU) return c == V2_64x64_s || c == V2_128x64_s || c == V2_128x128_k16 || c == V2_32x64_s;
     return true;
 }
 
@@ -362,6 +364,10 @@ int gemm2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hi
         case V2_128x64_s: return launch2<4, 1, 2, 4, 3, 32>(p, stream, ea, eb);
         case V2_128x64_k16: return launch2<4, 2, 2, 2, 4, 16>(p, stream, ea, eb);
         case V2_128x128_k16: return launch2<4, 2, 2, 4, 3, 16>(p, stream, ea, eb);
+        case V2_32x64: return launch2<2, 2, 1, 2, 3, 32>(p, stream, ea, eb);
+        case V2_32x64_s: return launch2<2, 1, 1, 4, 3, 32>(p, stream, ea, eb);
+        case V2_32x32: return launch2<2, 2, 1, 1, 3, 32>(p, stream, ea, eb);
+        case V2_64x32: return launch2<4, 1, 1, 2, 3, 32>(p, stream, ea, eb);
     }
     return 2;
 }
