@@ -317,7 +317,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
 // 32x64/s       2 x 1     16 x 64     32 x 64   32  3 x 12 KB    4 (8)    SiLU-GLU capable
 // Measured on the engine's shapes (tools/gemm2_bench.py, profiles/r02_gemm_families.txt) and dropped: 128x128 with 4 or 8 waves and
 // 256x128 at either BK (one or two blocks per CU leave every barrier exposed: 1.3-3x slower on the N <= 512 shapes), 112x64 /
-// 128x64 with 4 waves, 64x64 with a 4-deep ring or at BK = 16 (never ahead of the forms above).  Waves per CU is what pays.
+// 128x64 with 4 waves, 64x64 with a 4-deep ring or at BK = 16, 32x128 (SiLU-GLU capable) and 32x64 at BK = 16 (never ahead of the forms
+// above).  Waves per CU is what pays: the 32-row tiles added last (4-6 blocks per CU) win every N <= 512 shape.
 enum { V2_64x64 = 0, V2_64x64_s, V2_128x64_8, V2_128x64_s, V2_128x64_k16, V2_128x128_k16, V2_32x64, V2_32x64_s, V2_32x32, V2_64x32, V2_N };
 static const char* const kV2Kernel[V2_N] = {"gemm2_kernel<2, 2, 2, 2, 3, 32", "gemm2_kernel<4, 1, 1, 4, 3, 32", "gemm2_kernel<4, 2, 2, 2, 3, 32", "gemm2_kernel<4, 1, 2, 4, 3, 32",
                                             "gemm2_kernel<4, 2, 2, 2, 4, 16", "gemm2_kernel<4, 2, 2, 4, 3, 16", "gemm2_kernel<2, 2, 1, 2, 3, 32", "gemm2_kernel<2, 1, 1, 4, 3, 32", "gemm2_kernel<2, 2, 1, 1, 3, 32", "gemm2_kernel<4, 1, 1, 2, 3, 32"};
