@@ -350,8 +350,8 @@ bool gemm_bf16_profile_active();
 bool gemm_profile_active() { return g_prof_mask != 0 || gemm_bf16_profile_active(); }
 
 int gemm_profile_enable(int mask) {
-    g_prof_stride = (mask >> 16) > 0 ? (mask >> 16) : 1;
-    mask &= 0xFFFF;
+    g_prof_stride = (mask >> 24) > 0 ? (mask >> 24) : 1;          // bits 24..30: stride; bits 0..23: configurations
+    mask &= 0xFFFFFF;
     g_prof_tick = 0;
     g_prof_mask = mask;
     return 0;
