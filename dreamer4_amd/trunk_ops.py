@@ -351,18 +351,18 @@ def world_model_prediction(W, noised_latents, signal_levels, step_sizes_log2, *,
     return F.linear(x, W['to_latent_pred.2.weight']), agent_embed
 
 
-def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, *, max_steps, **model):
+def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, *, max_steps, return_agent_embed=False, **model):
     """The flow and shortcut-consistency losses of the dynamics training forward (dreamer4.py:6990-7003, 7335-7431; x-space prediction,
     ramp loss weight, no proprio / variable lengths / loss normalisers: the reference defaults).  `model`: the keyword arguments of
-    `world_model_prediction`.  Returns (flow_loss, shortcut_loss); backward runs through the HIP blocks."""
+    `world_model_prediction`.  Returns (flow_loss, shortcut_loss[, agent_embed of the main prediction]); backward runs through the HIP blocks."""
     from torch.nn import functional as F
     times = signal_levels.float() / max_steps
     tt = times[:, :, None, None]
     noised = noise.lerp(latents, tt)
-    pred, _ = world_model_prediction(W, noised, signal_levels, step_sizes_log2, **model)
+    pred, agent_embed = world_model_prediction(W, noised, signal_levels, step_sizes_log2, **model)
     flow_losses = F.mse_loss(pred, latents, reduction='none') * (0.9 * times + 0.1)[:, :, None, None]
     if not shortcut_train:
-        return flow_losses.mean(), latents.new_zeros(())
+        return (flow_losses.mean(), latents.new_zeros(()), agent_embed) if return_agent_embed else (flow_losses.mean(), latents.new_zeros(()))
     with torch.no_grad():
         half_log2 = step_sizes_log2 - 1
         half = 2 ** half_log2
@@ -375,4 +375,83 @@ def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shor
         target = (first_flow + second_flow) / 2
     shortcut_pred = (pred - noised) / (1. - tt)
     shortcut_losses = F.mse_loss(shortcut_pred, target, reduction='none') * (1. - tt) ** 2
-    return flow_losses.mean(), shortcut_losses.mean()
+    return (flow_losses.mean(), shortcut_losses.mean(), agent_embed) if return_agent_embed else (flow_losses.mean(), shortcut_losses.mean())
+
+
+# ------------------------------------------------------------------------------------------------ agent-token losses of the training forward
+def _head_mlp(W, pre, x, n_layers, recipe):
+    """The heads' normed MLP (x_mlps_pytorch.create_mlp stand-in): 'pre_rms' or 'post_layer'."""
+    from torch.nn import functional as F
+    eps = torch.finfo(torch.float32).eps
+    for i in range(n_layers):
+        last = i == n_layers - 1
+        if recipe == 'pre_rms':
+            x = F.linear(F.rms_norm(x, x.shape[-1:], W[f'{pre}layers.{i}.0.weight'], eps), W[f'{pre}layers.{i}.1.weight'], W[f'{pre}layers.{i}.1.bias'])
+            if not last:
+                x = F.silu(x)
+        elif last:
+            x = F.linear(x, W[f'{pre}layers.{i}.weight'], W[f'{pre}layers.{i}.bias'])
+        else:
+            x = F.linear(x, W[f'{pre}layers.{i}.0.weight'], W[f'{pre}layers.{i}.0.bias'])
+            x = F.silu(F.layer_norm(x, x.shape[-1:], W[f'{pre}layers.{i}.1.weight'], W[f'{pre}layers.{i}.1.bias'], 1e-5))
+    return x
+
+
+def _mtp_targets(t, steps):
+    """create_multi_token_prediction_targets (dreamer4.py:530-552)."""
+    n = t.shape[1]
+    idx = torch.arange(n, device=t.device)[:, None] + torch.arange(steps, device=t.device)[None, :]
+    mask = idx < n
+    idx = idx.masked_fill(~mask, 0)
+    return t[:, idx], mask[None].expand(t.shape[0], -1, -1)
+
+
+def hl_gauss_probs(values, vrange, num_bins, sigma_to_bin_ratio=2., eps=1e-10):
+    """HL-Gauss soft targets (Farebrother et al. 2024; hl_gauss_pytorch stand-in)."""
+    support = torch.linspace(vrange[0], vrange[1], num_bins + 1, device=values.device)
+    sigma = sigma_to_bin_ratio * (vrange[1] - vrange[0]) / num_bins
+    cdf = torch.special.erf((support - values.clamp(vrange[0], vrange[1])[..., None]) / (2. ** 0.5 * sigma))
+    z = cdf[..., -1] - cdf[..., 0]
+    return (cdf[..., 1:] - cdf[..., :-1]) / z.clamp(min=eps)[..., None]
+
+
+def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_discrete_actions, reward_range, reward_num_bins,
+                          policy_head_mlp_depth, terminal_mlp_depth, head_mlp_recipe='pre_rms', gae_discount_factor=0.997,
+                          hl_sigma_ratio=2., hl_eps=1e-10, rewards=None, discrete_actions=None, terminals=None):
+    """The agent-token losses of the training forward (dreamer4.py:7432-7598): multi-token-prediction reward cross entropy against HL-Gauss
+    soft targets, terminal BCE with label smoothing, behaviour-cloning log-likelihood of the discrete actions (multi-token prediction,
+    `shift_action_tokens=True`).  Plain torch ops on the device (the heads are three small MLPs on (b, t) rows); their gradients reach the
+    trunk through `agent_embed`.  Returns a dict of the terms that were asked for: rewards (mtp,), terminals (), discrete_actions (mtp,)."""
+    from torch.nn import functional as F
+    out = {}
+    mtp = multi_token_pred_len
+    eps = torch.finfo(torch.float32).eps
+    t = agent_embed.shape[1]
+    if rewards is not None:
+        two_hot = hl_gauss_probs(rewards, reward_range, reward_num_bins, hl_sigma_ratio, hl_eps)
+        x = agent_embed[:, :-1]
+        pred = torch.stack([F.linear(F.rms_norm(x, x.shape[-1:], W['to_reward_pred.params.0'][i], eps), W['to_reward_pred.params.1'][i]) for i in range(mtp)], dim=2)
+        tgt, mask = _mtp_targets(two_hot[:, 1:], mtp)
+        losses = -(tgt * pred.log_softmax(dim=-1)).sum(dim=-1).masked_fill(~mask, 0.)
+        out['rewards'] = losses.mean(dim=(0, 1))
+    if terminals is not None:
+        pooled = latents[:, 1:].mean(dim=-2)
+        logit = _head_mlp(W, 'to_state_terminal_pred.0.', pooled, terminal_mlp_depth + 2, head_mlp_recipe).squeeze(-1)
+        e = 1. - gae_discount_factor
+        out['terminals'] = F.binary_cross_entropy_with_logits(logit, terminals[:, 1:].float().clamp(min=e, max=1. - e))
+    if discrete_actions is not None and t > 1:
+        padded = F.pad(discrete_actions, (0, 0, 1, 0), value=-1)
+        tgt, mask = _mtp_targets(padded, mtp)
+        tgt, mask = tgt[:, 1:].clamp(min=0), mask[:, 1:]
+        pe = _head_mlp(W, 'policy_head.', agent_embed[:, :padded.shape[1] - 1], policy_head_mlp_depth + 2, head_mlp_recipe)
+        per = []
+        for i in range(mtp):
+            logits = F.linear(pe, W['action_embedder.discrete_action_unembed'][:, i])
+            lps, o = [], 0
+            for a, n in enumerate(num_discrete_actions):
+                lp = logits[..., o:o + n].log_softmax(dim=-1)
+                lps.append(lp.gather(-1, tgt[:, :, i, a:a + 1]).squeeze(-1))
+                o += n
+            per.append((-torch.stack(lps, dim=-1)).masked_fill(~mask[:, :, i, None], 0.).mean())
+        out['discrete_actions'] = torch.stack(per)
+    return out

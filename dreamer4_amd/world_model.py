@@ -589,9 +589,11 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         """DynamicsWorldModel.forward (dreamer4.py:6792-7743).
         Inference branch (`signal_levels` / `step_sizes` given, latents already noised): returns (pred_flow, (agent_embed, next_time_cache))
         from the engine.  Training branch (neither given): samples the shortcut coin, step sizes, signal levels and noise as the
-        reference does (dreamer4.py:6956-7003) and returns the flow + shortcut loss (`return_all_losses=True`: `(total, (flow,
-        shortcut))`), differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py); the reward / terminal / action
-        multi-token-prediction losses are not implemented (passing rewards / terminals raises)."""
+        reference does (dreamer4.py:6956-7003) and returns the total loss of dreamer4.py:7708-7723 (`return_all_losses=True`: `(total,
+        WorldModelLosses(flow, shortcut, rewards, terminals, discrete_actions))`): flow + shortcut, and — when `rewards` / `terminals` /
+        `discrete_actions` are given — the multi-token-prediction reward, terminal and behaviour-cloning losses (dreamer4.py:7432-7598);
+        differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py).  Not implemented: lens, proprio, continuous-action
+        behaviour cloning, loss normalisers."""
         if signal_levels is None and step_sizes is None:
             return self._training_forward(latents, discrete_actions, continuous_actions, tasks, **kwargs)
         with torch.no_grad():
@@ -650,15 +652,19 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         return pred, (agent, tc)
 
     def _training_forward(self, latents, discrete_actions, continuous_actions, tasks, *, return_all_losses=False, seed=None, generator=None,
-                          add_autoregressive_action_loss=False, prob_shortcut_train=None, draws=None, **kwargs):
-        """Training branch: flow loss (x-space, ramp weight) + shortcut consistency loss (dreamer4.py:6956-7003, 7335-7431, 7708-7711).
+                          add_autoregressive_action_loss=True, prob_shortcut_train=None, draws=None, rewards=None, terminals=None, **kwargs):
+        """Training branch: flow loss (x-space, ramp weight) + shortcut consistency loss (dreamer4.py:6956-7003, 7335-7431) + the
+        agent-token losses (dreamer4.py:7432-7598) + total (dreamer4.py:7708-7723).
         `draws` = dict(shortcut_train, step_sizes_log2, signal_levels, noise) injects the random draws (parity runs); otherwise they
         come from `generator` (or a generator seeded with `seed`, as the reference's `seed=`)."""
         from dreamer4_amd import trunk_ops
         unsupported = {k: v for k, v in kwargs.items() if v is not None and k not in ('update_loss_ema',)}
-        if unsupported or add_autoregressive_action_loss:
-            raise NotImplementedError(f'training forward: {sorted(unsupported) or "the autoregressive action loss"} is not implemented '
-                                      '(flow + shortcut losses only; rewards / terminals / lens / proprio / video are outside the built slice)')
+        if unsupported:
+            raise NotImplementedError(f'training forward: {sorted(unsupported)} is not implemented (lens / proprio / video / aug / genes are outside the built slice)')
+        if continuous_actions is not None and add_autoregressive_action_loss:
+            raise NotImplementedError('training forward: the continuous-action behaviour-cloning loss is not implemented (pass add_autoregressive_action_loss=False)')
+        if self.reward_encoder_type != 'hl_gauss' and rewards is not None:
+            raise NotImplementedError('training forward: reward loss with the symexp_two_hot encoder is not implemented')
         dev = self.device
         lat = latents.to(dev).float()
         if lat.ndim == 5:
@@ -686,14 +692,36 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         W = dict(self.named_parameters())
         W.update({k: v for k, v in self.named_buffers() if k.endswith('inv_freq')})
         is_time = [(i + 1) % self.time_block_every == 0 for i in range(self.depth)]
-        flow, short = trunk_ops.dynamics_flow_losses(
-            W, lat, noise, sig, step_log2, shortcut, max_steps=self.max_steps, is_time=is_time, num_spatial_tokens=self.num_spatial_tokens,
+        flow, short, agent_embed = trunk_ops.dynamics_flow_losses(
+            W, lat, noise, sig, step_log2, shortcut, max_steps=self.max_steps, return_agent_embed=True, is_time=is_time, num_spatial_tokens=self.num_spatial_tokens,
             num_register_tokens=self.num_register_tokens, num_discrete_actions=tuple(self.num_discrete_actions),
             discrete_actions=discrete_actions.to(dev).long() if discrete_actions is not None else None,
             continuous_actions=continuous_actions.to(dev).float() if continuous_actions is not None else None,
             tasks=tasks.to(dev).long() if tasks is not None else None, softclamp_value=self.attn_softclamp_value)
-        total = flow * 1. + short * 1.                  # latent_flow_loss_weight = shortcut_loss_weight = 1 (dreamer4.py:4719-4720)
-        return (total, (flow, short)) if return_all_losses else total
+        rew = rewards.to(dev).float() if rewards is not None else None
+        if rew is not None and rew.shape[1] == T - 1:
+            rew = torch.nn.functional.pad(rew, (1, 0), value=0.)                                           # dreamer4.py:6905-6907
+        term = terminals.to(dev) if (terminals is not None and self.predict_terminals) else None
+        if term is not None:
+            assert term.ndim == 2, 'terminals must be (batch, time) or (batch, time - 1)'
+            if term.shape[1] == T - 1:
+                term = torch.nn.functional.pad(term, (1, 0), value=False)
+        da = discrete_actions.to(dev).long() if (discrete_actions is not None and add_autoregressive_action_loss) else None
+        if da is not None and da.ndim == 2:
+            da = da[..., None]
+        agent = trunk_ops.dynamics_agent_losses(
+            W, agent_embed, lat, multi_token_pred_len=self.multi_token_pred_len, num_discrete_actions=tuple(self.num_discrete_actions),
+            reward_range=self.reward_range, reward_num_bins=self.reward_num_bins, policy_head_mlp_depth=self.policy_head_mlp_depth,
+            terminal_mlp_depth=self.terminal_mlp_depth, head_mlp_recipe=self.head_mlp_recipe, gae_discount_factor=self.gae_discount_factor,
+            hl_sigma_ratio=self.hl_sigma_ratio, hl_eps=self.hl_eps, rewards=rew, discrete_actions=da, terminals=term)
+        # unit loss weights: the reference defaults (dreamer4.py:4719-4725, 7708-7723)
+        total = flow + short + sum(v.sum() for v in agent.values())
+        if not return_all_losses:
+            return total
+        from collections import namedtuple
+        Losses = namedtuple('WorldModelLosses', ('flow', 'shortcut', 'rewards', 'terminals', 'discrete_actions'))
+        z = lat.new_zeros(())
+        return total, Losses(flow, short, agent.get('rewards', z), agent.get('terminals', z), agent.get('discrete_actions', z))
 
     # ------------------------------------------------------------------------------ generate
     @torch.no_grad()

@@ -29,6 +29,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   symexp.npz       reward_encoder_type='symexp_two_hot' (weights_symexp.npz): rollout, ppo losses and gradients
   encode.npz       VideoTokenizer.tokenize of reference tokenizers (weights_encode*.npz = the encoder half) + generate(prompt=video)
   train.npz        flow + shortcut losses of the dynamics training forward and their gradients (weights_train.npz)
+  train_agent.npz  the whole training forward with rewards / terminals / actions (weights_train_agent.npz)
   decode.npz       VideoTokenizer.decode of a reference tokenizer (weights_decode.npz = the decoder half of its state_dict): two flow steps
 """
 from __future__ import annotations
@@ -446,6 +447,60 @@ def gen_train():
     np.savez(os.path.join(OUT, 'train.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
 
 
+CFG_TRAIN_AGENT = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=3, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                       num_discrete_actions=(4, 3), num_tasks=0, reward_num_bins=11, value_num_bins=11, multi_token_pred_len=2, max_steps=16)
+
+
+def gen_train_agent():
+    """train_agent.npz / weights_train_agent.npz: the whole training forward (D4:6956-7743) with rewards, terminals and two discrete
+    action types, multi-token prediction length 2: flow / rewards / terminals / discrete-action losses, the total, and its gradient
+    with respect to every parameter; draws recorded as in `train`."""
+    D4 = load_reference()
+    cfg = Config(**CFG_TRAIN_AGENT)
+    m = build_reference_model(cfg, seed=73, head_scale=False)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(10.)
+        for p in m.to_reward_pred.parameters():
+            if p.ndim == 3: p.mul_(3.)
+    save_weights('weights_train_agent.npz', weights_of(m), CFG_TRAIN_AGENT)
+    g = torch.Generator().manual_seed(74)
+    B, T = 3, 5
+    lat = torch.randn(B, T, 6, 8, generator=g).clamp(-2, 2)
+    acts = torch.stack([torch.randint(0, 4, (B, T), generator=g), torch.randint(0, 3, (B, T), generator=g)], -1)
+    rew = torch.randn(B, T, generator=g) * 2.
+    term = torch.rand(B, T, generator=g) < 0.3
+    out = dict(latents=npy(lat), actions=npy(acts), rewards=npy(rew), terminals=npy(term))
+    rec = {}
+    saved = (D4.randint, D4.randn_like)
+
+    def rec_randint(*a, **k):
+        r = saved[0](*a, **k); rec.setdefault('randint', []).append(r.clone()); return r
+
+    def rec_randn_like(*a, **k):
+        r = saved[1](*a, **k); rec.setdefault('randn_like', []).append(r.clone()); return r
+
+    D4.randint, D4.randn_like = rec_randint, rec_randn_like
+    m.prob_shortcut_train = 1.
+    try:
+        m.zero_grad()
+        total, losses = m(latents=lat, discrete_actions=acts, rewards=rew, terminals=term, seed=9, return_all_losses=True)
+    finally:
+        D4.randint, D4.randn_like = saved
+    total.backward()
+    step_log2, sig_raw = rec['randint']
+    sig = sig_raw // (2 ** step_log2)[:, None] * (2 ** step_log2)[:, None]
+    out.update(step_sizes_log2=npy(step_log2), signal_levels=npy(sig), noise=npy(rec['randn_like'][0][:, :, 0]))
+    out.update(total=npy(total), flow_loss=npy(losses.flow), shortcut_loss=npy(losses.shortcut), rewards_loss=npy(losses.rewards),
+               terminals_loss=npy(losses.terminals), discrete_actions_loss=npy(losses.discrete_actions))
+    ng = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None and p.numel() > 0 and float(p.grad.abs().max()) > 0:
+            out[f'grad/{k}'] = npy(p.grad); ng += 1
+    print('train_agent total', float(total), 'flow', float(losses.flow), 'shortcut', float(losses.shortcut), 'rewards', losses.rewards.tolist(),
+          'terminals', float(losses.terminals), 'actions', losses.discrete_actions.tolist(), 'grads', ng)
+    np.savez(os.path.join(OUT, 'train_agent.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+
+
 CFG_SYMEXP = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
                   num_discrete_actions=(4,), num_tasks=0, reward_num_bins=41, value_num_bins=31, reward_range=(-3., 3.), value_range=(-4., 4.),
                   multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1, reward_encoder_type='symexp_two_hot')
@@ -472,7 +527,7 @@ def gen_symexp():
     print('symexp margin', out['cached_margin'], 'lens', out['cached_lens'], 'values', out['cached_values'][0])
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train)
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent)
 
 
 def main():

@@ -667,6 +667,68 @@ def value_head_bins(cfg, W, agent_embed):
     return mlp(W, 'value_head.', agent_embed, mlp_num_layers(cfg.value_head_mlp_depth), cfg.head_mlp_recipe)
 
 
+# ----------------------------------------------------------------------------- dynamics training losses (agent token)
+
+def mtp_targets(t, steps):
+    """create_multi_token_prediction_targets D4:530-552: t (b, n, ...) -> (b, n, steps, ...), mask (b, n, steps); out-of-range -> index 0."""
+    n = t.shape[1]
+    idx = torch.arange(n)[:, None] + torch.arange(steps)[None, :]
+    mask = idx < n
+    idx = idx.masked_fill(~mask, 0)
+    return t[:, idx], mask[None].expand(t.shape[0], -1, -1)
+
+
+def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, actions=None, terminals=None):
+    """The agent-token losses of the training forward (D4:7432-7598): multi-token-prediction reward cross entropy against the
+    encoder's soft targets, terminal BCE with DreamerV3 label smoothing, behaviour-cloning log-likelihood of the discrete actions
+    (multi-token prediction, `shift_action_tokens=True`).  agent_embed (b, t, d) from the main prediction; rewards (b, t); actions
+    (b, t, na) int64; terminals (b, t) bool.  Returns dict(rewards=(mtp,), terminals=(), discrete_actions=(mtp,)) for what was given."""
+    out = {}
+    b, t = agent_embed.shape[:2]
+    mtp = cfg.multi_token_pred_len
+    if rewards is not None:
+        if cfg.reward_encoder_type == 'symexp_two_hot':
+            two_hot = symexp_two_hot(rewards, cfg.reward_range, cfg.reward_num_bins)
+        else:
+            two_hot = hl_gauss_to_probs(cfg, rewards, cfg.reward_range, cfg.reward_num_bins)
+        x = agent_embed[:, :-1]                                                            # each agent token predicts the NEXT rewards
+        pred = torch.stack([rmsnorm(x, W['to_reward_pred.params.0'][i]) @ W['to_reward_pred.params.1'][i].t() for i in range(mtp)], dim=2)   # b t-1 mtp l
+        tgt, mask = mtp_targets(two_hot[:, 1:], mtp)                                       # b t-1 mtp l
+        losses = -(tgt * pred.log_softmax(dim=-1)).sum(dim=-1).masked_fill(~mask, 0.)
+        out['rewards'] = losses.mean(dim=(0, 1))                                           # D4:7463: mean INCLUDES the masked zeros
+    if terminals is not None and cfg.predict_terminals:
+        pooled = latents[:, 1:].mean(dim=-2)
+        logit = mlp(W, 'to_state_terminal_pred.0.', pooled, mlp_num_layers(cfg.terminal_mlp_depth), cfg.head_mlp_recipe).squeeze(-1)
+        eps = 1. - cfg.gae_discount_factor
+        tgt = terminals[:, 1:].float().clamp(min=eps, max=1. - eps)                        # D4:7481-7484
+        out['terminals'] = F.binary_cross_entropy_with_logits(logit, tgt)
+    if actions is not None and t > 1:
+        padded = F.pad(actions, (0, 0, 1, 0), value=-1)                                    # sentinel, D4:7540
+        tgt, mask = mtp_targets(padded, mtp)
+        tgt, mask = tgt[:, 1:], mask[:, 1:]                                                # b t mtp na
+        pe = policy_head(cfg, W, agent_embed[:, :padded.shape[1] - 1])
+        per = []
+        for i in range(mtp):
+            logits = pe @ W['action_embedder.discrete_action_unembed'][:, i].t()
+            lp = discrete_log_probs(cfg, logits, tgt[:, :, i].clamp(min=0))
+            per.append((-lp).masked_fill(~mask[:, :, i, None], 0.).mean())
+        out['discrete_actions'] = torch.stack(per)
+    return out
+
+
+def dynamics_training_losses(cfg: Config, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=None, rewards=None,
+                             terminals=None, tasks=None):
+    """Everything DynamicsWorldModel.forward returns in training for the supported subset (D4:6956-7743): flow, shortcut, rewards,
+    terminals, discrete_actions and the total of D4:7708-7723 with unit loss weights (the reference defaults)."""
+    times = signal_levels.float() / cfg.max_steps
+    noised = noise.lerp(latents, times[:, :, None, None])
+    _, agent_embed, _ = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks)
+    flow, short = dynamics_flow_losses(cfg, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=actions, tasks=tasks)
+    out = dict(flow=flow, shortcut=short, **dynamics_agent_losses(cfg, W, agent_embed, latents, rewards, actions, terminals))
+    out['total'] = sum(v.sum() for v in out.values())
+    return out
+
+
 # ----------------------------------------------------------------------------- generate
 
 def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, tasks=None,

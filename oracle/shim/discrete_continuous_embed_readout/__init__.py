@@ -36,7 +36,9 @@ class MultiCategorical:
             lp = l.log_softmax(dim = -1)
             t = targets[..., i]
             t = t.expand(lp.shape[:-1]) if t.shape != lp.shape[:-1] else t
-            out.append(lp.gather(-1, t[..., None]).squeeze(-1))
+            # negative targets are the reference's padding sentinel (D4:7540): every such position is masked out by the caller afterwards,
+            # so any in-range index is equivalent there (ASSUMED: the published package does not raise on them)
+            out.append(lp.gather(-1, t.clamp(min = 0)[..., None]).squeeze(-1))
         return torch.stack(out, dim = -1)
 
     def entropy(self):

@@ -229,7 +229,7 @@ def test_world_model_training_forward_matches_the_fixture_and_trains():
     g = load_golden('train.npz')
     m = golden_model('weights_train.npz').cuda()
     draws = dict(shortcut_train=True, step_sizes_log2=t(g['shortcut_step_sizes_log2']), signal_levels=t(g['shortcut_signal_levels']), noise=t(g['shortcut_noise']))
-    total, (fl, sl) = m(latents=t(g['latents']), discrete_actions=t(g['actions']), return_all_losses=True, draws=draws)
+    total, (fl, sl, *_) = m(latents=t(g['latents']), discrete_actions=t(g['actions']), return_all_losses=True, draws=draws, add_autoregressive_action_loss=False)
     close(fl, t(g['shortcut_flow_loss']), 'flow', tol=1e-5)
     close(total, t(g['shortcut_flow_loss']) + t(g['shortcut_shortcut_loss']), 'total', tol=1e-5)
     total.backward()
@@ -240,7 +240,7 @@ def test_world_model_training_forward_matches_the_fixture_and_trains():
             close(own[k[14:]].grad, t(g[k]), 'd ' + k[14:], tol=1e-3); n += 1
     assert n >= 90
     with pytest.raises(NotImplementedError):
-        m(latents=t(g['latents']), rewards=torch.zeros(3, 4))
+        m(latents=t(g['latents']), lens=torch.tensor([4, 3, 2]))
     # a short optimisation on a fixed batch of "data" latents, fresh draws every step
     trunk = [p for k, p in m.named_parameters() if p.grad is not None]
     opt = torch.optim.AdamW(trunk, lr=3e-3, weight_decay=0.)
@@ -249,13 +249,38 @@ def test_world_model_training_forward_matches_the_fixture_and_trains():
     first = last = None
     for step in range(40):
         opt.zero_grad(set_to_none=True)
-        loss = m(latents=lat, discrete_actions=t(g['actions']), generator=gen)
+        loss = m(latents=lat, discrete_actions=t(g['actions']), generator=gen, add_autoregressive_action_loss=False)
         loss.backward()
         opt.step()
         m.invalidate_prepared()
         last = loss.item()
         first = first if first is not None else last
     assert last < 0.7 * first, (first, last)
+
+
+def test_world_model_training_forward_with_rewards_terminals_and_actions_vs_reference_fixture():
+    """train_agent.npz: the reference's whole training forward (rewards, terminals, two discrete action types, multi-token prediction 2)
+    through the mirror: every loss term, the total, and the gradient of the total on 134 parameters."""
+    from util import golden_model, load_golden, t
+    g = load_golden('train_agent.npz')
+    m = golden_model('weights_train_agent.npz').cuda()
+    draws = dict(shortcut_train=True, step_sizes_log2=t(g['step_sizes_log2']), signal_levels=t(g['signal_levels']), noise=t(g['noise']))
+    total, L = m(latents=t(g['latents']), discrete_actions=t(g['actions']), rewards=t(g['rewards']), terminals=t(g['terminals']),
+                 return_all_losses=True, draws=draws)
+    close(L.flow, t(g['flow_loss']), 'flow', tol=1e-5); close(L.rewards, t(g['rewards_loss']), 'rewards', tol=1e-5)
+    close(L.terminals, t(g['terminals_loss']), 'terminals', tol=1e-5); close(L.discrete_actions, t(g['discrete_actions_loss']), 'actions', tol=1e-5)
+    close(total, t(g['total']), 'total', tol=1e-5)
+    total.backward()
+    own = dict(m.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('grad/'):
+            assert own[k[5:]].grad is not None, k
+            close(own[k[5:]].grad, t(g[k]), 'd ' + k[5:], tol=1e-3); n += 1
+    assert n >= 130
+    # rewards / terminals given without their first frame are left-padded as the reference does (dreamer4.py:6905-6911)
+    total2 = m(latents=t(g['latents']), discrete_actions=t(g['actions']), rewards=t(g['rewards'])[:, 1:], terminals=t(g['terminals'])[:, 1:], draws=draws)
+    close(total2, total, 'total with t-1 rewards', tol=1e-6)
 
 
 def test_blocks_compose_with_torch_autograd():
