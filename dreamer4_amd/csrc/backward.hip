@@ -1,11 +1,15 @@
-// Trunk backward, first slice (SURVEY.md 8f-3 groundwork): the FeedForward block (D4:2079-2116) and the space-attention block
-// (Attention.forward D4:1968-2075 in its self-attention form: RMSNorm, q/k/v, learned value-residual mix, K-head-RMSNorm, soft clamp,
-// special-token mask, belief projection, head gates, to_out) as forward + backward operators on the REFERENCE parameter layout, so they
-// can be checked directly against autograd of the oracle's restatement (tests/test_gpu_backward.py).
+// Trunk backward: the blocks of the AxialSpaceTimeTransformer as forward + backward operators on the REFERENCE parameter
+// layout — FeedForward (D4:2079-2116) and Attention.forward (D4:1968-2075) in its three uses: within-frame self attention (RMSNorm, q/k/v,
+// learned value-residual mix, K-head-RMSNorm, soft clamp, special-token mask, belief projection, head gates, to_out), time attention (the
+// same with rotary positions and a causal mask, one problem per token column), and attention over a context (attention pools over the
+// stack of layer hiddens, the special tokens' cross attention, learned-query pools) — so that each can be checked directly against
+// autograd of the oracle's restatement (tests/test_gpu_backward.py) and composed into the dynamics training forward
+// (dreamer4_amd/trunk_ops.py: D4:6956-7743).
 //
-// The matrix work is the engine's fp32 MFMA GEMM (transposed-operand forms for dX / dW); what is new here is the attention-core
-// backward kernel (one block per (frame, head), everything for <= 32 tokens in LDS) and the SiLU-GLU / RMSNorm backward glue.
-// Nothing here is called by the imagination path; the dynamics training branch (D4:7297-7431) is the consumer to come.
+// The matrix work is the engine's fp32 MFMA GEMM (transposed-operand forms for dX, split-K for dW); what is new here are the two
+// attention-core backward kernels (one block per (group, head), everything for <= 32 / 64 items in LDS) and the SiLU-GLU / RMSNorm
+// backward glue.  Every backward recomputes its forward: only the block inputs are kept between the two passes.  Nothing here is called
+// by the imagination path.
 #include "common.h"
 #include "kernels.h"
 #include "../../include/d4hip.h"

@@ -1,11 +1,13 @@
-"""Differentiable trunk blocks on the HIP kernels — the first slice of the trunk backward (SURVEY.md 8f-3 groundwork).
+"""Differentiable trunk blocks on the HIP kernels and the dynamics training forward composed from them.
 
-`feedforward` is the reference FeedForward (dreamer4/dreamer4.py:2079-2116) and `space_attention` the reference Attention in its
-within-frame self-attention form (dreamer4.py:1968-2075) as `torch.autograd.Function`s over the C-ABI operators
-`d4_ff_forward / d4_ff_backward` and `d4_space_attn_forward / d4_space_attn_backward` (include/d4hip.h).  Parameters are passed in the
-reference's own layout (the tensors of its state_dict), gradients come back in the same layout, and the backward recomputes the
-forward intermediates, so nothing but the inputs is kept alive between the two passes.  fp32, HIP device only — there is no CPU
-fallback.  Not used by the imagination path; the dynamics training branch (dreamer4.py:7297-7431) is the consumer to come."""
+`feedforward`, `space_attention`, `time_attention` and `cross_attention` are the reference FeedForward (dreamer4/dreamer4.py:2079-2116)
+and Attention (dreamer4.py:1968-2075: within a frame, along time with rotary + causal mask, over a context) as
+`torch.autograd.Function`s over the C-ABI operators `d4_ff_* / d4_space_attn_* / d4_time_attn_* / d4_cross_attn_*` (include/d4hip.h).
+Parameters are passed in the reference's own layout (the tensors of its state_dict), gradients come back in the same layout, and the
+backward recomputes the forward intermediates, so nothing but the inputs is kept alive between the two passes.  `transformer` composes
+the AxialSpaceTimeTransformer (dreamer4.py:2927-3267), `world_model_prediction` the dynamics model's `get_prediction`
+(dreamer4.py:7156-7287), `dynamics_flow_losses` / `dynamics_agent_losses` the losses of the training forward (dreamer4.py:7335-7598).
+fp32, HIP device only — there is no CPU fallback.  Not used by the imagination path."""
 from __future__ import annotations
 
 import ctypes as C
