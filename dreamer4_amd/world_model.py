@@ -108,6 +108,8 @@ class TimeCache:
 # buffers the engine never reads (key parity with the reference's state_dict only)
 _NOT_BOUND = {'zero', 'ema_returns_mean', 'ema_returns_var', 'reward_loss_weight', 'terminal_loss_weight',
               'discrete_action_loss_weight', 'continuous_action_loss_weight'}
+_LOSS_NORMALIZERS = ('flow_loss_normalizer', 'shortcut_flow_loss_normalizer', 'reward_loss_normalizer', 'state_terminal_loss_normalizer',
+                     'discrete_actions_loss_normalizer', 'continuous_actions_loss_normalizer')
 
 _UNSUPPORTED_DEFAULTS = dict(
     aux_image_encoder=None, num_agents=1, num_video_views=1, mot_temporal=False,
@@ -164,6 +166,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         policy_entropy_weight=.01,
         head_mlp_recipe='pre_rms',
         matmul_dtype='fp32',
+        use_loss_normalization=False,
         **kwargs,
     ):
         """`head_mlp_recipe` is not a reference argument: it names the layer recipe of x_mlps_pytorch's normed MLP (see MLP_RECIPES)."""
@@ -178,6 +181,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         if matmul_dtype not in ('fp32', 'bf16'):
             raise ValueError("matmul_dtype must be 'fp32' or 'bf16'")
         self.matmul_dtype = matmul_dtype
+        self.use_loss_normalization = bool(use_loss_normalization)
         for k, v in kwargs.items():
             if k not in _UNSUPPORTED_DEFAULTS:
                 raise TypeError(f'unknown argument {k!r}')
@@ -356,6 +360,26 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         for name, val in (('ema_returns_mean', 0.), ('ema_returns_var', 1.), ('reward_loss_weight', 1.), ('terminal_loss_weight', 1.),
                           ('discrete_action_loss_weight', 1.), ('continuous_action_loss_weight', 1.)):
             _register(self, name, torch.tensor(val), buffer=True)
+        # LossNormalizer state of the training forward (dreamer4.py:629-669, 5250-5255): running mean of the squared loss per term
+        if self.use_loss_normalization:
+            mtp = self.multi_token_pred_len
+            for name, n, on in (('flow_loss_normalizer', 1, True), ('shortcut_flow_loss_normalizer', 1, True), ('reward_loss_normalizer', mtp, True),
+                                ('state_terminal_loss_normalizer', 1, self.predict_terminals),
+                                ('discrete_actions_loss_normalizer', mtp, len(self.num_discrete_actions) > 0),
+                                ('continuous_actions_loss_normalizer', mtp, self.num_continuous_actions > 0)):
+                if on:
+                    _register(self, name + '.exp_avg_sq', torch.ones(n), buffer=True)
+
+    def _normalize_loss(self, name, loss, update_ema, beta=0.95, eps=1e-6):
+        """LossNormalizer.forward (dreamer4.py:645-669): divide by the root of the running mean square (taken BEFORE this call's update)."""
+        if not self.use_loss_normalization or not hasattr(self, name):
+            return loss
+        buf = getattr(self, name).exp_avg_sq
+        rms = buf.sqrt()
+        if update_ema:
+            with torch.no_grad():
+                buf.lerp_(loss.detach().reshape(buf.shape).square(), 1. - beta)
+        return loss / rms.clamp(min=eps).reshape(loss.shape)
 
     @property
     def device(self):
@@ -513,7 +537,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
                 grads[id(p)] = g['grad'][off:off + p.numel()]
                 off += p.numel()
         tensors = dict(self.named_parameters())
-        tensors.update({k: v for k, v in self.named_buffers() if k not in _NOT_BOUND})
+        tensors.update({k: v for k, v in self.named_buffers() if k not in _NOT_BOUND and not k.startswith(_LOSS_NORMALIZERS)})
         sig = tuple((k, t.data_ptr(), t.numel()) for k, t in tensors.items())
         if sig != self._bound_sig:
             for k, t in tensors.items():
@@ -593,7 +617,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         WorldModelLosses(flow, shortcut, rewards, terminals, discrete_actions))`): flow + shortcut, and — when `rewards` / `terminals` /
         `discrete_actions` are given — the multi-token-prediction reward, terminal and behaviour-cloning losses (dreamer4.py:7432-7598);
         differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py).  Not implemented: lens, proprio, continuous-action
-        behaviour cloning, loss normalisers."""
+        behaviour cloning.  `use_loss_normalization=True` (constructor) applies the reference's LossNormalizer per term."""
         if signal_levels is None and step_sizes is None:
             return self._training_forward(latents, discrete_actions, continuous_actions, tasks, **kwargs)
         with torch.no_grad():
@@ -652,13 +676,14 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         return pred, (agent, tc)
 
     def _training_forward(self, latents, discrete_actions, continuous_actions, tasks, *, return_all_losses=False, seed=None, generator=None,
-                          add_autoregressive_action_loss=True, prob_shortcut_train=None, draws=None, rewards=None, terminals=None, **kwargs):
+                          add_autoregressive_action_loss=True, prob_shortcut_train=None, draws=None, rewards=None, terminals=None,
+                          update_loss_ema=None, **kwargs):
         """Training branch: flow loss (x-space, ramp weight) + shortcut consistency loss (dreamer4.py:6956-7003, 7335-7431) + the
         agent-token losses (dreamer4.py:7432-7598) + total (dreamer4.py:7708-7723).
         `draws` = dict(shortcut_train, step_sizes_log2, signal_levels, noise) injects the random draws (parity runs); otherwise they
         come from `generator` (or a generator seeded with `seed`, as the reference's `seed=`)."""
         from dreamer4_amd import trunk_ops
-        unsupported = {k: v for k, v in kwargs.items() if v is not None and k not in ('update_loss_ema',)}
+        unsupported = {k: v for k, v in kwargs.items() if v is not None}
         if unsupported:
             raise NotImplementedError(f'training forward: {sorted(unsupported)} is not implemented (lens / proprio / video / aug / genes are outside the built slice)')
         if continuous_actions is not None and add_autoregressive_action_loss:
@@ -714,6 +739,13 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
             reward_range=self.reward_range, reward_num_bins=self.reward_num_bins, policy_head_mlp_depth=self.policy_head_mlp_depth,
             terminal_mlp_depth=self.terminal_mlp_depth, head_mlp_recipe=self.head_mlp_recipe, gae_discount_factor=self.gae_discount_factor,
             hl_sigma_ratio=self.hl_sigma_ratio, hl_eps=self.hl_eps, rewards=rew, discrete_actions=da, terminals=term)
+        upd = self.training if update_loss_ema is None else bool(update_loss_ema)                           # dreamer4.py:7637-7654
+        flow = self._normalize_loss('flow_loss_normalizer', flow, upd)
+        short = self._normalize_loss('shortcut_flow_loss_normalizer', short, upd)
+        for key, name in (('rewards', 'reward_loss_normalizer'), ('terminals', 'state_terminal_loss_normalizer'),
+                          ('discrete_actions', 'discrete_actions_loss_normalizer')):
+            if key in agent:
+                agent[key] = self._normalize_loss(name, agent[key], upd)
         # unit loss weights: the reference defaults (dreamer4.py:4719-4725, 7708-7723)
         total = flow + short + sum(v.sum() for v in agent.values())
         if not return_all_losses:

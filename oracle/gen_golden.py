@@ -496,6 +496,16 @@ def gen_train_agent():
     for k, p in m.named_parameters():
         if p.grad is not None and p.numel() > 0 and float(p.grad.abs().max()) > 0:
             out[f'grad/{k}'] = npy(p.grad); ng += 1
+    # the same forward with loss normalisation (D4:629-669, 5250-5255): two consecutive calls, the running mean squares evolve
+    mtp = cfg.multi_token_pred_len
+    m.flow_loss_normalizer, m.shortcut_flow_loss_normalizer = D4.LossNormalizer(), D4.LossNormalizer()
+    m.reward_loss_normalizer, m.state_terminal_loss_normalizer = D4.LossNormalizer(mtp), D4.LossNormalizer()
+    m.discrete_actions_loss_normalizer = D4.LossNormalizer(mtp)
+    for call in range(2):
+        t_, l_ = m(latents=lat, discrete_actions=acts, rewards=rew, terminals=term, seed=9, return_all_losses=True, update_loss_ema=True)
+        out[f'norm{call}_total'] = npy(t_)
+        out[f'norm{call}_terms'] = npy(torch.cat([l_.flow.reshape(1), l_.shortcut.reshape(1), l_.rewards, l_.terminals.reshape(1), l_.discrete_actions]))
+    out['norm_state_flow'] = npy(m.flow_loss_normalizer.exp_avg_sq); out['norm_state_rewards'] = npy(m.reward_loss_normalizer.exp_avg_sq)
     print('train_agent total', float(total), 'flow', float(losses.flow), 'shortcut', float(losses.shortcut), 'rewards', losses.rewards.tolist(),
           'terminals', float(losses.terminals), 'actions', losses.discrete_actions.tolist(), 'grads', ng)
     np.savez(os.path.join(OUT, 'train_agent.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})

@@ -716,15 +716,30 @@ def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, ac
     return out
 
 
+def loss_normalize(state, name, loss, update, beta=0.95, eps=1e-6):
+    """LossNormalizer.forward D4:645-669: loss / sqrt(exp_avg_sq) with the rms taken before the EMA update.  state: {name: exp_avg_sq}."""
+    if state is None or name not in state:
+        return loss
+    rms = state[name].sqrt()
+    if update:
+        state[name] = torch.lerp(state[name], loss.detach().reshape(state[name].shape).square(), 1. - beta)
+    return loss / rms.clamp(min=eps).reshape(loss.shape)
+
+
 def dynamics_training_losses(cfg: Config, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=None, rewards=None,
-                             terminals=None, tasks=None):
+                             terminals=None, tasks=None, normalizers=None, update_loss_ema=True):
     """Everything DynamicsWorldModel.forward returns in training for the supported subset (D4:6956-7743): flow, shortcut, rewards,
-    terminals, discrete_actions and the total of D4:7708-7723 with unit loss weights (the reference defaults)."""
+    terminals, discrete_actions and the total of D4:7708-7723 with unit loss weights (the reference defaults); `normalizers`: the
+    LossNormalizer buffers by module name when `use_loss_normalization` (updated in place in the dict)."""
     times = signal_levels.float() / cfg.max_steps
     noised = noise.lerp(latents, times[:, :, None, None])
     _, agent_embed, _ = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks)
     flow, short = dynamics_flow_losses(cfg, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=actions, tasks=tasks)
     out = dict(flow=flow, shortcut=short, **dynamics_agent_losses(cfg, W, agent_embed, latents, rewards, actions, terminals))
+    for key, name in (('flow', 'flow_loss_normalizer'), ('shortcut', 'shortcut_flow_loss_normalizer'), ('rewards', 'reward_loss_normalizer'),
+                      ('terminals', 'state_terminal_loss_normalizer'), ('discrete_actions', 'discrete_actions_loss_normalizer')):
+        if key in out:                                                                     # D4:7637-7654 (`normalizers`: {name: exp_avg_sq})
+            out[key] = loss_normalize(normalizers, name, out[key], update_loss_ema)
     out['total'] = sum(v.sum() for v in out.values())
     return out
 

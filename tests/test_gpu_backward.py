@@ -283,6 +283,22 @@ def test_world_model_training_forward_with_rewards_terminals_and_actions_vs_refe
     close(total2, total, 'total with t-1 rewards', tol=1e-6)
 
 
+def test_world_model_training_forward_with_loss_normalisation_vs_reference_fixture():
+    """train_agent.npz norm* keys: `use_loss_normalization=True`, two consecutive calls with the EMA updating."""
+    from util import golden_model, load_golden, t
+    g = load_golden('train_agent.npz')
+    m = golden_model('weights_train_agent.npz', use_loss_normalization=True).cuda()
+    draws = dict(shortcut_train=True, step_sizes_log2=t(g['step_sizes_log2']), signal_levels=t(g['signal_levels']), noise=t(g['noise']))
+    for call in range(2):
+        total, L = m(latents=t(g['latents']), discrete_actions=t(g['actions']), rewards=t(g['rewards']), terminals=t(g['terminals']),
+                     return_all_losses=True, draws=draws, update_loss_ema=True)
+        terms = torch.cat([L.flow.reshape(1), L.shortcut.reshape(1), L.rewards, L.terminals.reshape(1), L.discrete_actions])
+        close(terms, t(g[f'norm{call}_terms']), f'terms of call {call}', tol=2e-5); close(total.reshape(1), t(g[f'norm{call}_total']), 'total', tol=2e-5)
+    close(m.reward_loss_normalizer.exp_avg_sq, t(g['norm_state_rewards']), 'running mean squares', tol=1e-4)
+    total.backward()                                                 # the normalised total is differentiable like the plain one
+    assert m.get_parameter('transformer.layers.0.2.fn.to_q.weight').grad.abs().max().item() > 0
+
+
 def test_blocks_compose_with_torch_autograd():
     """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
     g = torch.Generator().manual_seed(11)

@@ -161,3 +161,25 @@ def test_save_load_and_init_and_load(tmp_path):
     tok.save(tmp_path / 'tok.pt')
     tok2 = VideoTokenizer.init_and_load(tmp_path / 'tok.pt')
     assert tok2.image_height == 16 and torch.equal(tok2.state_dict()['latents_to_decoder.weight'], tok.state_dict()['latents_to_decoder.weight'])
+
+
+def test_loss_normalizer_state_and_beta_zero_property():
+    """The training forward's LossNormalizer (reference tests/test_dreamer.py:558-569): with beta = 0 the second call of the same loss
+    returns exactly 1; buffers carry the reference's state_dict keys only when `use_loss_normalization=True`."""
+    import torch
+    from dreamer4_amd import DynamicsWorldModel
+    kw = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, num_discrete_actions=4, multi_token_pred_len=2)
+    plain = DynamicsWorldModel(**kw)
+    assert not any('loss_normalizer' in k for k in plain.state_dict())
+    m = DynamicsWorldModel(**kw, use_loss_normalization=True)
+    keys = {k for k in m.state_dict() if 'loss_normalizer' in k}
+    assert keys == {'flow_loss_normalizer.exp_avg_sq', 'shortcut_flow_loss_normalizer.exp_avg_sq', 'reward_loss_normalizer.exp_avg_sq',
+                    'state_terminal_loss_normalizer.exp_avg_sq', 'discrete_actions_loss_normalizer.exp_avg_sq'}
+    assert m.state_dict()['reward_loss_normalizer.exp_avg_sq'].shape == (2,)
+    loss = torch.tensor([3., 0.5])
+    first = m._normalize_loss('reward_loss_normalizer', loss, True, beta=0.)
+    assert torch.equal(first, loss)                                  # initial running mean square is 1
+    second = m._normalize_loss('reward_loss_normalizer', loss, True, beta=0.)
+    assert torch.allclose(second, torch.ones(2))
+    frozen = m._normalize_loss('flow_loss_normalizer', torch.tensor(2.), False)
+    assert frozen.item() == 2. and m.flow_loss_normalizer.exp_avg_sq.item() == 1.
