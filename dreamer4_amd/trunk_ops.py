@@ -353,7 +353,7 @@ def world_model_prediction(W, noised_latents, signal_levels, step_sizes_log2, *,
     return F.linear(x, W['to_latent_pred.2.weight']), agent_embed
 
 
-def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, *, max_steps, return_agent_embed=False, **model):
+def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, *, max_steps, return_agent_embed=False, lens=None, **model):
     """The flow and shortcut-consistency losses of the dynamics training forward (dreamer4.py:6990-7003, 7335-7431; x-space prediction,
     ramp loss weight, no proprio / variable lengths / loss normalisers: the reference defaults).  `model`: the keyword arguments of
     `world_model_prediction`.  Returns (flow_loss, shortcut_loss[, agent_embed of the main prediction]); backward runs through the HIP blocks."""
@@ -363,8 +363,14 @@ def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shor
     noised = noise.lerp(latents, tt)
     pred, agent_embed = world_model_prediction(W, noised, signal_levels, step_sizes_log2, **model)
     flow_losses = F.mse_loss(pred, latents, reduction='none') * (0.9 * times + 0.1)[:, :, None, None]
+    if lens is not None:                                  # variable lengths: frames past a trajectory's length leave the means (dreamer4.py:7418-7426)
+        lm = torch.arange(latents.shape[1], device=latents.device)[None, :] < lens[:, None]
+        sel = lambda x: x[lm]
+    else:
+        sel = lambda x: x
     if not shortcut_train:
-        return (flow_losses.mean(), latents.new_zeros(()), agent_embed) if return_agent_embed else (flow_losses.mean(), latents.new_zeros(()))
+        fl = sel(flow_losses).mean()
+        return (fl, latents.new_zeros(()), agent_embed) if return_agent_embed else (fl, latents.new_zeros(()))
     with torch.no_grad():
         half_log2 = step_sizes_log2 - 1
         half = 2 ** half_log2
@@ -377,7 +383,8 @@ def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shor
         target = (first_flow + second_flow) / 2
     shortcut_pred = (pred - noised) / (1. - tt)
     shortcut_losses = F.mse_loss(shortcut_pred, target, reduction='none') * (1. - tt) ** 2
-    return (flow_losses.mean(), shortcut_losses.mean(), agent_embed) if return_agent_embed else (flow_losses.mean(), shortcut_losses.mean())
+    fl, sh = sel(flow_losses).mean(), sel(shortcut_losses).mean()
+    return (fl, sh, agent_embed) if return_agent_embed else (fl, sh)
 
 
 # ------------------------------------------------------------------------------------------------ agent-token losses of the training forward
@@ -419,7 +426,7 @@ def hl_gauss_probs(values, vrange, num_bins, sigma_to_bin_ratio=2., eps=1e-10):
 
 def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_discrete_actions, reward_range, reward_num_bins,
                           policy_head_mlp_depth, terminal_mlp_depth, head_mlp_recipe='pre_rms', gae_discount_factor=0.997,
-                          hl_sigma_ratio=2., hl_eps=1e-10, rewards=None, discrete_actions=None, terminals=None):
+                          hl_sigma_ratio=2., hl_eps=1e-10, rewards=None, discrete_actions=None, terminals=None, lens=None):
     """The agent-token losses of the training forward (dreamer4.py:7432-7598): multi-token-prediction reward cross entropy against HL-Gauss
     soft targets, terminal BCE with label smoothing, behaviour-cloning log-likelihood of the discrete actions (multi-token prediction,
     `shift_action_tokens=True`).  Plain torch ops on the device (the heads are three small MLPs on (b, t) rows); their gradients reach the
@@ -429,18 +436,20 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
     mtp = multi_token_pred_len
     eps = torch.finfo(torch.float32).eps
     t = agent_embed.shape[1]
+    lm = (torch.arange(t, device=agent_embed.device)[None, :] < lens[:, None]) if lens is not None else None     # dreamer4.py:7418-7423
     if rewards is not None:
         two_hot = hl_gauss_probs(rewards, reward_range, reward_num_bins, hl_sigma_ratio, hl_eps)
         x = agent_embed[:, :-1]
         pred = torch.stack([F.linear(F.rms_norm(x, x.shape[-1:], W['to_reward_pred.params.0'][i], eps), W['to_reward_pred.params.1'][i]) for i in range(mtp)], dim=2)
         tgt, mask = _mtp_targets(two_hot[:, 1:], mtp)
         losses = -(tgt * pred.log_softmax(dim=-1)).sum(dim=-1).masked_fill(~mask, 0.)
-        out['rewards'] = losses.mean(dim=(0, 1))
+        out['rewards'] = losses[lm[:, :-1]].mean(dim=0) if lm is not None else losses.mean(dim=(0, 1))
     if terminals is not None:
         pooled = latents[:, 1:].mean(dim=-2)
         logit = _head_mlp(W, 'to_state_terminal_pred.0.', pooled, terminal_mlp_depth + 2, head_mlp_recipe).squeeze(-1)
         e = 1. - gae_discount_factor
-        out['terminals'] = F.binary_cross_entropy_with_logits(logit, terminals[:, 1:].float().clamp(min=e, max=1. - e))
+        tl = F.binary_cross_entropy_with_logits(logit, terminals[:, 1:].float().clamp(min=e, max=1. - e), reduction='none')
+        out['terminals'] = tl[lm[:, :-1]].mean() if lm is not None else tl.mean()
     if discrete_actions is not None and t > 1:
         padded = F.pad(discrete_actions, (0, 0, 1, 0), value=-1)
         tgt, mask = _mtp_targets(padded, mtp)
@@ -454,6 +463,7 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
                 lp = logits[..., o:o + n].log_softmax(dim=-1)
                 lps.append(lp.gather(-1, tgt[:, :, i, a:a + 1]).squeeze(-1))
                 o += n
-            per.append((-torch.stack(lps, dim=-1)).masked_fill(~mask[:, :, i, None], 0.).mean())
+            nl = (-torch.stack(lps, dim=-1)).masked_fill(~mask[:, :, i, None], 0.)
+            per.append(nl[lm].mean() if lm is not None else nl.mean())
         out['discrete_actions'] = torch.stack(per)
     return out

@@ -616,7 +616,8 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         reference does (dreamer4.py:6956-7003) and returns the total loss of dreamer4.py:7708-7723 (`return_all_losses=True`: `(total,
         WorldModelLosses(flow, shortcut, rewards, terminals, discrete_actions))`): flow + shortcut, and — when `rewards` / `terminals` /
         `discrete_actions` are given — the multi-token-prediction reward, terminal and behaviour-cloning losses (dreamer4.py:7432-7598);
-        differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py).  Not implemented: lens, proprio, continuous-action
+        differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py); `lens` masks frames past each trajectory's length out of
+        every term.  Not implemented: proprio, continuous-action
         behaviour cloning.  `use_loss_normalization=True` (constructor) applies the reference's LossNormalizer per term."""
         if signal_levels is None and step_sizes is None:
             return self._training_forward(latents, discrete_actions, continuous_actions, tasks, **kwargs)
@@ -677,7 +678,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
 
     def _training_forward(self, latents, discrete_actions, continuous_actions, tasks, *, return_all_losses=False, seed=None, generator=None,
                           add_autoregressive_action_loss=True, prob_shortcut_train=None, draws=None, rewards=None, terminals=None,
-                          update_loss_ema=None, **kwargs):
+                          update_loss_ema=None, lens=None, **kwargs):
         """Training branch: flow loss (x-space, ramp weight) + shortcut consistency loss (dreamer4.py:6956-7003, 7335-7431) + the
         agent-token losses (dreamer4.py:7432-7598) + total (dreamer4.py:7708-7723).
         `draws` = dict(shortcut_train, step_sizes_log2, signal_levels, noise) injects the random draws (parity runs); otherwise they
@@ -685,7 +686,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         from dreamer4_amd import trunk_ops
         unsupported = {k: v for k, v in kwargs.items() if v is not None}
         if unsupported:
-            raise NotImplementedError(f'training forward: {sorted(unsupported)} is not implemented (lens / proprio / video / aug / genes are outside the built slice)')
+            raise NotImplementedError(f'training forward: {sorted(unsupported)} is not implemented (proprio / video / aug / genes are outside the built slice)')
         if continuous_actions is not None and add_autoregressive_action_loss:
             raise NotImplementedError('training forward: the continuous-action behaviour-cloning loss is not implemented (pass add_autoregressive_action_loss=False)')
         if self.reward_encoder_type != 'hl_gauss' and rewards is not None:
@@ -718,7 +719,8 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         W.update({k: v for k, v in self.named_buffers() if k.endswith('inv_freq')})
         is_time = [(i + 1) % self.time_block_every == 0 for i in range(self.depth)]
         flow, short, agent_embed = trunk_ops.dynamics_flow_losses(
-            W, lat, noise, sig, step_log2, shortcut, max_steps=self.max_steps, return_agent_embed=True, is_time=is_time, num_spatial_tokens=self.num_spatial_tokens,
+            W, lat, noise, sig, step_log2, shortcut, max_steps=self.max_steps, return_agent_embed=True,
+            lens=lens.to(dev) if lens is not None else None, is_time=is_time, num_spatial_tokens=self.num_spatial_tokens,
             num_register_tokens=self.num_register_tokens, num_discrete_actions=tuple(self.num_discrete_actions),
             discrete_actions=discrete_actions.to(dev).long() if discrete_actions is not None else None,
             continuous_actions=continuous_actions.to(dev).float() if continuous_actions is not None else None,
@@ -738,7 +740,8 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
             W, agent_embed, lat, multi_token_pred_len=self.multi_token_pred_len, num_discrete_actions=tuple(self.num_discrete_actions),
             reward_range=self.reward_range, reward_num_bins=self.reward_num_bins, policy_head_mlp_depth=self.policy_head_mlp_depth,
             terminal_mlp_depth=self.terminal_mlp_depth, head_mlp_recipe=self.head_mlp_recipe, gae_discount_factor=self.gae_discount_factor,
-            hl_sigma_ratio=self.hl_sigma_ratio, hl_eps=self.hl_eps, rewards=rew, discrete_actions=da, terminals=term)
+            hl_sigma_ratio=self.hl_sigma_ratio, hl_eps=self.hl_eps, rewards=rew, discrete_actions=da, terminals=term,
+            lens=lens.to(dev) if lens is not None else None)
         upd = self.training if update_loss_ema is None else bool(update_loss_ema)                           # dreamer4.py:7637-7654
         flow = self._normalize_loss('flow_loss_normalizer', flow, upd)
         short = self._normalize_loss('shortcut_flow_loss_normalizer', short, upd)

@@ -496,6 +496,11 @@ def gen_train_agent():
     for k, p in m.named_parameters():
         if p.grad is not None and p.numel() > 0 and float(p.grad.abs().max()) > 0:
             out[f'grad/{k}'] = npy(p.grad); ng += 1
+    # variable lengths (D4:7418-7426, 7460, 7488, 7586): frames past `lens` drop out of every loss term
+    lens = torch.tensor([5, 3, 4])
+    t_, l_ = m(latents=lat, discrete_actions=acts, rewards=rew, terminals=term, lens=lens, seed=9, return_all_losses=True)
+    out['lens'] = npy(lens); out['lens_total'] = npy(t_)
+    out['lens_terms'] = npy(torch.cat([l_.flow.reshape(1), l_.shortcut.reshape(1), l_.rewards, l_.terminals.reshape(1), l_.discrete_actions]))
     # the same forward with loss normalisation (D4:629-669, 5250-5255): two consecutive calls, the running mean squares evolve
     mtp = cfg.multi_token_pred_len
     m.flow_loss_normalizer, m.shortcut_flow_loss_normalizer = D4.LossNormalizer(), D4.LossNormalizer()

@@ -421,8 +421,12 @@ def ramp_weight(times, slope=0.9, intercept=0.1):
     return slope * times + intercept                                                 # D4:897-899, eq. (8)
 
 
+def lens_to_mask(lens, time):
+    return torch.arange(time)[None, :] < lens[:, None]                               # D4 `lens_to_mask`
+
+
 def dynamics_flow_losses(cfg: Config, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=None, tasks=None,
-                         cont_actions=None):
+                         cont_actions=None, lens=None):
     """The flow and shortcut-consistency losses of DynamicsWorldModel.forward in training (D4:6990-7003, 7335-7431; x-space prediction,
     the default `pred_orig_latent=True`; no proprio, no variable lengths, no loss normalisers — the dynamics model's defaults).
     latents (b, t, n, dl) data, noise the same shape, signal_levels (b, t), step_sizes_log2 (b,) int64, shortcut_train: the coin of
@@ -432,8 +436,9 @@ def dynamics_flow_losses(cfg: Config, W, latents, noise, signal_levels, step_siz
     noised = noise.lerp(latents, tt)                                                 # D4:7003
     pred = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks, cont_actions=cont_actions)[0]
     flow_losses = F.mse_loss(pred, latents, reduction='none') * ramp_weight(times)[:, :, None, None]      # D4:7350, 7410-7414
+    sel = (lambda x: x[lens_to_mask(lens, latents.shape[1])]) if lens is not None else (lambda x: x)          # variable lengths  D4:7418-7426
     if not shortcut_train:
-        return flow_losses.mean(), latents.new_zeros(())
+        return sel(flow_losses).mean(), latents.new_zeros(())
     with torch.no_grad():                                                            # D4:7313, 7356-7388
         half_log2 = step_sizes_log2 - 1
         half = 2 ** half_log2
@@ -446,7 +451,7 @@ def dynamics_flow_losses(cfg: Config, W, latents, noise, signal_levels, step_siz
         target = (first_flow + second_flow) / 2
     shortcut_pred = (pred - noised) / (1. - tt)                                      # D4:7397-7398
     shortcut_losses = F.mse_loss(shortcut_pred, target, reduction='none') * (1. - tt) ** 2
-    return flow_losses.mean(), shortcut_losses.mean()
+    return sel(flow_losses).mean(), sel(shortcut_losses).mean()
 
 
 # ----------------------------------------------------------------------------- heads
@@ -678,7 +683,7 @@ def mtp_targets(t, steps):
     return t[:, idx], mask[None].expand(t.shape[0], -1, -1)
 
 
-def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, actions=None, terminals=None):
+def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, actions=None, terminals=None, lens=None):
     """The agent-token losses of the training forward (D4:7432-7598): multi-token-prediction reward cross entropy against the
     encoder's soft targets, terminal BCE with DreamerV3 label smoothing, behaviour-cloning log-likelihood of the discrete actions
     (multi-token prediction, `shift_action_tokens=True`).  agent_embed (b, t, d) from the main prediction; rewards (b, t); actions
@@ -686,6 +691,8 @@ def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, ac
     out = {}
     b, t = agent_embed.shape[:2]
     mtp = cfg.multi_token_pred_len
+    lm = lens_to_mask(lens, t) if lens is not None else None                                # D4:7418-7423: frames past a trajectory's length
+    lm_wo_last = lm[:, :-1] if lm is not None else None
     if rewards is not None:
         if cfg.reward_encoder_type == 'symexp_two_hot':
             two_hot = symexp_two_hot(rewards, cfg.reward_range, cfg.reward_num_bins)
@@ -695,13 +702,14 @@ def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, ac
         pred = torch.stack([rmsnorm(x, W['to_reward_pred.params.0'][i]) @ W['to_reward_pred.params.1'][i].t() for i in range(mtp)], dim=2)   # b t-1 mtp l
         tgt, mask = mtp_targets(two_hot[:, 1:], mtp)                                       # b t-1 mtp l
         losses = -(tgt * pred.log_softmax(dim=-1)).sum(dim=-1).masked_fill(~mask, 0.)
-        out['rewards'] = losses.mean(dim=(0, 1))                                           # D4:7463: mean INCLUDES the masked zeros
+        out['rewards'] = losses[lm_wo_last].mean(dim=0) if lm is not None else losses.mean(dim=(0, 1))   # D4:7460-7463: the mean INCLUDES the mtp-masked zeros
     if terminals is not None and cfg.predict_terminals:
         pooled = latents[:, 1:].mean(dim=-2)
         logit = mlp(W, 'to_state_terminal_pred.0.', pooled, mlp_num_layers(cfg.terminal_mlp_depth), cfg.head_mlp_recipe).squeeze(-1)
         eps = 1. - cfg.gae_discount_factor
         tgt = terminals[:, 1:].float().clamp(min=eps, max=1. - eps)                        # D4:7481-7484
-        out['terminals'] = F.binary_cross_entropy_with_logits(logit, tgt)
+        tl = F.binary_cross_entropy_with_logits(logit, tgt, reduction='none')
+        out['terminals'] = tl[lm_wo_last].mean() if lm is not None else tl.mean()
     if actions is not None and t > 1:
         padded = F.pad(actions, (0, 0, 1, 0), value=-1)                                    # sentinel, D4:7540
         tgt, mask = mtp_targets(padded, mtp)
@@ -711,7 +719,8 @@ def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, ac
         for i in range(mtp):
             logits = pe @ W['action_embedder.discrete_action_unembed'][:, i].t()
             lp = discrete_log_probs(cfg, logits, tgt[:, :, i].clamp(min=0))
-            per.append((-lp).masked_fill(~mask[:, :, i, None], 0.).mean())
+            nl = (-lp).masked_fill(~mask[:, :, i, None], 0.)
+            per.append(nl[lm].mean() if lm is not None else nl.mean())                      # D4:7586-7590 (pred_len = t + 1: the full-length mask)
         out['discrete_actions'] = torch.stack(per)
     return out
 
@@ -727,15 +736,15 @@ def loss_normalize(state, name, loss, update, beta=0.95, eps=1e-6):
 
 
 def dynamics_training_losses(cfg: Config, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=None, rewards=None,
-                             terminals=None, tasks=None, normalizers=None, update_loss_ema=True):
+                             terminals=None, tasks=None, normalizers=None, update_loss_ema=True, lens=None):
     """Everything DynamicsWorldModel.forward returns in training for the supported subset (D4:6956-7743): flow, shortcut, rewards,
     terminals, discrete_actions and the total of D4:7708-7723 with unit loss weights (the reference defaults); `normalizers`: the
     LossNormalizer buffers by module name when `use_loss_normalization` (updated in place in the dict)."""
     times = signal_levels.float() / cfg.max_steps
     noised = noise.lerp(latents, times[:, :, None, None])
     _, agent_embed, _ = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks)
-    flow, short = dynamics_flow_losses(cfg, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=actions, tasks=tasks)
-    out = dict(flow=flow, shortcut=short, **dynamics_agent_losses(cfg, W, agent_embed, latents, rewards, actions, terminals))
+    flow, short = dynamics_flow_losses(cfg, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=actions, tasks=tasks, lens=lens)
+    out = dict(flow=flow, shortcut=short, **dynamics_agent_losses(cfg, W, agent_embed, latents, rewards, actions, terminals, lens=lens))
     for key, name in (('flow', 'flow_loss_normalizer'), ('shortcut', 'shortcut_flow_loss_normalizer'), ('rewards', 'reward_loss_normalizer'),
                       ('terminals', 'state_terminal_loss_normalizer'), ('discrete_actions', 'discrete_actions_loss_normalizer')):
         if key in out:                                                                     # D4:7637-7654 (`normalizers`: {name: exp_avg_sq})

@@ -240,7 +240,7 @@ def test_world_model_training_forward_matches_the_fixture_and_trains():
             close(own[k[14:]].grad, t(g[k]), 'd ' + k[14:], tol=1e-3); n += 1
     assert n >= 90
     with pytest.raises(NotImplementedError):
-        m(latents=t(g['latents']), lens=torch.tensor([4, 3, 2]))
+        m(latents=t(g['latents']), proprio=torch.zeros(3, 4, 2))
     # a short optimisation on a fixed batch of "data" latents, fresh draws every step
     trunk = [p for k, p in m.named_parameters() if p.grad is not None]
     opt = torch.optim.AdamW(trunk, lr=3e-3, weight_decay=0.)
@@ -281,6 +281,11 @@ def test_world_model_training_forward_with_rewards_terminals_and_actions_vs_refe
     # rewards / terminals given without their first frame are left-padded as the reference does (dreamer4.py:6905-6911)
     total2 = m(latents=t(g['latents']), discrete_actions=t(g['actions']), rewards=t(g['rewards'])[:, 1:], terminals=t(g['terminals'])[:, 1:], draws=draws)
     close(total2, total, 'total with t-1 rewards', tol=1e-6)
+    # variable lengths (dreamer4.py:7418-7426): frames past `lens` drop out of every term
+    tl, Ll = m(latents=t(g['latents']), discrete_actions=t(g['actions']), rewards=t(g['rewards']), terminals=t(g['terminals']), lens=t(g['lens']),
+               return_all_losses=True, draws=draws)
+    terms = torch.cat([Ll.flow.reshape(1), Ll.shortcut.reshape(1), Ll.rewards, Ll.terminals.reshape(1), Ll.discrete_actions])
+    close(terms, t(g['lens_terms']), 'terms with lens', tol=1e-5); close(tl, t(g['lens_total']), 'total with lens', tol=1e-5)
 
 
 def test_world_model_training_forward_with_loss_normalisation_vs_reference_fixture():
