@@ -426,11 +426,12 @@ def hl_gauss_probs(values, vrange, num_bins, sigma_to_bin_ratio=2., eps=1e-10):
 
 def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_discrete_actions, reward_range, reward_num_bins,
                           policy_head_mlp_depth, terminal_mlp_depth, head_mlp_recipe='pre_rms', gae_discount_factor=0.997,
-                          hl_sigma_ratio=2., hl_eps=1e-10, rewards=None, discrete_actions=None, terminals=None, lens=None):
+                          hl_sigma_ratio=2., hl_eps=1e-10, rewards=None, discrete_actions=None, terminals=None, lens=None,
+                          continuous_actions=None):
     """The agent-token losses of the training forward (dreamer4.py:7432-7598): multi-token-prediction reward cross entropy against HL-Gauss
     soft targets, terminal BCE with label smoothing, behaviour-cloning log-likelihood of the discrete actions (multi-token prediction,
     `shift_action_tokens=True`).  Plain torch ops on the device (the heads are three small MLPs on (b, t) rows); their gradients reach the
-    trunk through `agent_embed`.  Returns a dict of the terms that were asked for: rewards (mtp,), terminals (), discrete_actions (mtp,)."""
+    trunk through `agent_embed`.  Returns a dict of the terms that were asked for: rewards (mtp,), terminals (), discrete_actions (mtp,), continuous_actions (mtp,)."""
     from torch.nn import functional as F
     out = {}
     mtp = multi_token_pred_len
@@ -450,11 +451,26 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
         e = 1. - gae_discount_factor
         tl = F.binary_cross_entropy_with_logits(logit, terminals[:, 1:].float().clamp(min=e, max=1. - e), reduction='none')
         out['terminals'] = tl[lm[:, :-1]].mean() if lm is not None else tl.mean()
+    if (discrete_actions is not None or continuous_actions is not None) and t > 1:
+        pe = _head_mlp(W, 'policy_head.', agent_embed, policy_head_mlp_depth + 2, head_mlp_recipe)
+    if continuous_actions is not None and t > 1:
+        # Beta log-likelihood (dreamer4.py:7566-7597); alpha = softplus(raw0) + 1, beta = softplus(raw1) + 1: the stand-in's parameterisation
+        padded = F.pad(continuous_actions, (0, 0, 1, 0), value=0.)
+        tgt, mask = _mtp_targets(padded, mtp)
+        tgt, mask = tgt[:, 1:].clamp(1e-5, 1. - 1e-5), mask[:, 1:]
+        per = []
+        for i in range(mtp):
+            params = torch.einsum('...d,ndt->...nt', pe, W['action_embedder.continuous_action_unembed'][:, i])
+            a, b_ = F.softplus(params[..., 0]) + 1., F.softplus(params[..., 1]) + 1.
+            x = tgt[:, :, i]
+            lp = (a - 1.) * torch.log(x) + (b_ - 1.) * torch.log1p(-x) + torch.lgamma(a + b_) - torch.lgamma(a) - torch.lgamma(b_)
+            nl = (-lp).masked_fill(~mask[:, :, i, None], 0.)
+            per.append(nl[lm].mean() if lm is not None else nl.mean())
+        out['continuous_actions'] = torch.stack(per)
     if discrete_actions is not None and t > 1:
         padded = F.pad(discrete_actions, (0, 0, 1, 0), value=-1)
         tgt, mask = _mtp_targets(padded, mtp)
         tgt, mask = tgt[:, 1:].clamp(min=0), mask[:, 1:]
-        pe = _head_mlp(W, 'policy_head.', agent_embed[:, :padded.shape[1] - 1], policy_head_mlp_depth + 2, head_mlp_recipe)
         per = []
         for i in range(mtp):
             logits = F.linear(pe, W['action_embedder.discrete_action_unembed'][:, i])

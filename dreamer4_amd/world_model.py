@@ -614,11 +614,10 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         Inference branch (`signal_levels` / `step_sizes` given, latents already noised): returns (pred_flow, (agent_embed, next_time_cache))
         from the engine.  Training branch (neither given): samples the shortcut coin, step sizes, signal levels and noise as the
         reference does (dreamer4.py:6956-7003) and returns the total loss of dreamer4.py:7708-7723 (`return_all_losses=True`: `(total,
-        WorldModelLosses(flow, shortcut, rewards, terminals, discrete_actions))`): flow + shortcut, and — when `rewards` / `terminals` /
+        WorldModelLosses(flow, shortcut, rewards, terminals, discrete_actions, continuous_actions))`): flow + shortcut, and — when `rewards` / `terminals` /
         `discrete_actions` are given — the multi-token-prediction reward, terminal and behaviour-cloning losses (dreamer4.py:7432-7598);
         differentiable through the HIP trunk blocks (dreamer4_amd/trunk_ops.py); `lens` masks frames past each trajectory's length out of
-        every term.  Not implemented: proprio, continuous-action
-        behaviour cloning.  `use_loss_normalization=True` (constructor) applies the reference's LossNormalizer per term."""
+        every term.  Not implemented: proprio.  `use_loss_normalization=True` (constructor) applies the reference's LossNormalizer per term."""
         if signal_levels is None and step_sizes is None:
             return self._training_forward(latents, discrete_actions, continuous_actions, tasks, **kwargs)
         with torch.no_grad():
@@ -687,8 +686,6 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         unsupported = {k: v for k, v in kwargs.items() if v is not None}
         if unsupported:
             raise NotImplementedError(f'training forward: {sorted(unsupported)} is not implemented (proprio / video / aug / genes are outside the built slice)')
-        if continuous_actions is not None and add_autoregressive_action_loss:
-            raise NotImplementedError('training forward: the continuous-action behaviour-cloning loss is not implemented (pass add_autoregressive_action_loss=False)')
         if self.reward_encoder_type != 'hl_gauss' and rewards is not None:
             raise NotImplementedError('training forward: reward loss with the symexp_two_hot encoder is not implemented')
         dev = self.device
@@ -736,17 +733,18 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         da = discrete_actions.to(dev).long() if (discrete_actions is not None and add_autoregressive_action_loss) else None
         if da is not None and da.ndim == 2:
             da = da[..., None]
+        ca = continuous_actions.to(dev).float() if (continuous_actions is not None and add_autoregressive_action_loss) else None
         agent = trunk_ops.dynamics_agent_losses(
             W, agent_embed, lat, multi_token_pred_len=self.multi_token_pred_len, num_discrete_actions=tuple(self.num_discrete_actions),
             reward_range=self.reward_range, reward_num_bins=self.reward_num_bins, policy_head_mlp_depth=self.policy_head_mlp_depth,
             terminal_mlp_depth=self.terminal_mlp_depth, head_mlp_recipe=self.head_mlp_recipe, gae_discount_factor=self.gae_discount_factor,
             hl_sigma_ratio=self.hl_sigma_ratio, hl_eps=self.hl_eps, rewards=rew, discrete_actions=da, terminals=term,
-            lens=lens.to(dev) if lens is not None else None)
+            lens=lens.to(dev) if lens is not None else None, continuous_actions=ca)
         upd = self.training if update_loss_ema is None else bool(update_loss_ema)                           # dreamer4.py:7637-7654
         flow = self._normalize_loss('flow_loss_normalizer', flow, upd)
         short = self._normalize_loss('shortcut_flow_loss_normalizer', short, upd)
         for key, name in (('rewards', 'reward_loss_normalizer'), ('terminals', 'state_terminal_loss_normalizer'),
-                          ('discrete_actions', 'discrete_actions_loss_normalizer')):
+                          ('discrete_actions', 'discrete_actions_loss_normalizer'), ('continuous_actions', 'continuous_actions_loss_normalizer')):
             if key in agent:
                 agent[key] = self._normalize_loss(name, agent[key], upd)
         # unit loss weights: the reference defaults (dreamer4.py:4719-4725, 7708-7723)
@@ -754,9 +752,9 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         if not return_all_losses:
             return total
         from collections import namedtuple
-        Losses = namedtuple('WorldModelLosses', ('flow', 'shortcut', 'rewards', 'terminals', 'discrete_actions'))
+        Losses = namedtuple('WorldModelLosses', ('flow', 'shortcut', 'rewards', 'terminals', 'discrete_actions', 'continuous_actions'))
         z = lat.new_zeros(())
-        return total, Losses(flow, short, agent.get('rewards', z), agent.get('terminals', z), agent.get('discrete_actions', z))
+        return total, Losses(flow, short, agent.get('rewards', z), agent.get('terminals', z), agent.get('discrete_actions', z), agent.get('continuous_actions', z))
 
     # ------------------------------------------------------------------------------ generate
     @torch.no_grad()

@@ -30,6 +30,7 @@ Fixtures (model: dim 32, 2 heads x 64, 6 latent tokens x 8, depth 4, time block 
   encode.npz       VideoTokenizer.tokenize of reference tokenizers (weights_encode*.npz = the encoder half) + generate(prompt=video)
   train.npz        flow + shortcut losses of the dynamics training forward and their gradients (weights_train.npz)
   train_agent.npz  the whole training forward with rewards / terminals / actions (weights_train_agent.npz)
+  train_cont.npz   the training forward with discrete + continuous action cloning (weights_train_cont.npz)
   decode.npz       VideoTokenizer.decode of a reference tokenizer (weights_decode.npz = the decoder half of its state_dict): two flow steps
 """
 from __future__ import annotations
@@ -516,6 +517,54 @@ def gen_train_agent():
     np.savez(os.path.join(OUT, 'train_agent.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
 
 
+CFG_TRAIN_CONT = dict(dim=32, dim_latent=8, num_latent_tokens=6, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
+                      num_discrete_actions=(4,), num_continuous_actions=2, num_tasks=0, reward_num_bins=11, value_num_bins=11, multi_token_pred_len=2,
+                      max_steps=16)
+
+
+def gen_train_cont():
+    """train_cont.npz / weights_train_cont.npz: the training forward with discrete AND continuous (Beta) actions: the behaviour-cloning terms
+    of both kinds at multi-token-prediction length 2 (D4:7514-7597), total and gradients.  The Beta parameterisation is the stand-in's."""
+    D4 = load_reference()
+    cfg = Config(**CFG_TRAIN_CONT)
+    m = build_reference_model(cfg, seed=77, head_scale=False)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(10.)
+        m.action_embedder.continuous_action_unembed.mul_(10.)
+    save_weights('weights_train_cont.npz', weights_of(m), CFG_TRAIN_CONT)
+    g = torch.Generator().manual_seed(78)
+    B, T = 3, 4
+    lat = torch.randn(B, T, 6, 8, generator=g).clamp(-2, 2)
+    acts = torch.randint(0, 4, (B, T, 1), generator=g)
+    cont = torch.rand(B, T, 2, generator=g)
+    out = dict(latents=npy(lat), actions=npy(acts), actions_cont=npy(cont))
+    rec = {}
+    saved = (D4.randint, D4.randn_like)
+
+    def rec_randint(*a, **k):
+        r = saved[0](*a, **k); rec.setdefault('randint', []).append(r.clone()); return r
+
+    def rec_randn_like(*a, **k):
+        r = saved[1](*a, **k); rec.setdefault('randn_like', []).append(r.clone()); return r
+
+    D4.randint, D4.randn_like = rec_randint, rec_randn_like
+    m.prob_shortcut_train = 0.
+    try:
+        m.zero_grad()
+        total, losses = m(latents=lat, discrete_actions=acts, continuous_actions=cont, seed=11, return_all_losses=True)
+    finally:
+        D4.randint, D4.randn_like = saved
+    total.backward()
+    out.update(step_sizes_log2=npy(torch.zeros(B, dtype=torch.long)), signal_levels=npy(rec['randint'][0]), noise=npy(rec['randn_like'][0][:, :, 0]))
+    out.update(total=npy(total), flow_loss=npy(losses.flow), discrete_actions_loss=npy(losses.discrete_actions), continuous_actions_loss=npy(losses.continuous_actions))
+    ng = 0
+    for k, p in m.named_parameters():
+        if p.grad is not None and p.numel() > 0 and float(p.grad.abs().max()) > 0:
+            out[f'grad/{k}'] = npy(p.grad); ng += 1
+    print('train_cont total', float(total), 'discrete', losses.discrete_actions.tolist(), 'continuous', losses.continuous_actions.tolist(), 'grads', ng)
+    np.savez(os.path.join(OUT, 'train_cont.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+
+
 CFG_SYMEXP = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, time_block_every=2, attn_heads=2, attn_dim_head=32,
                   num_discrete_actions=(4,), num_tasks=0, reward_num_bins=41, value_num_bins=31, reward_range=(-3., 3.), value_range=(-4., 4.),
                   multi_token_pred_len=2, policy_head_mlp_depth=1, value_head_mlp_depth=1, reward_encoder_type='symexp_two_hot')
@@ -542,7 +591,7 @@ def gen_symexp():
     print('symexp margin', out['cached_margin'], 'lens', out['cached_lens'], 'values', out['cached_values'][0])
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent)
+EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent, train_cont=gen_train_cont)
 
 
 def main():

@@ -683,7 +683,7 @@ def mtp_targets(t, steps):
     return t[:, idx], mask[None].expand(t.shape[0], -1, -1)
 
 
-def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, actions=None, terminals=None, lens=None):
+def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, actions=None, terminals=None, lens=None, cont_actions=None):
     """The agent-token losses of the training forward (D4:7432-7598): multi-token-prediction reward cross entropy against the
     encoder's soft targets, terminal BCE with DreamerV3 label smoothing, behaviour-cloning log-likelihood of the discrete actions
     (multi-token prediction, `shift_action_tokens=True`).  agent_embed (b, t, d) from the main prediction; rewards (b, t); actions
@@ -710,11 +710,22 @@ def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, ac
         tgt = terminals[:, 1:].float().clamp(min=eps, max=1. - eps)                        # D4:7481-7484
         tl = F.binary_cross_entropy_with_logits(logit, tgt, reduction='none')
         out['terminals'] = tl[lm_wo_last].mean() if lm is not None else tl.mean()
+    if (actions is not None or cont_actions is not None) and t > 1:
+        pe = policy_head(cfg, W, agent_embed)                                              # num_targets = t for (b, t, na) actions, D4:7553-7556
+    if cont_actions is not None and t > 1:                                                 # Beta log-likelihood, D4:7566-7597 (stand-in parameterisation)
+        padded = F.pad(cont_actions, (0, 0, 1, 0), value=0.)
+        tgt, mask = mtp_targets(padded, mtp)
+        tgt, mask = tgt[:, 1:].clamp(1e-5, 1. - 1e-5), mask[:, 1:]                         # soft_validate_range, D4:1439-1440
+        per = []
+        for i in range(mtp):
+            params = torch.einsum('...d,ndt->...nt', pe, W['action_embedder.continuous_action_unembed'][:, i])
+            nl = (-beta_log_prob(params, tgt[:, :, i])).masked_fill(~mask[:, :, i, None], 0.)
+            per.append(nl[lm].mean() if lm is not None else nl.mean())
+        out['continuous_actions'] = torch.stack(per)
     if actions is not None and t > 1:
         padded = F.pad(actions, (0, 0, 1, 0), value=-1)                                    # sentinel, D4:7540
         tgt, mask = mtp_targets(padded, mtp)
         tgt, mask = tgt[:, 1:], mask[:, 1:]                                                # b t mtp na
-        pe = policy_head(cfg, W, agent_embed[:, :padded.shape[1] - 1])
         per = []
         for i in range(mtp):
             logits = pe @ W['action_embedder.discrete_action_unembed'][:, i].t()
@@ -736,17 +747,20 @@ def loss_normalize(state, name, loss, update, beta=0.95, eps=1e-6):
 
 
 def dynamics_training_losses(cfg: Config, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=None, rewards=None,
-                             terminals=None, tasks=None, normalizers=None, update_loss_ema=True, lens=None):
+                             terminals=None, tasks=None, normalizers=None, update_loss_ema=True, lens=None, cont_actions=None):
     """Everything DynamicsWorldModel.forward returns in training for the supported subset (D4:6956-7743): flow, shortcut, rewards,
     terminals, discrete_actions and the total of D4:7708-7723 with unit loss weights (the reference defaults); `normalizers`: the
     LossNormalizer buffers by module name when `use_loss_normalization` (updated in place in the dict)."""
     times = signal_levels.float() / cfg.max_steps
     noised = noise.lerp(latents, times[:, :, None, None])
-    _, agent_embed, _ = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks)
-    flow, short = dynamics_flow_losses(cfg, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=actions, tasks=tasks, lens=lens)
-    out = dict(flow=flow, shortcut=short, **dynamics_agent_losses(cfg, W, agent_embed, latents, rewards, actions, terminals, lens=lens))
+    _, agent_embed, _ = wm_forward(cfg, W, noised, signal_levels, step_sizes_log2, actions=actions, tasks=tasks, cont_actions=cont_actions)
+    flow, short = dynamics_flow_losses(cfg, W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, actions=actions, tasks=tasks, lens=lens,
+                                       cont_actions=cont_actions)
+    out = dict(flow=flow, shortcut=short, **dynamics_agent_losses(cfg, W, agent_embed, latents, rewards, actions, terminals, lens=lens,
+                                                                  cont_actions=cont_actions))
     for key, name in (('flow', 'flow_loss_normalizer'), ('shortcut', 'shortcut_flow_loss_normalizer'), ('rewards', 'reward_loss_normalizer'),
-                      ('terminals', 'state_terminal_loss_normalizer'), ('discrete_actions', 'discrete_actions_loss_normalizer')):
+                      ('terminals', 'state_terminal_loss_normalizer'), ('discrete_actions', 'discrete_actions_loss_normalizer'),
+                      ('continuous_actions', 'continuous_actions_loss_normalizer')):
         if key in out:                                                                     # D4:7637-7654 (`normalizers`: {name: exp_avg_sq})
             out[key] = loss_normalize(normalizers, name, out[key], update_loss_ema)
     out['total'] = sum(v.sum() for v in out.values())

@@ -304,6 +304,24 @@ def test_world_model_training_forward_with_loss_normalisation_vs_reference_fixtu
     assert m.get_parameter('transformer.layers.0.2.fn.to_q.weight').grad.abs().max().item() > 0
 
 
+def test_world_model_training_forward_with_continuous_action_cloning_vs_reference_fixture():
+    """train_cont.npz: discrete + continuous (Beta) behaviour cloning through the mirror: terms, total, 103 parameter gradients."""
+    from util import golden_model, load_golden, t
+    g = load_golden('train_cont.npz')
+    m = golden_model('weights_train_cont.npz').cuda()
+    draws = dict(shortcut_train=False, step_sizes_log2=t(g['step_sizes_log2']), signal_levels=t(g['signal_levels']), noise=t(g['noise']))
+    total, L = m(latents=t(g['latents']), discrete_actions=t(g['actions']), continuous_actions=t(g['actions_cont']), return_all_losses=True, draws=draws)
+    close(L.flow, t(g['flow_loss']), 'flow', tol=1e-5); close(L.discrete_actions, t(g['discrete_actions_loss']), 'discrete', tol=1e-5)
+    close(L.continuous_actions, t(g['continuous_actions_loss']), 'continuous', tol=1e-5); close(total, t(g['total']), 'total', tol=1e-5)
+    total.backward()
+    own = dict(m.named_parameters())
+    n = 0
+    for k in g:
+        if k.startswith('grad/'):
+            close(own[k[5:]].grad, t(g[k]), 'd ' + k[5:], tol=1e-3); n += 1
+    assert n >= 100
+
+
 def test_blocks_compose_with_torch_autograd():
     """x + attention(x), then x + feedforward(x), then a torch loss: gradients flow through both HIP blocks and torch ops."""
     g = torch.Generator().manual_seed(11)
