@@ -80,7 +80,8 @@ struct d4_engine {
     float *pos_emb = nullptr, *t2p_wf = nullptr, *dec_in = nullptr, *img_tok = nullptr, *lat_tok = nullptr, *dec_out = nullptr, *posA = nullptr, *posB = nullptr, *zerosD = nullptr;
 
     // ---- bf16 compute (opt-in): bf16 mirrors of every weight the trunk GEMMs read, carved from one arena of the workspace
-    bool bf16 = false;
+    bool bf16 = false;                     // the trunk's GEMMs read mirrors of their weights (bf16 mode, or the three planes of the split-operand fp32 mode)
+    bool split = false;                    // mirrors are three bf16 planes (plane stride = bf16_cap): fp32 GEMMs on the bf16 matrix cores (gemm_x3.hip)
     uint16_t* bf16_arena = nullptr; size_t bf16_cap = 0, bf16_used = 0;
     struct Mirror { const float* src; size_t n; uint16_t* dst; };
     std::vector<Mirror> mirrors;

@@ -70,8 +70,8 @@ int engine_layout(d4_engine* e, bool assign) {
         const size_t per_layer = (size_t)(e->Nproj0 + hd) * D + (size_t)3 * e->inner_pad * D;
         const size_t per_pool = (size_t)(hp + e->php + 2 * hp) * D + (size_t)D * hp;
         const size_t extra = (size_t)(hd + c.attn_heads + 2 * hd + hd) * D + (size_t)2 * hd * dl + (size_t)2 * hd * D + (size_t)dl * (hd > D ? hd : D) + (size_t)D * hd + (size_t)D * dl;
-        e->bf16_cap = (size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096;
-        e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * sizeof(uint16_t)));
+        e->bf16_cap = ((size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096 + 7) / 8 * 8;
+        e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * (e->split ? 3 : 1) * sizeof(uint16_t)));     // split mode: three planes
     }
     const size_t KR = e->decoder ? (size_t)e->P : (e->encoder ? (size_t)n : (size_t)ns + 1);        // token rows per frame the final stage keeps (compact copies)
     const size_t KQ = e->encoder ? (size_t)n : 1;                        // special tokens per frame that cross-attend (D4:3227-3238)
@@ -349,6 +349,7 @@ static int mirror_weight(d4_engine* e, const float* src, size_t n, hipStream_t s
     uint16_t* dst = e->bf16_arena + e->bf16_used;
     e->bf16_used += n;
     e->mirrors.push_back({src, n, dst});
+    if (e->split) return split_bf16x3(src, dst, (int64_t)n, (int64_t)e->bf16_cap, s);
     return cvt_f32_to_bf16(src, dst, (int64_t)n, s);
 }
 
@@ -358,6 +359,10 @@ static int engine_gemm(GemmArgs& g, hipStream_t s) {
         for (const auto& m : e->mirrors)
             if (g.W >= m.src && g.W < m.src + m.n) { g.Wb = m.dst + (g.W - m.src); break; }
         D4_REQUIRE(g.Wb != nullptr, "bf16 engine: a trunk GEMM weight has no bf16 mirror (M=%d N=%d K=%d)", g.M, g.N, g.K);
+        if (e->split) {
+            g.wplane = (int64_t)e->bf16_cap;
+            if (!gemm_x3_applicable(g)) { g.Wb = nullptr; g.wplane = 0; }
+        } else
         if (!gemm_bf16_applicable(g)) g.Wb = nullptr;       // e.g. K not a multiple of 32: this call stays on the fp32 kernel
     }
     return gemm(g, s);
@@ -382,7 +387,7 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
 
 // Two independent projections of equal K: one launch when both are few-row problems (fp32 engine), else one after the other.
 static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
-    if (!t_bf16 && gemm_skinny_pair_applicable(a, b)) return gemm_skinny_pair(a, b, s);
+    if ((!t_bf16 || t_bf16->split) && gemm_skinny_pair_applicable(a, b)) return gemm_skinny_pair(a, b, s);
     int rc;
     if ((rc = engine_gemm(a, s))) return rc;
     return engine_gemm(b, s);
@@ -946,6 +951,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->na = c.num_discrete_action_types;
     e->nc = c.num_continuous_actions;
     e->bf16 = c.matmul_bf16 != 0;
+    e->split = c.matmul_bf16 == 2;
     D4_REQUIRE(e->nc >= 0 && e->nc <= 64, "num_continuous_actions out of range");
     e->A = 0;
     for (int a = 0; a < e->na; ++a) e->A += c.num_discrete_actions[a];
@@ -1291,7 +1297,11 @@ int d4_profile_bf16_read(double* ms, double* flops, int64_t* count) { return d4:
 int d4_profile_enable(int on) { return d4::gemm_profile_enable(on); }
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { return d4::gemm_profile_read(ms, flops, count, nclass); }
 int d4_profile_classes(void) { return d4::gemm_profile_classes(); }
-int d4_gemm_force_config(int id) { if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1); return d4::gemm_force_config(id >= 200 ? -1 : id); }
+int d4_gemm_force_config(int id) {
+    if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile configuration c of the split-operand fp32 family (gemm_x3.hip)
+    if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1);
+    return d4::gemm_force_config(id >= 200 ? -1 : id);
+}
 const char* d4_profile_class_name(int c) { return d4::gemm_profile_class_name(c); }
 
 int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
@@ -1327,6 +1337,19 @@ int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, 
     return d4::gemm(g, static_cast<hipStream_t>(stream));
 }
 
+int d4_split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane_stride, void* stream) {
+    D4_REQUIRE(src && dst && n >= 0 && plane_stride >= n && (plane_stride % 8) == 0, "d4_split_bf16x3: bad arguments");
+    return d4::split_bf16x3(src, dst, n, plane_stride, static_cast<hipStream_t>(stream));
+}
+int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_stride, int ldw, float* C, int ldc, const float* bias,
+                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, void* stream) {
+    d4::GemmArgs g{A, lda, reinterpret_cast<const float*>(W3), ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.Wb = W3; g.wplane = plane_stride;
+    D4_REQUIRE(d4::gemm_x3_applicable(g), "d4_gemm_split: call not supported (M=%d N=%d K=%d flags=%d: K %% 32, ldw %% 8, plane_stride %% 8, 16-byte alignment)", M, N, K, flags);
+    if (M == 0) return 0;
+    if (config >= 0) return d4::gemm_x3_launch(config, g, static_cast<hipStream_t>(stream));
+    return d4::gemm_x3_launch(d4::gemm_x3_heuristic(g), g, static_cast<hipStream_t>(stream));
+}
 int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream) {
     d4::GemmArgs g{A, lda, reinterpret_cast<const float*>(Wb), ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};

@@ -436,8 +436,9 @@ static const char* const kTileKernel[N_TILE_CFG] = {
     "gemm_kernel<128, 128, 2, 4, 32, 1", "gemm_kernel<128, 128, 4, 2, 32, 1", "gemm_kernel<128, 96, 4, 1, 32, 1", "gemm_kernel<64, 128, 2, 2, 32, 1",
     "gemm_kernel<64, 64, 2, 2, 32, 1", "gemm_kernel<256, 128, 4, 4, 32, 1", "gemm_kernel<64, 128, 2, 2, 16, 1", "gemm_kernel<64, 64, 2, 2, 16, 1"};
 // profile classes: the N_TILE_CFG configurations of this family, then the configurations of the second family (gemm2.hip)
-int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs(); }
+int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs(); }
 const char* gemm_profile_class_name(int c) {
+    if (c >= N_TILE_CFG + gemm2_configs()) return gemm_x3_config_name(c - N_TILE_CFG - gemm2_configs());
     if (c >= N_TILE_CFG) return gemm2_config_name(c - N_TILE_CFG);
     return c >= 0 ? kTileKernel[c] : "";
 }
@@ -508,7 +509,7 @@ struct TuneKey {
     int M, N, K, flags, batch;
     bool operator<(const TuneKey& o) const { return std::tie(M, N, K, flags, batch) < std::tie(o.M, o.N, o.K, o.flags, o.batch); }
 };
-static std::map<TuneKey, int> g_tuned, g_tuned2;
+static std::map<TuneKey, int> g_tuned, g_tuned2, g_tuned3;
 static int g_forced_cfg = -1;          // test hook (d4_gemm_force_config): run this configuration wherever it is valid;
                                        // 100 + c: configuration c of the second family (gemm2.hip)
 int gemm_force_config(int id) { g_forced_cfg = id; return N_TILE_CFG; }
@@ -528,6 +529,7 @@ static void tune_cache_read(const char* path) {
             if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d", &k.M, &k.N, &k.K, &k.flags, &k.batch, &id) != 6) continue;
             if (id >= 0 && id < N_TILE_CFG) g_tuned[k] = id;
             else if (id >= 100 && id < 100 + gemm2_configs()) g_tuned2[k] = id - 100;      // second family (gemm2.hip)
+            else if (id >= 300 && id < 300 + gemm_x3_configs()) g_tuned3[k] = id - 300;    // split-operand family (gemm_x3.hip)
         }
         fclose(f);
     }
@@ -689,6 +691,74 @@ static int gemm_v2(const GemmArgs& p, hipStream_t stream) {
     return launch_v2(best, p, stream);
 }
 
+// ---- third family (split operands on the bf16 matrix cores): launch with the optional event pair, timed choice among its tiles ----
+static int launch_v3(int c, const GemmArgs& p, hipStream_t stream) {
+    const int cls = N_TILE_CFG + gemm2_configs() + c;
+    const bool timed = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
+    if (!timed) return gemm_x3_launch(c, p, stream);
+    ProfRec rec{};
+    rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.flags = p.flags; rec.batch = p.batch;
+    gemm_x3_config_tile(c, &rec.bm, &rec.bn);
+    rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+    if (int rc = gemm_x3_launch(c, p, stream, rec.a, rec.b)) return rc;
+    g_prof.push_back(rec);
+    return 0;
+}
+
+static int autotune_v3(const GemmArgs& p, hipStream_t stream, int* best_out) {
+    hipEvent_t e0 = prof_event(), e1 = prof_event();
+    const int saved_mask = g_prof_mask;
+    g_prof_mask = 0;
+    int best = -1, rc = 0;
+    float best_ms = 0.f;
+    for (int c = 0; c < gemm_x3_configs() && !rc; ++c) {
+        if (!gemm_x3_config_valid(c, p)) continue;
+        if ((rc = gemm_x3_launch(c, p, stream))) break;
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2 && !rc; ++rep) {
+            (void)hipEventRecord(e0, stream);
+            if ((rc = gemm_x3_launch(c, p, stream))) break;
+            if ((rc = gemm_x3_launch(c, p, stream))) break;
+            (void)hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            ms = t < ms ? t : ms;
+        }
+        if (!rc && (best < 0 || ms < best_ms)) { best = c; best_ms = ms; }
+    }
+    g_prof_mask = saved_mask;
+    g_event_pool.push_back(e0);
+    g_event_pool.push_back(e1);
+    if (rc) return rc;
+    D4_REQUIRE(best >= 0, "gemm_x3: no configuration for M=%d N=%d K=%d flags=%d", p.M, p.N, p.K, p.flags);
+    if (getenv("D4_GEMM_LOG"))
+        fprintf(stderr, "[d4 gemm_x3] tuned M %6d N %5d K %5d batch %2d flags %3d -> %s (%.1f us)\n", p.M, p.N, p.K, p.batch, p.flags, gemm_x3_config_name(best), 500.f * best_ms);
+    *best_out = best;
+    return 0;
+}
+
+static int gemm_v3(const GemmArgs& p, hipStream_t stream) {
+    static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
+    const int nb = p.batch > 0 ? p.batch : 1;
+    if (g_forced_cfg >= 300 && gemm_x3_config_valid(g_forced_cfg - 300, p)) return launch_v3(g_forced_cfg - 300, p, stream);
+    const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
+    tune_cache_load();
+    auto it = g_tuned3.find(key);
+    if (it != g_tuned3.end() && gemm_x3_config_valid(it->second, p)) return launch_v3(it->second, p, stream);
+    const bool idempotent = !(p.flags & GEMM_ACCUMULATE) && p.R != p.C && p.A != p.C;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
+        return launch_v3(gemm_x3_heuristic(p), p, stream);
+    int best = 0;
+    if (int rc = autotune_v3(p, stream, &best)) return rc;
+    g_tuned3[key] = best;
+    tune_cache_append(key, 300 + best);
+    return launch_v3(best, p, stream);
+}
+
 int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0, "gemm: bad sizes M=%d N=%d K=%d", p.M, p.N, p.K);
     if (p.M == 0) return 0;
@@ -698,11 +768,24 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(!((p.flags & GEMM_RMS_ROWSCALE) && ta), "gemm: rms rowscale needs a non-transposed A");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (p.N % 64) != 0), "gemm: swiglu needs N %% 64 == 0 (packed pairs)");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (ta || tb)), "gemm: swiglu epilogue is forward-only");
+    // split-operand fp32 (three bf16 planes of W): few-row calls stay on the few-row kernel (a rule on the shape, like every family choice)
+    if (p.Wb && p.wplane > 0) {
+        // Which calls take it is a RULE on the call's shape (never a timing).  Measured on MI355X (tools/gemm_x3_bench.py,
+        // profiles/r02_gemm_split_operands.txt): it wins where a launch has enough wide tiles to hide its heavier staging — the SiLU-GLU
+        // input projections (N = 2 x 1376 ... 5504: 1.2-1.35x the f32-input MFMA kernels) and other N >= 2048 projections (level to 1.3x) —
+        // and loses on the N <= 1552 shapes (0.8-0.95x).  D4_GEMM_X3 = 0: never, 2: every applicable call (experiments).
+        static const int mode = getenv("D4_GEMM_X3") ? atoi(getenv("D4_GEMM_X3")) : 1;
+        const bool preferred = mode >= 2 || (mode == 1 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && p.M >= 256);
+        if (preferred && gemm_x3_applicable(p) && !gemm_skinny_applicable(p)) return gemm_v3(p, stream);
+        GemmArgs q = p;
+        q.Wb = nullptr; q.wplane = 0;
+        return gemm(q, stream);
+    }
     if (p.Wb) return gemm_bf16(p, stream);
     // test hook: 100 + c forces configuration c of the second family, 0 .. N_TILE_CFG-1 a configuration of this one
     if (g_forced_cfg >= 100 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);
     if (gemm_skinny_applicable(p)) return gemm_skinny(p, stream);
-    if (g_forced_cfg < 0 && use_v2(p)) return gemm_v2(p, stream);
+    if ((g_forced_cfg < 0 || g_forced_cfg >= 300) && use_v2(p)) return gemm_v2(p, stream);      // (300 + c forces a tile of the split-operand family only)
     if (!ta && !tb) return launch_t<false, false>(p, stream);
     if (!ta && tb) return launch_t<false, true>(p, stream);
     if (ta && tb) return launch_t<true, true>(p, stream);

@@ -31,6 +31,8 @@ struct GemmArgs {
     // strided batch (blockIdx.y): A += b * strideA, W += b * strideW, C/R += b * strideC   (elements)
     int batch = 1; int64_t strideA = 0, strideW = 0, strideC = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
     const uint16_t* Wb = nullptr;      // bf16 image of W (same [N][ldw] layout): when set the call runs on the bf16 MFMA kernel (gemm_bf16.hip)
+    int64_t wplane = 0;                // > 0: Wb holds THREE bf16 planes (W = W1 + W2 + W3, plane stride in elements) and the call runs as
+                                       // an fp32 GEMM on the bf16 matrix cores (split operands, six products: gemm_x3.hip)
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
@@ -47,6 +49,15 @@ int gemm_bf16_force_config(int id);                          // test / microbenc
 int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
 void gemm_bf16_profile_enable(int stride);
 int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count);
+// third fp32 family (gemm_x3.hip): fp32 operands split into three bf16 numbers, six bf16 MFMA products, fp32 accumulate (fp32 accuracy)
+bool gemm_x3_applicable(const GemmArgs& p);
+bool gemm_x3_config_valid(int c, const GemmArgs& p);
+int gemm_x3_configs();
+const char* gemm_x3_config_name(int c);
+void gemm_x3_config_tile(int c, int* bm, int* bn);
+int gemm_x3_heuristic(const GemmArgs& p);
+int gemm_x3_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+int split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane, hipStream_t s);
 // second fp32 family (gemm2.hip): 16x16x4 MFMA fed by an LDS-DMA ring; non-transposed operands, K % 32 == 0
 bool gemm2_applicable(const GemmArgs& p);
 bool gemm2_config_valid(int c, const GemmArgs& p);

@@ -176,10 +176,16 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         if head_mlp_recipe not in MLP_RECIPES:
             raise ValueError(f'head_mlp_recipe must be one of {sorted(MLP_RECIPES)}')
         self.head_mlp_recipe = head_mlp_recipe
-        # 'bf16' (not a reference argument): the trunk's GEMMs run on the bf16 MFMA path — bf16 weights and activations, fp32
-        # accumulation, norms, softmax and residual stream (BASELINE config 5); the default is the reference's own fp32 arithmetic
-        if matmul_dtype not in ('fp32', 'bf16'):
-            raise ValueError("matmul_dtype must be 'fp32' or 'bf16'")
+        # (not a reference argument) arithmetic of the trunk's GEMMs:
+        #   'fp32' (default)  the reference's fp32; the wide projections (SiLU-GLU input, N >= 2048) run on the bf16 matrix cores with
+        #                     every fp32 operand split exactly into three bf16 numbers and six products accumulated in fp32
+        #                     (csrc/gemm_x3.hip: fp32 accuracy — measured error against float64 below the f32-input MFMA kernels'),
+        #                     everything else on the f32-input MFMA
+        #   'fp32_mfma'       every GEMM on the f32-input MFMA (the round-1 arithmetic)
+        #   'bf16'            bf16-rounded weights and activations on the bf16 MFMA, fp32 accumulation / norms / softmax / residual
+        #                     stream (BASELINE config 5)
+        if matmul_dtype not in ('fp32', 'fp32_mfma', 'bf16'):
+            raise ValueError("matmul_dtype must be 'fp32', 'fp32_mfma' or 'bf16'")
         self.matmul_dtype = matmul_dtype
         self.use_loss_normalization = bool(use_loss_normalization)
         for k, v in kwargs.items():
@@ -440,7 +446,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         c.reward_num_bins, c.value_num_bins = self.reward_num_bins, self.value_num_bins
         c.head_mlp_recipe = MLP_RECIPES[self.head_mlp_recipe]
         c.reward_encoder_type = int(self.reward_encoder_type == 'symexp_two_hot')
-        c.matmul_bf16 = int(self.matmul_dtype == 'bf16')
+        c.matmul_bf16 = {'fp32': 2, 'fp32_mfma': 0, 'bf16': 1}[self.matmul_dtype]
         c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
         c.gae_discount_factor, c.gae_lambda, c.ppo_eps_clip = self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip
         c.policy_entropy_weight = self.policy_entropy_weight

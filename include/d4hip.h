@@ -51,8 +51,10 @@ typedef struct d4_config {
     int32_t policy_head_mlp_depth, value_head_mlp_depth, terminal_mlp_depth, predict_terminals;
     int32_t reward_num_bins, value_num_bins;
     int32_t reward_encoder_type;                /* 0 = hl_gauss (default, D4:1041), 1 = symexp_two_hot (D4:947): bins = symexp(linspace), two-hot targets */
-    int32_t matmul_bf16;                        /* 1: trunk GEMMs on the bf16 MFMA path (bf16 weights + activations, fp32 accumulate, fp32 norms /
-                                                   softmax / residual stream); 0: fp32 MFMA as the reference computes (default) */
+    int32_t matmul_bf16;                        /* trunk GEMM arithmetic.  0: fp32 on the f32-input MFMA; 2: fp32 on the bf16 matrix cores by operand
+                                                   splitting (three bf16 planes per operand, six products, fp32 accumulate: fp32 accuracy,
+                                                   csrc/gemm_x3.hip) — the Python mirror's default; 1: bf16 MFMA (bf16-rounded weights +
+                                                   activations, fp32 accumulate, fp32 norms / softmax / residual stream) */
     int32_t head_mlp_recipe;                    /* D4_MLP_PRE_RMS / D4_MLP_POST_LAYER: layer recipe of the policy / value / terminal MLPs (engine.h) */
     int32_t pool_heads, pool_dim_head;          /* AttentionPool defaults 4 x 64 (D4:2147-2148) */
     /* learn_from_experience hyper-parameters (D4:4731-4744) */
@@ -231,7 +233,8 @@ int d4_profile_classes(void);
 const char* d4_profile_class_name(int c);
 
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
- * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel.
+ * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
+ * split-operand fp32 family (gemm_x3.hip).
  * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
 int d4_gemm_force_config(int id);
 
@@ -249,6 +252,14 @@ int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, 
 /* the bf16 MFMA kernel alone: A fp32 [M][lda] (rounded to bf16 on the way in), Wb bf16 [N][ldw] (raw 16-bit patterns), C fp32 */
 int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
+/* fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip; the trunk's default `Linear` arithmetic): every fp32 operand is the exact sum of three
+ * bf16 numbers and a product is accumulated from its six leading bf16 x bf16 terms in fp32 — fp32 accuracy (error against float64 no
+ * larger than the f32-input MFMA kernels'), 6/16 of their matrix-pipe time.  d4_split_bf16x3 writes the three planes of W
+ * (dst[p * plane_stride + i], p = 0..2; plane_stride % 8 == 0); d4_gemm_split takes A in fp32 and splits it on the fly.  `config` = -1: the
+ * dispatcher's choice, else one tile configuration of the family (all give the same bits). */
+int d4_split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane_stride, void* stream);
+int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_stride, int ldw, float* C, int ldc, const float* bias,
+                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, void* stream);
 /* ---- trunk backward, first slice (SURVEY.md 8f-3 groundwork; not on the imagination path) ----
  * FeedForward block (dreamer4.py:2079-2116) on the reference parameter layout: y = proj_out(a * silu(g)) with [a | g] = proj_in(RMSNorm(x));
  * x / y / dy / dx [rows][dim], norm_w [dim], w_in [2*inner][dim], b_in [2*inner], w_out [dim][inner], b_out [dim].  The backward

@@ -81,10 +81,10 @@ def test_gemm_bf16_lds_dma_form_matches_the_register_staged_form(M, N, K, flags)
             assert torch.equal(out, ref), c
 
 
-def _pair(kw, seed=0):
+def _pair(kw, seed=0, dtypes=('fp32', 'bf16')):
     torch.manual_seed(seed)
-    a = randomize_weights(DynamicsWorldModel(**kw), seed=seed)
-    b = DynamicsWorldModel(**kw, matmul_dtype='bf16')
+    a = randomize_weights(DynamicsWorldModel(**kw, matmul_dtype=dtypes[0]), seed=seed)
+    b = DynamicsWorldModel(**kw, matmul_dtype=dtypes[1])
     b.load_state_dict(a.state_dict())
     return a.cuda(), b.cuda()
 
@@ -124,3 +124,22 @@ def test_config5_shape_bf16_vs_fp32_at_the_per_gpu_batch():
     # frame 0's Beta parameters come from one evaluation chain: the sampled continuous actions agree to bf16 accuracy
     pa, pb = ea.old_action_unembeds.continuous[:, 0], eb.old_action_unembeds.continuous[:, 0]
     assert (pa - pb).abs().max().item() < 2e-2 * pa.abs().max().item()            # raw parameters of scale ~25: 1-2 % relative
+
+
+def test_fp32_default_with_split_operand_projections_equals_the_f32_mfma_engine_to_fp32_accuracy():
+    """matmul_dtype='fp32' (default) runs the SiLU-GLU input projections as split-operand fp32 GEMMs on the bf16 matrix cores
+    (csrc/gemm_x3.hip); 'fp32_mfma' keeps every GEMM on the f32-input MFMA.  Both are fp32 arithmetic: at config 2's architecture
+    (B = 32: 448 token rows per evaluation, 6 frames x 5 evaluations) they agree to fp32 rounding noise and sample the same actions."""
+    kw = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4)
+    a, b = _pair(kw, dtypes=('fp32', 'fp32_mfma'))
+    cfg = oracle_config(a)
+    B, T = 32, 6
+    nz = make_noise(cfg, T, B, 11)
+    gk = dict(return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, return_terminals=False)
+    ea = a.generate(T, batch_size=B, noise=nz, **gk)
+    eb = b.generate(T, batch_size=B, noise=nz, **gk)
+    d = (ea.latents - eb.latents).abs().max().item()
+    assert 0. < d < 2e-5, d                    # different summation order (it really took the other kernel), fp32 noise only
+    assert torch.equal(ea.actions.discrete, eb.actions.discrete)
+    assert (ea.values - eb.values).abs().max().item() < 2e-4
+    assert (ea.agent_embed - eb.agent_embed).abs().max().item() < 2e-5 * max(1., ea.agent_embed.abs().max().item())

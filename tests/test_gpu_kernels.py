@@ -109,7 +109,7 @@ def test_gemm_second_family_every_configuration(lib, M, N, K):
     """gemm2.hip (16x16x4 MFMA fed by the LDS-DMA ring): every configuration against fp64, partial tiles included, and all of
     them bit-identical to each other (the choice among them is made by timing)."""
     n1 = lib.d4_gemm_force_config(-1)
-    n2 = lib.d4_profile_classes() - n1
+    n2 = sum(lib.d4_profile_class_name(c).decode().startswith('gemm2_kernel') for c in range(lib.d4_profile_classes()))
     assert n2 >= 4
     variants = [dict(), dict(flags=_lib.GEMM_RMS_ROWSCALE, bias=True), dict(flags=_lib.GEMM_SILU, bias=True, res=True)]
     ref = None
@@ -128,7 +128,7 @@ def test_gemm_second_family_every_configuration(lib, M, N, K):
 @pytest.mark.parametrize('M,N,K', [(45, 192, 64), (3584, 2752, 512), (256, 128, 32), (300, 2752, 512)])
 def test_gemm_second_family_swiglu(lib, M, N, K):
     n1 = lib.d4_gemm_force_config(-1)
-    n2 = lib.d4_profile_classes() - n1
+    n2 = sum(lib.d4_profile_class_name(c).decode().startswith('gemm2_kernel') for c in range(lib.d4_profile_classes()))
     outs = []
     try:
         for c in range(n2):
@@ -152,6 +152,74 @@ def test_gemm_row_scale_is_identical_across_families(lib):
     finally:
         lib.d4_gemm_force_config(-1)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def split_planes(lib, W):
+    """W [N][K] fp32 -> the three bf16 planes d4_gemm_split reads (d4_split_bf16x3)."""
+    n = W.numel()
+    plane = (n + 7) // 8 * 8
+    W3 = torch.zeros(3 * plane, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.d4_split_bf16x3(_lib.ptr(W), _lib.ptr(W3), n, plane, stream()))
+    return W3, plane
+
+
+def test_split_bf16x3_is_an_exact_decomposition(lib):
+    """Every fp32 number is the exact sum of its three bf16 planes (3 x 8 significant bits; round to nearest even at each level)."""
+    g = torch.Generator(device='cuda').manual_seed(0)
+    W = torch.randn(1000, 96, device='cuda', generator=g) * torch.exp(4 * torch.randn(1000, 96, device='cuda', generator=g))
+    W3, plane = split_planes(lib, W)
+    n = W.numel()
+    parts = [W3[i * plane:i * plane + n].double() for i in range(3)]
+    assert torch.equal((parts[0] + parts[1] + parts[2]).float().reshape(W.shape), W)
+    assert torch.equal(parts[0].float().reshape(W.shape), W.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize('M,N,K,flags', [(3584, 2752, 512, 5), (3584, 512, 1376, 0), (1000, 300, 96, 1), (45, 388, 32, 3), (3840, 2064, 512, 1),
+                                         (130, 129, 2048, 0), (257, 64, 64, 2)])
+def test_gemm_split_operands_is_fp32_accurate(lib, M, N, K, flags):
+    """gemm_x3.hip: fp32 GEMM on the bf16 matrix cores (operands split into three bf16 numbers, six products, fp32 accumulate).
+    It must be an fp32 GEMM, not a reduced-precision one: its error against float64 may not exceed the f32-input MFMA kernels'
+    (measured: about 0.4x), every tile configuration gives the same bits, and all epilogues (folded RMSNorm, bias, SiLU, SiLU-GLU,
+    residual) and partial tiles agree with float64."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    b = torch.randn(N, device='cuda', generator=g)
+    swiglu = bool(flags & _lib.GEMM_SWIGLU)
+    R = None if swiglu else torch.randn(M, N, device='cuda', generator=g)
+    W3, plane = split_planes(lib, W)
+    Nout = N // 2 if swiglu else N
+    eps = 1.1920929e-07
+    Ad, Wd = A.double(), W.double()
+    X = Ad * torch.rsqrt(Ad.pow(2).mean(-1, keepdim=True) + eps) if flags & _lib.GEMM_RMS_ROWSCALE else Ad
+    ref = X @ Wd.t() + b.double()
+    if flags & _lib.GEMM_SILU:
+        ref = torch.nn.functional.silu(ref)
+    if swiglu:
+        r = ref.reshape(M, N // 64, 2, 32)
+        ref = (r[:, :, 0] * torch.nn.functional.silu(r[:, :, 1])).reshape(M, N // 2)
+    if R is not None:
+        ref = ref + R.double()
+    native = torch.full((M, Nout), float('nan'), device='cuda')
+    _lib.check(lib.d4_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(native), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, stream()))
+    outs = []
+    for cfg in range(6):
+        o = torch.full((M, Nout), float('nan'), device='cuda')
+        rc = lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, cfg, stream())
+        if rc != 0:                       # SiLU-GLU needs a wave tile of two 32-column sub-tiles: three of the six configurations
+            assert swiglu and cfg in (0, 1, 5), lib.d4_last_error()
+            continue
+        outs.append(o)
+    assert len(outs) >= 3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    rms = lambda x: (x.double() - ref).pow(2).mean().sqrt().item()
+    e_split, e_native = rms(outs[0]), rms(native)
+    # (+ one output rounding, 2^-24 / sqrt(3) of the result's rms: few-row shapes run natively on the VALU kernel, whose K-split tree sums
+    # leave little more than that)
+    slack = 6e-8 * ref.pow(2).mean().sqrt().item()
+    assert e_split <= 1.05 * e_native + slack, f'split-operand error {e_split:.3e} exceeds the f32-input MFMA error {e_native:.3e}'
+    tol = 3e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
+    assert (outs[0].double() - ref).abs().max().item() <= tol
 
 
 def test_gemm_rejects_misaligned_operands(lib):
