@@ -8,9 +8,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // PATTERN 0: 12 MFMAs on 12 independent accumulators; 1: the 8-wave tile's order (lo0 lo1 hi0 hi1 lo0 lo1 lo0 lo1 lo0 lo1 lo0 lo1);
 // 2: one accumulator (fully dependent chain); 3: two accumulators alternating
 template <int PATTERN>
-__global__ __launch_bounds__(512) void k(float* out, int iters) {
-    bf16x8 a, b;
-    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x + e); b[e] = (__bf16)(float)(e + 1); }
+__global__ __launch_bounds__(512) void k(float* out, int iters, const float* rnd) {
+    bf16x8 a, b;       // rnd == nullptr: constant small integers (few toggling bits); else random normal operands (what a GEMM feeds the pipe)
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (__bf16)(rnd ? rnd[(threadIdx.x * 16 + e) % 8192] : (float)(threadIdx.x + e));
+        b[e] = (__bf16)(rnd ? rnd[(threadIdx.x * 16 + 8 + e) % 8192] : (float)(e + 1));
+    }
     f32x16 acc[12];
     for (int i = 0; i < 12; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     for (int it = 0; it < iters; ++it) {
@@ -26,13 +29,20 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 }
 
 template <int P>
-void run(const char* name, int threads) {
+void run(const char* name, int threads, bool random = false) {
     float* out; hipMalloc(&out, 256 * 512 * 4 * 2);
-    const int iters = 4000;
+    float* rnd = nullptr;
+    if (random) {
+        static float host[8192];
+        unsigned s = 12345u;
+        for (int i = 0; i < 8192; ++i) { float acc = 0; for (int j = 0; j < 12; ++j) { s = s * 1664525u + 1013904223u; acc += (s >> 8) * (1.f / 16777216.f); } host[i] = acc - 6.f; }
+        hipMalloc(&rnd, sizeof(host)); hipMemcpy(rnd, host, sizeof(host), hipMemcpyHostToDevice);
+    }
+    const int iters = 40000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<P>, dim3(256), dim3(threads), 0, 0, out, 10);
+    hipLaunchKernelGGL(k<P>, dim3(256), dim3(threads), 0, 0, out, 10, rnd);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<P>, dim3(256), dim3(threads), 0, 0, out, iters);
+    hipLaunchKernelGGL(k<P>, dim3(256), dim3(threads), 0, 0, out, iters, rnd);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double mfma_per_simd = (double)iters * 12 * (threads / 64) / 4.0;
@@ -47,6 +57,8 @@ int main() {
         run<1>("gemm_x3 8-wave order (4 acc)", threads);
         run<3>("2 accumulators alternating", threads);
         run<2>("1 accumulator (dependent chain)", threads);
+        run<0>("12 independent, RANDOM operands", threads, true);
+        run<1>("gemm_x3 order, RANDOM operands", threads, true);
     }
     return 0;
 }
