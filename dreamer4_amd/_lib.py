@@ -69,6 +69,7 @@ class LearnIO(C.Structure):
         ('terminals', C.c_void_p),
         ('allreduce_sum', ALLREDUCE_FN), ('allreduce_user', C.c_void_p),
         ('losses', C.c_void_p), ('returns', C.c_void_p),
+        ('d_agent_embed_policy', C.c_void_p), ('d_agent_embed_value', C.c_void_p),
     ]
 
 

@@ -419,7 +419,8 @@ static int gemm_l(const float* A, int lda, const float* W, int ldw, float* C, in
 }
 
 // Backward of mlp_forward(save=...).  dout: [R][dims[nl]] gradient of the (un-activated) output.
-static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, const float* dout, int ld_dout, hipStream_t s) {
+// dx0 (optional, [R][dims[0]]): gradient with respect to the MLP's INPUT (the agent embeddings), for fine-tuning the whole world model
+static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, const float* dout, int ld_dout, hipStream_t s, float* dx0 = nullptr) {
     int rc;
     float* sx[9]; float* sxh[9]; float* sz[9];
     for (int i = 0; i < m.nl; ++i) m.save_ptrs(const_cast<float*>(save), R, i, &sx[i], &sxh[i], &sz[i]);
@@ -454,6 +455,7 @@ static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, co
         if (!pre) {
             // dx[r][k] = sum_n dz[r][n] * W[n][k] is the previous layer's activation gradient directly
             if (i > 0 && (rc = gemm_l(dzp, ldd, m.w[i], din, dy, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
+            if (i == 0 && dx0 && (rc = gemm_l(dzp, ldd, m.w[i], din, dx0, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
             cur = dy;
             continue;
         }
@@ -462,7 +464,7 @@ static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, co
         if ((rc = gemm_l(dzp, ldd, m.w[i], din, dxh, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
         // through the RMSNorm; dy of the previous layer overwrites e->l_tmp[0]; tg reuses dz (dz is dead after the GEMMs)
         float* tg = dz;
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, sx[i], dxh, m.g[i], tg, i > 0 ? dy : nullptr, R, din, RMS_EPS_L);
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, sx[i], dxh, m.g[i], tg, i > 0 ? dy : dx0, R, din, RMS_EPS_L);
         D4_LAUNCH_CHECK();
         if ((rc = colsum(tg, din, R, din, m.dg[i], s))) return rc;
         cur = dy;
@@ -582,8 +584,8 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
         // dpe (+)= dcparams . cu_w
         if ((rc = gemm_l(e->l_dcparams, Cpad, e->cu_w, 4 * D, dpe, 4 * D, R, 4 * D, 2 * nc, GEMM_TRANS_B | (na > 0 ? GEMM_ACCUMULATE : 0), s))) return rc;
     }
-    if ((rc = mlp_backward(e, e->policy, save_p, R, dpe, 4 * D, s))) return rc;
-    if ((rc = mlp_backward(e, e->value, save_v, R, e->l_dvbins, vld, s))) return rc;
+    if ((rc = mlp_backward(e, e->policy, save_p, R, dpe, 4 * D, s, io->d_agent_embed_policy))) return rc;
+    if ((rc = mlp_backward(e, e->value, save_v, R, e->l_dvbins, vld, s, io->d_agent_embed_value))) return rc;
     return 0;
 }
 

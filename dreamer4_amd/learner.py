@@ -34,10 +34,68 @@ class _NativeLoss(torch.autograd.Function):
         return (None, None, *out)
 
 
+class _NativeLossFull(torch.autograd.Function):
+    """The same, for learn_from_experience(only_learn_policy_value_heads=False): the loss also depends on the agent embeddings (which carry
+    the world model's graph), with d loss / d agent_embed computed by the HIP learner as well."""
+
+    @staticmethod
+    def forward(ctx, loss, grad_flat, d_embed, agent_embed, *params):
+        ctx.grad_flat, ctx.d_embed = grad_flat, d_embed
+        ctx.shapes = [p.shape for p in params]
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for s in shp:
+                n *= s
+            out.append(ctx.grad_flat[off:off + n].view(shp) * g)
+            off += n
+        return (None, None, None, ctx.d_embed * g, *out)
+
+
+def agent_embed_with_grad(model, exp):
+    """dreamer4.py:6045-6070 with gradient: ONE parallel forward over the experience's latents at the clean signal level, conditioned on
+    the stored actions, through the differentiable HIP trunk blocks (dreamer4_amd/trunk_ops.py).  Returns agent embeddings (B, T, dim)
+    connected to every world-model parameter."""
+    from math import log2
+    from dreamer4_amd import trunk_ops
+    dev = model.device
+    if exp.latents is None:
+        raise ValueError('fine-tuning the world model from an Experience needs its latents')
+    lat = exp.latents.to(dev).float()
+    if lat.ndim == 5:
+        lat = lat[:, :, 0]
+    if lat.shape[1] != exp.values.shape[1]:
+        raise NotImplementedError('recomputing agent embeddings for an experience with prompt frames is not implemented')
+    B, T = lat.shape[:2]
+    W = dict(model.named_parameters())
+    W.update({k: v for k, v in model.named_buffers() if k.endswith('inv_freq')})
+    is_time = [(i + 1) % model.time_block_every == 0 for i in range(model.depth)]
+    sig = torch.full((B, T), model.max_steps - 1, dtype=torch.long, device=dev)
+    step_log2 = torch.full((B,), int(log2(int(exp.step_size))), dtype=torch.long, device=dev)
+    da = exp.actions.discrete if exp.actions is not None else None
+    ca = exp.actions.continuous if exp.actions is not None else None
+    if da is not None:
+        da = (da[..., None] if da.ndim == 2 else da).to(dev).long()
+    if ca is not None:
+        ca = (ca[..., None] if ca.ndim == 2 else ca).to(dev).float()
+    tasks = getattr(exp, 'tasks', None)
+    _, agent = trunk_ops.world_model_prediction(
+        W, lat, sig, step_log2, is_time=is_time, num_spatial_tokens=model.num_spatial_tokens, num_register_tokens=model.num_register_tokens,
+        num_discrete_actions=tuple(model.num_discrete_actions), discrete_actions=da, continuous_actions=ca,
+        tasks=tasks.to(dev).long() if tasks is not None else None, softclamp_value=model.attn_softclamp_value)
+    return agent
+
+
 def run_learner(model, experience: Experience, objective='ppo', use_delight_gating=None, delight_temperature=None,
-                normalize_advantages=None, eps=1e-6, process_group=None, stats='global', want_returns=False):
-    """Runs d4_learn: returns (losses[2] device tensor, returns or None).  Head gradients land in the
-    per-group flat gradient buffers (model._groups[...]['grad'])."""
+                normalize_advantages=None, eps=1e-6, process_group=None, stats='global', want_returns=False, agent_embed=None,
+                want_embed_grads=False):
+    """Runs d4_learn: returns (losses[2] device tensor, returns or None) — plus (d policy_loss / d agent_embed, d value_loss / d agent_embed)
+    with `want_embed_grads`.  Head gradients land in the per-group flat gradient buffers (model._groups[...]['grad']).  `agent_embed`
+    overrides the experience's stored embeddings."""
     assert isinstance(experience, Experience)
     if objective not in _OBJECTIVES:
         raise ValueError(f'unknown objective {objective}')
@@ -45,7 +103,9 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
     exp = experience.to(dev)
     assert all(v is not None for v in (exp.log_probs, exp.actions, exp.values, exp.rewards, exp.step_size)), \
         'the generations need to contain the log probs, values, and rewards for policy optimization'
-    if exp.agent_embed is None:
+    if agent_embed is not None:
+        agent = agent_embed
+    elif exp.agent_embed is None:
         # generate(store_agent_embed=False): recompute the agent embeddings with one parallel forward over the stored latents at
         # the clean signal level, conditioned on the stored actions (dreamer4.py:6045-6070)
         if exp.latents is None:
@@ -110,6 +170,10 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
     io.actions_cont, io.old_log_probs_cont, io.old_cont_params = P(actions_c), P(old_lp_c), P(old_cparams)
     io.rewards, io.old_action_logits, io.lens, io.is_truncated, io.terminals = P(rewards), P(old_logits), P(lens), P(trunc), P(terms)
     io.losses, io.returns = P(losses), P(returns)
+    d_pol = d_val = None
+    if want_embed_grads:
+        d_pol, d_val = torch.zeros_like(agent), torch.zeros_like(agent)
+        io.d_agent_embed_policy, io.d_agent_embed_value = P(d_pol), P(d_val)
 
     cb, failure = None, []
     if stats == 'global' and (parallel.world_size(process_group) > 1 or parallel.force_collectives()):
@@ -134,14 +198,46 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
     if failure:
         raise failure[0]
     _lib.check(rc)
+    if want_embed_grads:
+        return losses, returns, (d_pol, d_val)
     return losses, returns
 
 
 def learn(model, experience, policy_optim, value_optim, only_learn_policy_value_heads, objective,
           use_delight_gating, delight_temperature, normalize_advantages, eps, process_group, stats):
     if not only_learn_policy_value_heads:
-        raise NotImplementedError('fine-tuning the whole world model through learn_from_experience is out of scope '
-                                  '(needs the trunk backward, SURVEY.md 8f-3)')
+        # fine-tuning the whole world model (dreamer4.py:6045-6075): agent embeddings from a forward WITH gradient through the HIP trunk
+        # blocks; the learner also returns d loss / d agent_embed, which autograd carries on into the trunk.  (Data parallel: only the head
+        # buckets are all-reduced by DreamTrainer — wrap the model / reduce the trunk gradients yourself for this mode.)
+        agent = agent_embed_with_grad(model, experience.to(model.device))
+        losses, _, (d_pol, d_val) = run_learner(model, experience, objective, use_delight_gating, delight_temperature, normalize_advantages,
+                                                eps, process_group, stats, agent_embed=agent.detach(), want_embed_grads=True)
+        gp, gv = model._groups['policy'], model._groups['value']           # (bound by the engine set-up inside run_learner)
+        policy_loss = _NativeLossFull.apply(losses[0], gp['grad'].clone(), d_pol, agent, *gp['params'])
+        value_loss = _NativeLossFull.apply(losses[1], gv['grad'].clone(), d_val, agent, *gv['params'])
+        # both losses hang off ONE world-model graph built before any step (as in the reference, whose value branch reuses the agent
+        # embeddings computed up front): take both gradients first — an optimiser step writes parameters the graph has saved — then step
+        params = [p for p in model.parameters() if p.requires_grad]
+
+        def grads_of(loss, retain):
+            for p in params:
+                p.grad = None
+            loss.backward(retain_graph=retain)
+            out = [p.grad for p in params]
+            for p in params:
+                p.grad = None
+            return out
+
+        gpol = grads_of(policy_loss, value_optim is not None) if policy_optim is not None else None
+        gval = grads_of(value_loss, False) if value_optim is not None else None
+        for optim, grads in ((policy_optim, gpol), (value_optim, gval)):
+            if optim is None:
+                continue
+            for p, gr in zip(params, grads):
+                p.grad = gr
+            optim.step()
+            optim.zero_grad()
+        return policy_loss, value_loss
     losses, _ = run_learner(model, experience, objective, use_delight_gating, delight_temperature,
                             normalize_advantages, eps, process_group, stats)
     gp, gv = model._groups['policy'], model._groups['value']

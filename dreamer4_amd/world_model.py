@@ -992,10 +992,11 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         process_group=None,
         stats='global',
     ):
-        """DynamicsWorldModel.learn_from_experience (dreamer4.py:5893-6305) for the default
-        `only_learn_policy_value_heads=True` path with stored agent embeddings.  Losses and the
+        """DynamicsWorldModel.learn_from_experience (dreamer4.py:5893-6305).  Losses and the
         gradients of both heads come from the HIP learner; the returned tensors are autograd-connected
         to the head parameters, so `loss.backward()` / optimiser usage is unchanged.
+        `only_learn_policy_value_heads=False` (dreamer4.py:6045-6075) recomputes the agent embeddings with a forward WITH gradient
+        through the differentiable HIP trunk blocks, so both losses also reach every world-model parameter.
 
         Data parallel: with an initialised process group and `stats='global'` the advantage
         statistics and every masked-mean denominator are all-reduced, so N ranks x B_local equal one

@@ -207,6 +207,11 @@ typedef struct d4_learn_io {
     void* allreduce_user;
     float* losses;                 /* device [2]: total_policy_loss, value_loss */
     float* returns;                /* optional device [batch][time] */
+    /* optional device [batch][time][dim] each: d total_policy_loss / d agent_embed and d value_loss / d agent_embed, for
+     * learn_from_experience(only_learn_policy_value_heads=False) (D4:6045-6075): the caller backpropagates them through the world model
+     * that produced agent_embed (dreamer4_amd/trunk_ops.py).  NULL (the default path): not computed. */
+    float* d_agent_embed_policy;
+    float* d_agent_embed_value;
 } d4_learn_io;
 
 int d4_learn(d4_engine* e, const d4_learn_io* io, void* stream);

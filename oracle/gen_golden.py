@@ -591,7 +591,45 @@ def gen_symexp():
     print('symexp margin', out['cached_margin'], 'lens', out['cached_lens'], 'values', out['cached_values'][0])
 
 
-EXTRA = dict(postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent, train_cont=gen_train_cont)
+def gen_learn_full():
+    """learn_full.npz / weights_learn_full.npz: learn_from_experience(only_learn_policy_value_heads=False) (D4:6045-6075): the agent
+    embeddings are recomputed by a forward WITH gradient over the stored latents at the clean signal level, so both losses reach the
+    whole world model.  Losses + the gradient of each loss with respect to every parameter it reaches (trunk, embeddings, heads)."""
+    cfg = Config(**CFG_TRAIN)
+    m = build_reference_model(cfg, seed=81)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)
+    W = weights_of(m)
+    save_weights('weights_learn_full.npz', W, CFG_TRAIN)
+    out = {}
+    nz = make_noise(cfg, 5, 3, 811)
+    with injected(nz):
+        e = m.generate(5, batch_size=3, return_for_policy_optimization=True)
+    exp_dict('exp_', e, out); noise_dict('exp_', nz, out)
+    out['exp_margin'] = np.array(min_margin(e, nz, cfg))
+    for obj in ('ppo', 'pmpo'):
+        m.zero_grad()
+        pl_, vl_ = m.learn_from_experience(e, objective=obj, only_learn_policy_value_heads=False)
+        out[f'{obj}_policy_loss'], out[f'{obj}_value_loss'] = npy(pl_), npy(vl_)
+        pl_.backward(retain_graph=True)
+        np_ = 0
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None and p_.numel() > 0 and float(p_.grad.abs().max()) > 0:
+                out[f'{obj}_pgrad/{k}'] = npy(p_.grad) if obj == 'ppo' else npy(p_.grad.norm()); np_ += 1       # pmpo: norms only (fixture size)
+        m.zero_grad()
+        vl_.backward()
+        nv_ = 0
+        for k, p_ in m.named_parameters():
+            if p_.grad is not None and p_.numel() > 0 and float(p_.grad.abs().max()) > 0:
+                if obj == 'ppo':
+                    out[f'{obj}_vgrad/{k}'] = npy(p_.grad)
+                nv_ += 1
+        print(obj, 'policy', float(pl_), 'value', float(vl_), 'grads', np_, nv_)
+    np.savez(os.path.join(OUT, 'learn_full.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    print('learn_full margin', out['exp_margin'], 'lens', out['exp_lens'])
+
+
+EXTRA = dict(learn_full=gen_learn_full, postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent, train_cont=gen_train_cont)
 
 
 def main():

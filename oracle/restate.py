@@ -1023,22 +1023,24 @@ def returns_and_advantage(cfg: Config, exp, normalize=True, eps=1e-6):
 
 
 def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, delight_temperature=None,
-                 normalize_advantages=None, eps=1e-6):
-    """learn_from_experience(only_learn_policy_value_heads=True) with stored agent embeds  D4:5893-6305.
-    Returns (total_policy_loss, value_loss); differentiable w.r.t. the head tensors in W.
+                 normalize_advantages=None, eps=1e-6, only_learn_policy_value_heads=True):
+    """learn_from_experience with stored agent embeds  D4:5893-6305.
+    Returns (total_policy_loss, value_loss); differentiable w.r.t. the head tensors in W — and, with
+    only_learn_policy_value_heads=False (D4:6045-6075: the agent embeddings are recomputed by a forward WITH gradient over the stored
+    latents and never detached), w.r.t. every world-model tensor in W.
     The three optional arguments default as the reference's do (D4:5905-5906, 6021)."""
     use_gate = cfg.use_delight_gating if use_delight_gating is None else use_delight_gating
     gate_temp = cfg.delight_temperature if delight_temperature is None else delight_temperature
     normalize = (objective != 'pmpo') if normalize_advantages is None else normalize_advantages
     returns, old_values, adv, mask = returns_and_advantage(cfg, exp, normalize=normalize, eps=eps)
     na, nc = len(cfg.num_discrete_actions), cfg.num_continuous_actions
-    if exp.get('agent_embed') is None:
-        # generate(store_agent_embed=False): the agent embeddings are recomputed with ONE parallel forward over the stored
-        # latents at the clean signal level, conditioned on the stored actions  D4:6045-6070
+    if exp.get('agent_embed') is None or not only_learn_policy_value_heads:
+        # generate(store_agent_embed=False), or fine-tuning the whole world model: the agent embeddings are recomputed with ONE
+        # parallel forward over the stored latents at the clean signal level, conditioned on the stored actions  D4:6045-6070
         lat = exp['latents']
         sig = torch.full(lat.shape[:2], cfg.max_steps - 1, dtype=torch.long)
-        with torch.no_grad():
-            _, agent_embeds, _ = wm_forward(cfg, W, lat, sig, exp['step_size'], exp.get('actions') if na > 0 else None, None, None,
+        with torch.set_grad_enabled(not only_learn_policy_value_heads):
+            _, agent_embeds, _ = wm_forward(cfg, W, lat, sig, exp['step_size'], exp.get('actions') if na > 0 else None, exp.get('tasks'), None,
                                             cont_actions=exp.get('actions_cont') if nc > 0 else None)
     else:
         agent_embeds = exp['agent_embed'].detach()

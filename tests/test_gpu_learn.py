@@ -46,6 +46,51 @@ def test_learn_vs_reference_fixture(objective):
     assert all(p.grad is None for k, p in P.items() if not k.startswith(HEADS)), 'only the two heads learn (D4:5898)'
 
 
+def test_learning_the_whole_world_model_vs_reference_fixture():
+    """learn_full.npz: learn_from_experience(only_learn_policy_value_heads=False) (D4:6045-6075).  The agent embeddings are recomputed by a
+    forward WITH gradient through the HIP trunk blocks, the HIP learner returns d loss / d agent_embed next to the head gradients, and
+    autograd carries it on: both losses and every one of the reference's 112 / 111 parameter gradients (ppo; norms under pmpo)."""
+    g = load_golden('learn_full.npz')
+    exp = Experience(latents=t(g['exp_latents']), agent_embed=t(g['exp_agent_embed']), rewards=t(g['exp_rewards']), values=t(g['exp_values']),
+                     log_probs=Actions(t(g['exp_log_probs']), None), actions=Actions(t(g['exp_actions']), None), lens=t(g['exp_lens']),
+                     terminals=t(g['exp_terminals']), is_truncated=~t(g['exp_terminals']), old_action_unembeds=Actions(t(g['exp_unembeds']), None),
+                     step_size=4)
+    for obj in ('ppo', 'pmpo'):
+        m = golden_model('weights_learn_full.npz').cuda()
+        pl, vl = m.learn_from_experience(exp, objective=obj, only_learn_policy_value_heads=False)
+        close(pl, g[f'{obj}_policy_loss'], atol=1e-5); close(vl, g[f'{obj}_value_loss'], atol=1e-5)
+        P = dict(m.named_parameters())
+        pl.backward(retain_graph=True)
+        n = 0
+        for k, v in g.items():
+            if k.startswith(f'{obj}_pgrad/'):
+                gr = P[k.split('/', 1)[1]].grad
+                assert gr is not None, k
+                if obj == 'ppo':
+                    close(gr, v, atol=3e-6, rtol=2e-3)
+                else:
+                    close(gr.norm(), v, atol=3e-6, rtol=2e-3)
+                n += 1
+        assert n == 112
+        if obj == 'ppo':
+            m.zero_grad()
+            vl.backward()
+            n = 0
+            for k, v in g.items():
+                if k.startswith('ppo_vgrad/'):
+                    gr = P[k.split('/', 1)[1]].grad
+                    assert gr is not None, k
+                    close(gr, v, atol=3e-6, rtol=2e-3); n += 1
+            assert n == 111
+    # with optimisers: one step of each moves trunk and heads
+    m = golden_model('weights_learn_full.npz').cuda()
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    po, vo = torch.optim.SGD(m.parameters(), lr=1e-2), torch.optim.SGD(m.parameters(), lr=1e-2)
+    m.learn_from_experience(exp, po, vo, only_learn_policy_value_heads=False)
+    moved = [k for k, p in m.named_parameters() if not torch.equal(p.detach(), before[k])]
+    assert any(k.startswith('transformer.layers.0') for k in moved) and any(k.startswith('value_head') for k in moved)
+
+
 @pytest.mark.parametrize('tag,kw', (('nogate', dict(objective='ppo', use_delight_gating=False)), ('temp', dict(objective='spo', delight_temperature=2.5)),
                                     ('rawadv', dict(objective='ppo', normalize_advantages=False)),
                                     ('pmpo_norm', dict(objective='pmpo', normalize_advantages=True, eps=1e-3))))
