@@ -6,6 +6,8 @@ from dreamer4_amd import DynamicsWorldModel
 from dreamer4_amd.synthetic import randomize_weights
 
 CFG = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4)
+if len(sys.argv) > 2 and sys.argv[2] == 'cfg5':       # BASELINE config 5 on the bf16 path, B = 128
+    CFG = dict(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_continuous_actions=6, matmul_dtype='bf16')
 
 
 def model():
@@ -21,7 +23,7 @@ def med(f, n=5):
 
 
 parts = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-B = 256
+B = 128 if 'matmul_dtype' in CFG else 256
 one = model()
 g = torch.Generator(device='cuda').manual_seed(1234)
 kw = dict(return_for_policy_optimization=True)
