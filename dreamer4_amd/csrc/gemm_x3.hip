@@ -14,6 +14,9 @@
 // host model of both, rms error 1.3e-7 vs 2.5e-7 of the result scale at K = 512): this is fp32 arithmetic re-associated, not a
 // reduced-precision mode — there is no bf16 rounding of any operand or result anywhere.
 //
+// Non-finite operands: an infinite a gives a2 = bf16(inf - inf) = NaN, so the result is NaN where the f32-input MFMA would give +-inf (both are
+// failures upstream: every operand on this path is finite); fp32 subnormals are below bf16's three-plane range and count as zero.
+//
 // Weights are split ONCE (engine prepare: split_bf16x3) into three planes [3][N][ldw] (plane stride p.wplane elements);
 // activations are split in registers on their way into LDS (11 VALU ops per pair of elements, beside the MFMAs).  The folded
 // RMSNorm's 1/rms is accumulated from the fp32 registers in the canonical order of the other families (one running sum per 16-byte
