@@ -151,7 +151,13 @@ def train_flow_step(device, B=16, T=16, reps=4):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
         out[f'{name}_ms_per_step'] = round(1e3 * dt, 2)
         out[f'{name}_frames_per_sec'] = round(B * T / dt, 1)
+    # GEMM work of one flow-only step: forward + its recomputation inside the backward operators + dX + dW = 4 x the forward's 2MNK
+    # (66.5 MFLOP per token, SURVEY.md 8d, + the learned-query pools) -> a lower bound on the executed flops, against the fp32 matrix peak
+    fwd_flop = 66.5e6 * B * T * 15 + 11.5e9 * (B * T) / 256.
+    out['flow_only_gemm_tflops'] = round(4. * fwd_flop / (out['flow_only_ms_per_step'] * 1e-3) / 1e12, 1)
+    out['flow_only_frac_of_fp32_matrix_peak'] = round(out['flow_only_gemm_tflops'] / PEAK_FP32_MFMA_TFLOPS, 3)
     out['workload'] = f'cfg2 architecture, training forward + backward, B={B} x T={T} frames x 15 tokens = {B * T * 15} token rows, fp32'
+
     return out
 
 
