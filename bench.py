@@ -16,8 +16,13 @@ the timed region.  Rank 0 prints ONE JSON line.
   roofline     = the dominant kernel (the fp32 MFMA GEMM tile configuration with the largest share of GPU time, found in the
                  warm-up step): algorithmic flops of its launches in the timed region / their summed HIP-event durations,
                  against the 157.3 TFLOP/s fp32 matrix peak
-  cpu_baseline = the CPU oracle (oracle/restate.py, torch fp32, all host cores) on a bounded sample of the same
-                 workload, rank 0 at N=1 only.  Reported baseline, not the target.
+  glue_kernels_hbm = the non-GEMM kernel classes of the rollout (attention cores, KV append, pool mix, ...): ALGORITHMIC bytes of
+                 their launches in the last warm-up step / their HIP-event durations, against the 8 TB/s HBM peak — measured live
+                 in this process (d4_profile_glue_*), not replayed from a file
+  cpu_baseline = the CPU oracle (oracle/restate.py, torch fp32) running the FULL workload once on 16 host threads, rank 0 at N=1
+                 only; cpu_baseline_sharded = the same workload sharded by trajectory over 16 processes x 16 threads (the fair
+                 "all host cores" form: the path is thousands of small ops, one process cannot use 256 threads).  Reported
+                 baselines, not the target.
 """
 from __future__ import annotations
 
@@ -94,6 +99,50 @@ def cpu_baseline(max_threads=16, full_budget_s=150.0):
                 f'num_steps={NUM_STEPS}) + learn(ppo)')
     return dict(value=steps / dt, unit='imagined steps/s', cores=cores, host_cores=host, kind='port',
                 sample=f'oracle/restate.py, {what} at dim=512 depth=6: {steps} imagined steps in {dt:.1f} s, torch fp32, {cores} of {host} host threads')
+
+
+def _cpu_shard_worker(args):
+    """One trajectory shard of the CPU baseline (spawned process): generate(B_shard, H+1) + learn(ppo) with `threads` intra-op threads."""
+    shard, batch, threads, frames = args
+    import torch as _t
+    _t.set_num_threads(threads)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import make_noise, oracle_config, oracle_weights
+    from dreamer4_amd import DynamicsWorldModel
+    from dreamer4_amd.synthetic import randomize_weights
+    from oracle import restate
+    _t.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG2), seed=0, terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    heads = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
+    with _t.no_grad():                                   # warm-up (thread pool, allocator), untimed
+        restate.generate(cfg, W, 1, batch_size=1, noise=make_noise(cfg, 1, 1, 1), num_steps=NUM_STEPS)
+    nz = make_noise(cfg, frames, batch, 1234 + shard)
+    t0 = time.perf_counter()
+    with _t.no_grad():
+        exp = restate.generate(cfg, W, frames, batch_size=batch, noise=nz, num_steps=NUM_STEPS)
+    Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
+    pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
+    pl.backward(); vl.backward()
+    return batch * exp['latents'].shape[1], time.perf_counter() - t0
+
+
+def cpu_baseline_sharded(procs=16, threads=16):
+    """The same full workload (B = 256, H + 1 = 16 frames + learn) sharded by dream trajectory over `procs` processes x `threads`
+    intra-op threads each (the path shards by trajectory, north_star).  Wall time = the slowest shard, model construction excluded
+    (each worker times its own generate + learn).  Per-shard advantage statistics (no cross-process reduce): baseline only."""
+    import multiprocessing as mp
+    host = os.cpu_count() or 1
+    procs = max(1, min(procs, host // max(threads, 1)) or 1)
+    per = B_LOCAL // procs
+    ctx = mp.get_context('spawn')
+    with ctx.Pool(procs) as pool:
+        res = pool.map(_cpu_shard_worker, [(i, per, threads, HORIZON + 1) for i in range(procs)])
+    steps = sum(r[0] for r in res)
+    dt = max(r[1] for r in res)
+    return dict(value=steps / dt, unit='imagined steps/s', cores=procs * threads, host_cores=host, kind='port',
+                sample=f'oracle/restate.py, the full workload sharded by trajectory: {procs} processes x {threads} threads, each generate(B={per}, '
+                       f'frames={HORIZON + 1}, num_steps={NUM_STEPS}) + learn(ppo): {steps} imagined steps, slowest shard {dt:.1f} s')
 
 
 CFG4 = dict(dim=512, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=6, num_discrete_actions=4)
@@ -224,16 +273,25 @@ def main():
     names = [n + (', *> fp32 by split operands on the bf16 MFMA' if sp else ', *> fp32 MFMA') for n, sp in zip(raw_names, is_split)]
     # warm-up: first-use tile autotuning of every GEMM shape happens here; the last warm-up step is also used to find the
     # dominant tile configuration (all configurations event-timed), so that the timed region only carries events for it
-    dom, warm_classes, warm_exec = None, None, (0., 0.)
+    dom, warm_classes, warm_exec, glue_measured = None, None, (0., 0.), None
     for w in range(args.warmup):
         last = timing and w == args.warmup - 1
         if last:
             torch.cuda.synchronize()
             lib.d4_profile_enable((1 << ncls) - 1)
+            lib.d4_profile_glue_enable((1 << lib.d4_profile_glue_classes()) - 1)
         trainer.train_step()
         if last:
             torch.cuda.synchronize()
             lib.d4_profile_enable(0)
+            lib.d4_profile_glue_enable(0)
+            ng = lib.d4_profile_glue_classes()
+            gms = (C.c_double * ng)(); gby = (C.c_double * ng)(); gcnt = (C.c_int64 * ng)()
+            _lib.check(lib.d4_profile_glue_read(gms, gby, gcnt, ng))
+            glue_measured = {lib.d4_profile_glue_class_name(i).decode(): dict(
+                hbm_gbs=round(gby[i] / max(gms[i], 1e-9) / 1e6, 1), frac_of_8tbs=round(gby[i] / max(gms[i], 1e-9) / 1e6 / 8000., 3),
+                avg_us=round(1e3 * gms[i] / gcnt[i], 2), launches=int(gcnt[i]), ms_per_step=round(gms[i], 2),
+                algorithmic_mb_per_launch=round(gby[i] / gcnt[i] / 1e6, 2)) for i in range(ng) if gcnt[i]}
             ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
             _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
             dom = max(range(ncls), key=lambda i: ms[i])
@@ -280,16 +338,17 @@ def main():
         if dom is None:
             dom = max(range(ncls), key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.
-        traffic, glue = None, None     # HBM bytes per launch from the committed rocprofv3 PMC passes (separate runs; profiles/pmc_traffic.json)
-        try:
+        traffic = None     # HBM bytes per launch of the dominant class from the committed rocprofv3 PMC passes (separate runs; profiles/pmc_traffic.json):
+        try:               # the class has an RMS and a non-RMS instantiation -> the one with the larger share of GPU time
             pj = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            for k, v in pj.get('kernels', {}).items():
-                if names[dom].startswith(k.split('>')[0].rstrip(', fp32MFMA*')[:30]):
-                    traffic = v['hbm_bytes_per_launch']
-            glue = {k: dict(hbm_gbs=v['hbm_gbs'], frac_of_8tbs=round(v['hbm_gbs'] / 8000., 3), avg_us=v['avg_us'])
-                    for k, v in pj.get('kernels', {}).items() if not k.startswith('gemm')}
+            stem = raw_names[dom]
+            cands = [v for k, v in pj.get('kernels', {}).items() if k.startswith(stem)]
+            if cands:
+                best = max(cands, key=lambda v: v['launches'] * v['avg_us'])
+                traffic = best['hbm_bytes_per_launch']
         except (OSError, ValueError, KeyError):
             pass
+        glue = glue_measured
         # a split-operand launch executes 6 bf16 MFMA products per fp32 product: its matrix-pipe bound is the bf16 dense peak / 6
         peak = PEAK_BF16_MFMA_TFLOPS / 6. if is_split[dom] else PEAK_FP32_MFMA_TFLOPS
         roofline = dict(bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s',
@@ -334,6 +393,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+        if (os.cpu_count() or 1) >= 64:
+            out['cpu_baseline_sharded'] = cpu_baseline_sharded()
     print(json.dumps(out))
 
 

@@ -11,6 +11,7 @@
 // HBM/latency bound (S = 15 tokens per frame): each q/k/v element is read exactly once per wave.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 #include <float.h>
 #include <stdlib.h>
 
@@ -340,7 +341,8 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
             attr_set = true;
         }
         if (p.groups * p.heads == 0) return 0;
-        hipLaunchKernelGGL(attn_wide_kernel, dim3(p.groups * p.heads), dim3(256), lds, stream, p);
+        const double wide_bytes = 4.0 * p.groups * p.heads * p.dh * ((double)p.nq * 2 + (double)p.nk * (p.vres ? 3 : 2));
+        D4_GLUE_LAUNCH(GL_ATTN_WIDE, wide_bytes, attn_wide_kernel, dim3(p.groups * p.heads), dim3(256), lds, stream, p);
         D4_LAUNCH_CHECK();
         return 0;
     }
@@ -351,15 +353,20 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
     if (waves == 0) return 0;
     dim3 block(256);
     if (p.nq == p.nk && p.nk <= 16 && p.nq >= 8 && p.q_group_stride != 0) {
-        if (p.dh == 64) hipLaunchKernelGGL(space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
+        // algorithmic bytes: q, k, v (+ value residual) rows of every (frame, head) read once, the kept query rows written once
+        const int nq_out = p.q_hi > 0 ? (p.q_hi - p.q_lo + p.q_last) : p.nq;
+        const double sp_bytes = 4.0 * p.groups * p.heads * (p.dh * ((double)p.nk * (p.vres ? 4 : 3) + nq_out) + 2.0 * p.nk);
+        if (p.dh == 64) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
         else if (p.dh == 32) hipLaunchKernelGGL(space_attn_kernel<32>, dim3(waves), block, 0, stream, p);
         else hipLaunchKernelGGL(space_attn_kernel<16>, dim3(waves), block, 0, stream, p);
         D4_LAUNCH_CHECK();
         return 0;
     }
+    // algorithmic bytes: a batch-independent operand (group stride 0) is counted once
+    const double sm_bytes = 4.0 * p.heads * p.dh * ((p.q_group_stride ? (double)p.groups : 1.0) * p.nq + (p.k_group_stride ? (double)p.groups : 1.0) * p.nk * 2 + (double)p.groups * p.nq);
 #define D4_SMALL_ATTN(NK)                                                                                       \
     do {                                                                                                          \
-        if (p.dh == 64) hipLaunchKernelGGL((small_attn_kernel<NK, 64>), dim3(waves), block, 0, stream, p);        \
+        if (p.dh == 64) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (small_attn_kernel<NK, 64>), dim3(waves), block, 0, stream, p);        \
         else if (p.dh == 32) hipLaunchKernelGGL((small_attn_kernel<NK, 32>), dim3(waves), block, 0, stream, p);   \
         else hipLaunchKernelGGL((small_attn_kernel<NK, 16>), dim3(waves), block, 0, stream, p);                   \
     } while (0)
@@ -659,8 +666,10 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
         D4_LAUNCH_CHECK();
         return 0;
     }
+    // algorithmic bytes: L hiddens + L projected keys per token row, queries + the row itself, the per-head mixes written
+    const double pm_bytes = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
     if (p.D <= 256) hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p);
-    else if (p.D <= 512) hipLaunchKernelGGL(pool_mix_kernel<2>, grid, block, 0, stream, p);
+    else if (p.D <= 512) D4_GLUE_LAUNCH(GL_POOL_MIX, pm_bytes, pool_mix_kernel<2>, grid, block, 0, stream, p);
     else hipLaunchKernelGGL(pool_mix_kernel<4>, grid, block, 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
@@ -876,7 +885,9 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.t0 + p.Tq <= p.Tcap, "time attention: cache capacity %d exceeded (t0=%d, Tq=%d)", p.Tcap, p.t0, p.Tq);
     const int waves = p.B * p.Tq * p.S * p.H;
     if (waves == 0) return 0;
-    if (p.dh == 64) hipLaunchKernelGGL(time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    // algorithmic bytes: k, v, value residual read from the projection rows; K and V written into the cache
+    const double ka_bytes = 4.0 * waves * p.dh * 5.0;
+    if (p.dh == 64) D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else if (p.dh == 32) hipLaunchKernelGGL(time_kv_append_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(time_kv_append_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
@@ -889,7 +900,9 @@ int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
     static const bool legacy = getenv("D4_TIME_ATTN_LEGACY") != nullptr;       // the one-key-per-reduction form (kept for head dims 16 / 32)
     if (p.dh == 64 && !legacy && (p.ldp % 4) == 0 && (p.ldo % 4) == 0) {
         const int units = p.B * p.S * p.H;
-        if (p.Tq == 1) hipLaunchKernelGGL(time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
+        // algorithmic bytes (cached decode): the K and V of frames 0..t0 of every (column, head) read once + q read + out written
+        const double ta_bytes = 4.0 * units * 64.0 * (2.0 * (p.t0 + 1) + 2.0);
+        if (p.Tq == 1) D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
         else {
             // one block per (column, head): min(Tq, 4) waves = query frames, the chunk's K / V staged once in LDS
             const int nwv = p.Tq < 4 ? p.Tq : 4;

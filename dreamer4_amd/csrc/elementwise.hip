@@ -4,6 +4,7 @@
 // (float4 where the layout allows), grid-stride.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 #include "beta.h"
 #include <float.h>
 
@@ -230,7 +231,7 @@ __global__ void assemble_kernel(AssembleArgs p) {
 int assemble_tokens(const AssembleArgs& p, hipStream_t s) {
     const int64_t n = (int64_t)p.B * p.Tq * p.S * p.D;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(assemble_kernel, grid1d(n), dim3(256), 0, s, p);
+    D4_GLUE_LAUNCH(GL_ASSEMBLE, 4.0 * (double)n + 4.0 * p.B * p.Tq * p.ns * p.D, assemble_kernel, grid1d(n), dim3(256), 0, s, p);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -300,7 +301,7 @@ __global__ void splitk_reduce_kernel(const float* part, int S, int M, int N, con
 }
 int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy, hipStream_t s) {
     if (M == 0) return 0;
-    hipLaunchKernelGGL(splitk_reduce_kernel, grid1d((int64_t)M * N), dim3(256), 0, s, part, S, M, N, bias, silu, y, ldy);
+    D4_GLUE_LAUNCH(GL_SPLITK_REDUCE, 4.0 * (double)M * N * (S + 1), splitk_reduce_kernel, grid1d((int64_t)M * N), dim3(256), 0, s, part, S, M, N, bias, silu, y, ldy);
     D4_LAUNCH_CHECK();
     return 0;
 }

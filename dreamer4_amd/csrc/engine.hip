@@ -5,6 +5,7 @@
 // host synchronisation; the only host-side state is the KV-cache frame counter.
 #include "common.h"
 #include "engine.h"
+#include "prof.h"
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1297,6 +1298,10 @@ int d4_profile_bf16_read(double* ms, double* flops, int64_t* count) { return d4:
 int d4_profile_enable(int on) { return d4::gemm_profile_enable(on); }
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass) { return d4::gemm_profile_read(ms, flops, count, nclass); }
 int d4_profile_classes(void) { return d4::gemm_profile_classes(); }
+int d4_profile_glue_enable(int mask) { return d4::glue_profile_enable(mask); }
+int d4_profile_glue_read(double* ms, double* bytes, int64_t* count, int nclass) { return d4::glue_profile_read(ms, bytes, count, nclass); }
+int d4_profile_glue_classes(void) { return d4::GL_N; }
+const char* d4_profile_glue_class_name(int c) { return d4::glue_class_name(c); }
 int d4_gemm_force_config(int id) {
     if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile configuration c of the split-operand fp32 family (gemm_x3.hip)
     if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1);

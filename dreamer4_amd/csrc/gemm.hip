@@ -23,6 +23,7 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include "kernels.h"
+#include <mutex>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -347,9 +348,12 @@ static hipEvent_t prof_event() {
 }
 
 bool gemm_bf16_profile_active();
-bool gemm_profile_active() { return g_prof_mask != 0 || gemm_bf16_profile_active(); }
+bool glue_profile_active();            // prof.cpp: event-timed launches cannot be captured into a graph either
+bool gemm_profile_active() { return g_prof_mask != 0 || gemm_bf16_profile_active() || glue_profile_active(); }
 
+static std::recursive_mutex& gemm_mutex();
 int gemm_profile_enable(int mask) {
+    std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
     g_prof_stride = (mask >> 24) > 0 ? (mask >> 24) : 1;          // bits 24..30: stride; bits 0..23: configurations
     mask &= 0xFFFFFF;
     g_prof_tick = 0;
@@ -359,6 +363,7 @@ int gemm_profile_enable(int mask) {
 
 // Sums elapsed time / algorithmic flops / launch count per tile class (0: 128x128, 1: 64x128, 2: 64x64) and clears the log.
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass) {
+    std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
     for (int i = 0; i < nclass; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
     // D4_GEMM_LOG=1: also print a per-shape table (launches, total ms, TFLOP/s) to stderr
     static const bool log_shapes = getenv("D4_GEMM_LOG") != nullptr;
@@ -759,7 +764,15 @@ static int gemm_v3(const GemmArgs& p, hipStream_t stream) {
     return launch_v3(best, p, stream);
 }
 
+// The dispatcher's process-global state (tile choices per shape, the tuning-cache file, the profiling log and its event pool, the static
+// per-instantiation attribute flags) is guarded by ONE recursive mutex taken at this entry: ctypes releases the GIL, and two engines may be
+// driven from two host threads (tools/two_stream_rollout.py).  Launches are asynchronous, so the lock is held for microseconds except
+// while a shape is being timed for the first time.
+static std::recursive_mutex g_gemm_mu;
+static std::recursive_mutex& gemm_mutex() { return g_gemm_mu; }
+
 int gemm(const GemmArgs& p, hipStream_t stream) {
+    std::lock_guard<std::recursive_mutex> lock(g_gemm_mu);
     D4_REQUIRE(p.M >= 0 && p.N > 0 && p.K > 0, "gemm: bad sizes M=%d N=%d K=%d", p.M, p.N, p.K);
     if (p.M == 0) return 0;
     const bool ta = p.flags & GEMM_TRANS_A, tb = p.flags & GEMM_TRANS_B;

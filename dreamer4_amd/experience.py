@@ -77,26 +77,35 @@ class Experience:
                 kwargs[k] = data_dict[k]
         return cls(**kwargs)
 
+    # ---- memmap replay buffer (third-party `memmap_replay_buffer.ReplayBuffer`, dreamer4.py:186-216).  `buffer_cls` lets a caller (or a
+    # test) supply the buffer class; by default the third-party package is imported, as the reference does.
+    @staticmethod
+    def _field_spec(value, leading_dims):
+        """Field declaration the buffer expects: a python type name for plain values, (dtype name, per-item shape) for tensors; dtype
+        names follow the reference's rule (dreamer4.py: tensor_dtype_to_string): 'bool', 'float' for EVERY floating dtype, else 'int'."""
+        if not torch.is_tensor(value):
+            return type(value).__name__
+        name = 'bool' if value.dtype == torch.bool else ('float' if value.is_floating_point() else 'int')
+        return name, tuple(value.shape[leading_dims:])
+
     @classmethod
-    def create_memmap_replay_buffer(cls, template_experience, *args, **kwargs):
-        from memmap_replay_buffer import ReplayBuffer        # third-party, as in the reference (dreamer4.py:190)
-        data_dict, meta_dict = template_experience.to_buffer_dict()
-
-        def infer(v, is_meta=False):
-            if not torch.is_tensor(v):
-                return type(v).__name__
-            return (str(v.dtype).replace('torch.', '').replace('float32', 'float').replace('int64', 'int'), tuple(v.shape[1:] if is_meta else v.shape[2:]))
-
-        return ReplayBuffer(*args, fields={k: infer(v) for k, v in data_dict.items()},
-                            meta_fields={k: infer(v, True) for k, v in meta_dict.items()}, **kwargs)
+    def create_memmap_replay_buffer(cls, template_experience, *args, buffer_cls=None, **kwargs):
+        if buffer_cls is None:
+            from memmap_replay_buffer import ReplayBuffer as buffer_cls
+        per_step, per_episode = template_experience.to_buffer_dict()
+        return buffer_cls(*args, fields={k: cls._field_spec(v, 2) for k, v in per_step.items()},          # (batch, time, ...) -> item shape
+                          meta_fields={k: cls._field_spec(v, 1) for k, v in per_episode.items()}, **kwargs)   # (batch, ...) -> item shape
 
     def add_to_memmap_buffer(self, buffer):
-        data_dict, meta_dict = self.to_buffer_dict()
-        batch_size, time_steps = self.payload.shape[:2]
-        meta_batch = {k: (v if torch.is_tensor(v) else [v] * batch_size) for k, v in meta_dict.items()}
-        with buffer.batched_episode(batch_size=batch_size, **meta_batch):
-            for step in range(time_steps):
-                buffer.store_batch(**{k: v[:, step] for k, v in data_dict.items()})
+        """One batched episode per call: per-episode values as keyword arguments of `batched_episode` (plain values repeated per
+        trajectory), then one `store_batch` per time step with the step's slice of every per-step field."""
+        per_step, per_episode = self.to_buffer_dict()
+        batch = self.payload.shape[0]
+        episode_kw = {k: (v if torch.is_tensor(v) else [v] * batch) for k, v in per_episode.items()}
+        names = list(per_step)
+        with buffer.batched_episode(batch_size=batch, **episode_kw):
+            for step_values in zip(*(per_step[k].unbind(1) for k in names)):
+                buffer.store_batch(**dict(zip(names, step_values)))
 
     def cpu(self):
         return self.to(torch.device('cpu'))

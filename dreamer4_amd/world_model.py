@@ -167,6 +167,12 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         head_mlp_recipe='pre_rms',
         matmul_dtype='fp32',
         use_loss_normalization=False,
+        latent_flow_loss_weight=1.,
+        shortcut_loss_weight=1.,
+        reward_loss_weight: float | list = 1.,
+        terminal_loss_weight=1.,
+        discrete_action_loss_weight: float | list = 1.,
+        continuous_action_loss_weight: float | list = 1.,
         **kwargs,
     ):
         """`head_mlp_recipe` is not a reference argument: it names the layer recipe of x_mlps_pytorch's normed MLP (see MLP_RECIPES)."""
@@ -188,6 +194,11 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
             raise ValueError("matmul_dtype must be 'fp32', 'fp32_mfma' or 'bf16'")
         self.matmul_dtype = matmul_dtype
         self.use_loss_normalization = bool(use_loss_normalization)
+        # loss weights of the training forward's total (dreamer4.py:4719-4725, 5257-5267, 7708-7723): two plain floats and four persistent
+        # buffers of 1 or multi_token_pred_len elements — a checkpoint's values are loaded and used
+        self.latent_flow_loss_weight, self.shortcut_loss_weight = float(latent_flow_loss_weight), float(shortcut_loss_weight)
+        self._loss_weight_init = dict(reward_loss_weight=reward_loss_weight, terminal_loss_weight=terminal_loss_weight,
+                                      discrete_action_loss_weight=discrete_action_loss_weight, continuous_action_loss_weight=continuous_action_loss_weight)
         for k, v in kwargs.items():
             if k not in _UNSUPPORTED_DEFAULTS:
                 raise TypeError(f'unknown argument {k!r}')
@@ -363,16 +374,20 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         _register(self, 'zero', torch.tensor(0.), buffer=True, persistent=False)
         # buffers of the reference's state_dict that the imagination path never reads (dreamer4.py:5245-5246, 5260-5263): registered
         # so that a reference checkpoint loads with strict=True
-        for name, val in (('ema_returns_mean', 0.), ('ema_returns_var', 1.), ('reward_loss_weight', 1.), ('terminal_loss_weight', 1.),
-                          ('discrete_action_loss_weight', 1.), ('continuous_action_loss_weight', 1.)):
+        for name, val in (('ema_returns_mean', 0.), ('ema_returns_var', 1.)):
             _register(self, name, torch.tensor(val), buffer=True)
+        for name, val in self._loss_weight_init.items():
+            w = torch.tensor(val, dtype=torch.float32)
+            assert w.numel() in (1, self.multi_token_pred_len), f'{name}: 1 or multi_token_pred_len values (dreamer4.py:5265-5267)'
+            _register(self, name, w, buffer=True)
         # LossNormalizer state of the training forward (dreamer4.py:629-669, 5250-5255): running mean of the squared loss per term
         if self.use_loss_normalization:
             mtp = self.multi_token_pred_len
             for name, n, on in (('flow_loss_normalizer', 1, True), ('shortcut_flow_loss_normalizer', 1, True), ('reward_loss_normalizer', mtp, True),
                                 ('state_terminal_loss_normalizer', 1, self.predict_terminals),
-                                ('discrete_actions_loss_normalizer', mtp, len(self.num_discrete_actions) > 0),
-                                ('continuous_actions_loss_normalizer', mtp, self.num_continuous_actions > 0)):
+                                # the reference creates both action normalizers whenever normalisation is on (`exists(0)` is true, dreamer4.py:5254-5255)
+                                ('discrete_actions_loss_normalizer', mtp, True),
+                                ('continuous_actions_loss_normalizer', mtp, True)):
                 if on:
                     _register(self, name + '.exp_avg_sq', torch.ones(n), buffer=True)
 
@@ -753,8 +768,10 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
                           ('discrete_actions', 'discrete_actions_loss_normalizer'), ('continuous_actions', 'continuous_actions_loss_normalizer')):
             if key in agent:
                 agent[key] = self._normalize_loss(name, agent[key], upd)
-        # unit loss weights: the reference defaults (dreamer4.py:4719-4725, 7708-7723)
-        total = flow + short + sum(v.sum() for v in agent.values())
+        # the reference's weighted total (dreamer4.py:7708-7723); the per-term weights are the module's buffers (1 or mtp elements)
+        wmap = dict(rewards=self.reward_loss_weight, terminals=self.terminal_loss_weight, discrete_actions=self.discrete_action_loss_weight,
+                    continuous_actions=self.continuous_action_loss_weight)
+        total = flow * self.latent_flow_loss_weight + short * self.shortcut_loss_weight + sum((v * wmap[k].to(v.device)).sum() for k, v in agent.items())
         if not return_all_losses:
             return total
         from collections import namedtuple

@@ -236,6 +236,13 @@ int d4_profile_enable(int mask);
 int d4_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int d4_profile_classes(void);
 const char* d4_profile_class_name(int c);
+/* The same for the non-GEMM kernel classes of the rollout (within-frame / time attention, KV append, attention-pool mix, the small
+ * attention forms, token assembly, split-K reduce): d4_profile_glue_read sums elapsed ms / ALGORITHMIC HBM bytes / launches per class.
+ * Mask and stride as d4_profile_enable.  (bench.py's HBM roofline leg; replaces nothing in the reference.) */
+int d4_profile_glue_enable(int mask);
+int d4_profile_glue_read(double* ms, double* bytes, int64_t* count, int nclass);
+int d4_profile_glue_classes(void);
+const char* d4_profile_glue_class_name(int c);
 
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the

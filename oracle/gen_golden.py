@@ -45,7 +45,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle.ref_harness import build_reference_model, injected, make_noise, weights_of   # noqa: E402
-from oracle.ref_import import load_reference                                            # noqa: E402
+from oracle.ref_import import load_reference, third_party_sources                       # noqa: E402
 from oracle.restate import Config                                                       # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
@@ -632,7 +632,18 @@ def gen_learn_full():
 EXTRA = dict(learn_full=gen_learn_full, postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent, train_cont=gen_train_cont)
 
 
+def _record_third_party_sources():
+    """META['oracle'] stays 'shim' while every stood-in package came from oracle/shim; under D4_ORACLE_REAL=1 with real packages
+    installed it names, per package, which ones the reference imported for real (the one-flag switch)."""
+    load_reference()
+    src = third_party_sources()
+    real = sorted(k for k, v in src.items() if v == 'real')
+    if real:
+        META['oracle'] = 'real: ' + ' '.join(real) + ' | shim: ' + ' '.join(sorted(k for k, v in src.items() if v != 'real'))
+
+
 def main():
+    _record_third_party_sources()
     if len(sys.argv) > 1:                     # python -m oracle.gen_golden postln continuous : only these families
         os.makedirs(OUT, exist_ok=True)
         for name in sys.argv[1:]:

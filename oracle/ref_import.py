@@ -19,14 +19,49 @@ def reference_available():
 
 _cached = None
 
+# The stand-ins on the imagination path.  D4_ORACLE_REAL=1: a REAL installed package wins over its stand-in — the
+# shim directory goes to the END of sys.path instead of the front, so `import x_mlps_pytorch` finds the site-packages copy first — and
+# `third_party_sources()` reports, per package, which one the reference actually imported (gen_golden records it in every fixture).
+SHIMMED = ('x_mlps_pytorch', 'hl_gauss_pytorch', 'discrete_continuous_embed_readout', 'assoc_scan', 'einx', 'torch_einops_utils')
+
+
+def prefer_real():
+    return os.environ.get('D4_ORACLE_REAL', '0') == '1'
+
+
+def resolve_third_party():
+    """Which of the stood-in packages would resolve to a real installation (outside oracle/shim) right now."""
+    real = {}
+    for name in SHIMMED:
+        found = None
+        for entry in sys.path:
+            if os.path.abspath(entry or '.') == _SHIM:
+                continue
+            if os.path.isdir(os.path.join(entry or '.', name)) or os.path.isfile(os.path.join(entry or '.', name + '.py')):
+                found = entry
+                break
+        real[name] = found
+    return real
+
+
+def third_party_sources():
+    """After load_reference(): {'package': 'real' | 'shim'} by where the imported module lives."""
+    out = {}
+    for name in SHIMMED:
+        mod = sys.modules.get(name)
+        f = getattr(mod, '__file__', None) or ''
+        out[name] = 'unloaded' if mod is None else ('shim' if os.path.abspath(f).startswith(_SHIM) else 'real')
+    return out
+
 def load_reference():
     """Returns the reference `dreamer4.dreamer4` module object."""
     global _cached
     if _cached is not None:
         return _cached
     assert reference_available(), f'{REFERENCE_ROOT} not present (GPU box?)'
+    resolve_third_party()
     if _SHIM not in sys.path:
-        sys.path.insert(0, _SHIM)
+        sys.path.append(_SHIM) if prefer_real() else sys.path.insert(0, _SHIM)
     import _inert
     _inert.install()
     path = os.path.join(REFERENCE_ROOT, 'dreamer4', 'dreamer4.py')

@@ -18,8 +18,8 @@ Everything is a plain function of (config, weights dict keyed by the
 reference's state_dict names, explicit noise tensors).  No hidden RNG.
 
 Parity pin: `oracle/gen_golden.py` imports the reference unmodified through
-`oracle/shim/` in the build container and checks this file against it
-(tests/test_oracle_vs_reference.py), then freezes tests/golden/*.npz.  The
+`oracle/shim/` in the build container and freezes its outputs into tests/golden/*.npz;
+tests/test_oracle_golden.py checks this file against those fixtures.  The
 third-party pieces the reference delegates to (x_mlps_pytorch create_mlp /
 Ensemble, hl_gauss_pytorch, discrete_continuous_embed_readout.MultiCategorical,
 assoc_scan, torch_einops_utils.masked_mean) are absent from the image: they are

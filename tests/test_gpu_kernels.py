@@ -222,6 +222,55 @@ def test_gemm_split_operands_is_fp32_accurate(lib, M, N, K, flags):
     assert (outs[0].double() - ref).abs().max().item() <= tol
 
 
+def test_gemm_split_operands_wide_exponent_spread(lib):
+    """gemm_x3.hip with operands whose magnitudes span 2^120 inside one row (|a|, |w| from 2^-60 to 2^60): every output must stay within
+    fp32 rounding of float64 RELATIVE TO sum_k |a_k w_k| (the dropped a2.w3 + a3.w2 + a3.w3 terms are <= 2^-24 of each product, and no
+    plane of a normal fp32 number of this range is a bf16 subnormal), and no worse than the f32-input MFMA on the same operands."""
+    M, N, K = 256, 256, 512
+    g = torch.Generator(device='cuda').manual_seed(11)
+
+    def spread(r, c):
+        mag = torch.exp2(torch.randint(-60, 61, (r, c), device='cuda', generator=g).float())
+        return torch.randn(r, c, device='cuda', generator=g) * mag
+    A, W = spread(M, K), spread(N, K)
+    W3, plane = split_planes(lib, W)
+    ref = A.double() @ W.double().t()
+    scale = A.double().abs() @ W.double().abs().t()
+    native = torch.full((M, N), float('nan'), device='cuda'); o = torch.full((M, N), float('nan'), device='cuda')
+    _lib.check(lib.d4_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(native), N, None, None, N, M, N, K, 0, 0., stream()))
+    _lib.check(lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), N, None, None, N, M, N, K, 0, 0., 0, stream()))
+    assert torch.isfinite(o).all()
+    e_split = ((o.double() - ref).abs() / scale).max().item()
+    e_native = ((native.double() - ref).abs() / scale).max().item()
+    assert e_split <= 2.5e-7, e_split                      # a few ulp of fp32 relative to the absolute-value sum
+    assert e_split <= 1.25 * e_native + 6e-8, (e_split, e_native)
+
+
+def test_gemm_split_operands_non_finite_and_subnormal_operands(lib):
+    """The documented edge behaviour of gemm_x3.hip: an infinite or NaN operand makes every output that depends on
+    it NON-FINITE (NaN where the f32-input MFMA gives +-inf: a2 = bf16(inf - inf)) and leaves every other output untouched — a failure
+    upstream is never turned into a finite number; fp32 subnormal operands count as zero (error <= K * 2^-126 * max|other operand|)."""
+    M, N, K = 64, 128, 256
+    g = torch.Generator(device='cuda').manual_seed(12)
+    A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g)
+    A[3, 7] = float('inf'); A[5, 9] = float('nan'); W[11, 20] = float('-inf')
+    W3, plane = split_planes(lib, W)
+    o = torch.zeros(M, N, device='cuda'); native = torch.zeros(M, N, device='cuda')
+    _lib.check(lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), N, None, None, N, M, N, K, 0, 0., 0, stream()))
+    _lib.check(lib.d4_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(native), N, None, None, N, M, N, K, 0, 0., stream()))
+    bad = torch.zeros(M, N, dtype=torch.bool, device='cuda'); bad[3] = True; bad[5] = True; bad[:, 11] = True
+    assert (~torch.isfinite(o[bad])).all() and (~torch.isfinite(native[bad])).all()
+    assert torch.isfinite(o[~bad]).all()
+    ref = A.double() @ W.double().t()
+    assert torch.allclose(o[~bad].double(), ref[~bad], atol=3e-5, rtol=1e-5)
+    # subnormals: a row of A that holds only fp32 subnormals contributes (at most) its exact tiny product
+    A2 = torch.randn(M, K, device='cuda', generator=g); A2[0] = 1e-40
+    o2 = torch.zeros(M, N, device='cuda')
+    _lib.check(lib.d4_gemm_split(_lib.ptr(A2), K, _lib.ptr(W3), plane, K, _lib.ptr(o2), N, None, None, N, M, N, K, 0, 0., 0, stream()))
+    keep = torch.ones(N, dtype=torch.bool, device='cuda'); keep[11] = False
+    assert o2[0, keep].abs().max().item() <= K * 1e-40 * 8.
+
+
 def test_gemm_rejects_misaligned_operands(lib):
     A = torch.randn(8, 34, device='cuda')
     with pytest.raises(_lib.D4Error, match='multiples of 4'):

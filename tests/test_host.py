@@ -139,8 +139,55 @@ def test_experience_replay_buffer_dictionaries_round_trip():
     assert set(meta) == {'step_size', 'lens', 'is_truncated', 'agent_index', 'is_from_world_model'}
     back = Experience.from_buffer_dict({**data, **meta})
     assert torch.equal(back.actions.continuous, e.actions.continuous) and back.log_probs.continuous is None and back.step_size == 16
-    with pytest.raises(ImportError):
+    with pytest.raises(ImportError):                       # default: the third-party buffer, as the reference (absent from the image)
         Experience.create_memmap_replay_buffer(e, './x', max_episodes=1, max_timesteps=4)
+
+
+class _StubReplayBuffer:
+    """The call pattern dreamer4.py:186-216 makes against memmap_replay_buffer.ReplayBuffer, recorded: constructor (fields=,
+    meta_fields=), `with buffer.batched_episode(batch_size=, **meta)`, one `store_batch(**fields)` per time step."""
+
+    def __init__(self, folder, max_episodes, max_timesteps, fields, meta_fields):
+        self.fields, self.meta_fields, self.max_timesteps = fields, meta_fields, max_timesteps
+        self.episodes, self._open = [], None
+
+    def batched_episode(self, batch_size, **meta):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._open = dict(batch_size=batch_size, meta=meta, steps=[])
+            yield
+            self.episodes.append(self._open); self._open = None
+        return cm()
+
+    def store_batch(self, **step):
+        assert self._open is not None and set(step) == set(self.fields)
+        for k, v in step.items():
+            kind, shape = self.fields[k]
+            assert tuple(v.shape) == (self._open['batch_size'], *shape), k
+            assert kind == ('bool' if v.dtype == torch.bool else 'float' if v.is_floating_point() else 'int')
+        self._open['steps'].append(step)
+
+
+def test_experience_memmap_buffer_call_pattern_with_a_stub_buffer():
+    """create_memmap_replay_buffer / add_to_memmap_buffer against a stub with the reference's call pattern (dreamer4.py:186-216): field
+    declarations use the reference's dtype rule ('bool' / 'float' for every floating dtype / 'int' for everything else — uint8 terminals
+    and int32 lens included), per-step fields drop (batch, time), per-episode fields drop (batch), and the stored steps restore the tensors."""
+    B, T = 2, 3
+    e = Experience(latents=torch.randn(B, T, 4, 5).half(), rewards=torch.ones(B, T), terminals=torch.zeros(B, dtype=torch.uint8),
+                   actions=Actions(torch.arange(B * T).reshape(B, T, 1), torch.rand(B, T, 2)), lens=torch.tensor([3, 2], dtype=torch.int32),
+                   is_truncated=torch.tensor([True, False]), step_size=16)
+    buf = Experience.create_memmap_replay_buffer(e, './x', max_episodes=4, max_timesteps=8, buffer_cls=_StubReplayBuffer)
+    assert buf.fields == {'latents': ('float', (4, 5)), 'rewards': ('float', ()), 'actions_discrete': ('int', (1,)), 'actions_continuous': ('float', (2,))}
+    assert buf.meta_fields['terminals'] == ('int', ())            # a per-episode (meta) field of the reference, uint8 here -> 'int'
+    assert buf.meta_fields['lens'] == ('int', ()) and buf.meta_fields['is_truncated'] == ('bool', ()) and buf.meta_fields['step_size'] == 'int'
+    e.add_to_memmap_buffer(buf)
+    (ep,) = buf.episodes
+    assert ep['batch_size'] == B and len(ep['steps']) == T and ep['meta']['step_size'] == [16, 16] and torch.equal(ep['meta']['lens'], e.lens)
+    stacked = {k: torch.stack([s[k] for s in ep['steps']], 1) for k in buf.fields}
+    back = Experience.from_buffer_dict({**stacked, **{k: v for k, v in ep['meta'].items() if torch.is_tensor(v)}, 'step_size': 16})
+    assert torch.equal(back.latents, e.latents) and torch.equal(back.actions.discrete, e.actions.discrete) and torch.equal(back.terminals, e.terminals)
 
 
 def test_save_load_and_init_and_load(tmp_path):
@@ -163,6 +210,48 @@ def test_save_load_and_init_and_load(tmp_path):
     assert tok2.image_height == 16 and torch.equal(tok2.state_dict()['latents_to_decoder.weight'], tok.state_dict()['latents_to_decoder.weight'])
 
 
+def test_checkpoint_files_laid_out_as_the_reference_trainer_writes_them(tmp_path):
+    """trainers.py:1074-1088 is the only in-tree evidence of the file layout: dict(model=state_dict, config=pickle.dumps(dehydrated
+    `_config`) or None, step=int), `_config` a live object on the module.  Files written that way — by this package's `save`, by hand
+    with a plain (args, kwargs) config, with config=None, and as a bare state_dict (trainers.py:1048-1072 accepts `pkg.get('model', pkg)`)
+    — all load; a nested video tokenizer survives the round trip as a rebuilt module; an unknown config structure fails with a message."""
+    import pickle
+    from dreamer4_amd import VideoTokenizer
+    tok = VideoTokenizer(dim=32, dim_latent=8, patch_size=4, image_size=16, num_latent_tokens=4, decoder_depth=2)
+    m = small_model(dim_latent=8, num_latent_tokens=4, video_tokenizer=tok, latent_flow_loss_weight=0.5, multi_token_pred_len=2, reward_loss_weight=[1., 0.25])
+    assert isinstance(m._config, tuple) and m._config[1]['video_tokenizer'] is tok and '_config' not in m.state_dict()
+    m.save(tmp_path / 'a.pt', step=7)
+    pkg = torch.load(tmp_path / 'a.pt', weights_only=False)
+    assert set(pkg) >= {'model', 'config', 'step'} and pkg['step'] == 7 and isinstance(pkg['config'], bytes)
+    args, kwargs = pickle.loads(pkg['config'])                       # unpickles without this package's classes: plain containers only
+    assert args == () and kwargs['video_tokenizer']['__d4_module__'] == 'VideoTokenizer'
+    m2 = DynamicsWorldModel.init_and_load(tmp_path / 'a.pt')
+    assert isinstance(m2.video_tokenizer, VideoTokenizer) and m2.video_tokenizer.image_height == 16
+    assert m2.latent_flow_loss_weight == 0.5 and torch.equal(m2.reward_loss_weight, torch.tensor([1., 0.25]))
+    # by hand, the way save_checkpoint does it, with an already-plain config and a step
+    plain = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, num_discrete_actions=4, multi_token_pred_len=2)
+    src = DynamicsWorldModel(**plain)
+    torch.save(dict(model=src.state_dict(), config=pickle.dumps(((), plain)), step=3), tmp_path / 'b.pt')
+    assert DynamicsWorldModel.init_and_load(tmp_path / 'b.pt', strict=False).dim == 32
+    torch.save(dict(model=src.state_dict(), config=pickle.dumps(dict(args=(), kwargs=plain)), step=3), tmp_path / 'b2.pt')
+    assert DynamicsWorldModel.init_and_load(tmp_path / 'b2.pt').depth == 2
+    # config = None (a model without `_config`): needs the constructor arguments, or .load on a built model
+    torch.save(dict(model=src.state_dict(), config=None, step=3), tmp_path / 'c.pt')
+    with pytest.raises(TypeError, match='without a config'):
+        DynamicsWorldModel.init_and_load(tmp_path / 'c.pt')
+    assert DynamicsWorldModel.init_and_load(tmp_path / 'c.pt', **plain).depth == 2
+    DynamicsWorldModel(**plain).load(tmp_path / 'c.pt')
+    torch.save(src.state_dict(), tmp_path / 'd.pt')                     # bare state_dict
+    DynamicsWorldModel(**plain).load(tmp_path / 'd.pt')
+    torch.save(dict(model=src.state_dict(), config=pickle.dumps(42)), tmp_path / 'e.pt')
+    with pytest.raises(TypeError, match='unknown structure'):
+        DynamicsWorldModel.init_and_load(tmp_path / 'e.pt')
+    # a reference checkpoint trained with loss normalisation carries BOTH action normalizers (dreamer4.py:5254-5255) and loss-weight buffers
+    ref_like = DynamicsWorldModel(**plain, use_loss_normalization=True).state_dict()
+    assert {'discrete_actions_loss_normalizer.exp_avg_sq', 'continuous_actions_loss_normalizer.exp_avg_sq', 'reward_loss_weight',
+            'terminal_loss_weight', 'discrete_action_loss_weight', 'continuous_action_loss_weight'} <= set(ref_like)
+
+
 def test_loss_normalizer_state_and_beta_zero_property():
     """The training forward's LossNormalizer (reference tests/test_dreamer.py:558-569): with beta = 0 the second call of the same loss
     returns exactly 1; buffers carry the reference's state_dict keys only when `use_loss_normalization=True`."""
@@ -174,7 +263,8 @@ def test_loss_normalizer_state_and_beta_zero_property():
     m = DynamicsWorldModel(**kw, use_loss_normalization=True)
     keys = {k for k in m.state_dict() if 'loss_normalizer' in k}
     assert keys == {'flow_loss_normalizer.exp_avg_sq', 'shortcut_flow_loss_normalizer.exp_avg_sq', 'reward_loss_normalizer.exp_avg_sq',
-                    'state_terminal_loss_normalizer.exp_avg_sq', 'discrete_actions_loss_normalizer.exp_avg_sq'}
+                    'state_terminal_loss_normalizer.exp_avg_sq', 'discrete_actions_loss_normalizer.exp_avg_sq',
+                    'continuous_actions_loss_normalizer.exp_avg_sq'}          # both action normalizers, always (dreamer4.py:5254-5255: exists(0))
     assert m.state_dict()['reward_loss_normalizer.exp_avg_sq'].shape == (2,)
     loss = torch.tensor([3., 0.5])
     first = m._normalize_loss('reward_loss_normalizer', loss, True, beta=0.)
