@@ -20,7 +20,7 @@ the timed region.  Rank 0 prints ONE JSON line.
                  their launches in the last warm-up step / their HIP-event durations, against the 8 TB/s HBM peak — measured live
                  in this process (d4_profile_glue_*), not replayed from a file
   cpu_baseline = the CPU oracle (oracle/restate.py, torch fp32) running the FULL workload once on 16 host threads, rank 0 at N=1
-                 only; cpu_baseline_sharded = the same workload sharded by trajectory over 16 processes x 16 threads (the fair
+                 only; cpu_baseline_sharded = the same workload sharded by trajectory over 16 processes x 4 threads (the best sharded form measured; the fair
                  "all host cores" form: the path is thousands of small ops, one process cannot use 256 threads).  Reported
                  baselines, not the target.
 """
@@ -127,9 +127,10 @@ def _cpu_shard_worker(args):
     return batch * exp['latents'].shape[1], time.perf_counter() - t0
 
 
-def cpu_baseline_sharded(procs=16, threads=16):
+def cpu_baseline_sharded(procs=16, threads=4):
     """The same full workload (B = 256, H + 1 = 16 frames + learn) sharded by dream trajectory over `procs` processes x `threads`
-    intra-op threads each (the path shards by trajectory, north_star).  Wall time = the slowest shard, model construction excluded
+    intra-op threads each (the path shards by trajectory, north_star; measured on the MI355X host, tools/cpu_shard_tune.py: 16 x 4 -> 128
+    steps/s, 32 x 4 -> 86, 32 x 8 -> 33, 16 x 16 -> 29: small per-shard matrices do not feed more threads).  Wall time = the slowest shard, model construction excluded
     (each worker times its own generate + learn).  Per-shard advantage statistics (no cross-process reduce): baseline only."""
     import multiprocessing as mp
     host = os.cpu_count() or 1
