@@ -389,6 +389,19 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
 // Two independent projections of equal K: one launch when both are few-row problems (fp32 engine), else one after the other.
 static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
     if ((!t_bf16 || t_bf16->split) && gemm_skinny_pair_applicable(a, b)) return gemm_skinny_pair(a, b, s);
+    if (!t_bf16 || t_bf16->split) {
+        // fp32 engine: one grid for both when the dispatcher's pair form applies (gemm_pair falls back to two launches itself)
+        if (d4_engine* e = t_bf16) {
+            for (GemmArgs* g : {&a, &b}) {
+                g->Wb = nullptr;
+                for (const auto& m : e->mirrors)
+                    if (g->W >= m.src && g->W < m.src + m.n) { g->Wb = m.dst + (g->W - m.src); break; }
+                g->wplane = g->Wb ? (int64_t)e->bf16_cap : 0;
+                if (!g->Wb || !gemm_x3_applicable(*g)) { g->Wb = nullptr; g->wplane = 0; }
+            }
+        }
+        return gemm_pair(a, b, s);
+    }
     int rc;
     if ((rc = engine_gemm(a, s))) return rc;
     return engine_gemm(b, s);
@@ -1332,6 +1345,13 @@ int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
             const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream) {
     d4::GemmArgs g{A, lda, W, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
     return d4::gemm(g, static_cast<hipStream_t>(stream));
+}
+
+int d4_gemm_pair(const float* A1, int lda1, const float* W1, float* C1, int ldc1, int M1, int N1, const float* A2, int lda2, const float* W2, float* C2,
+                 int ldc2, int M2, int N2, int K, int flags, float rms_eps, void* stream) {
+    d4::GemmArgs a{A1, lda1, W1, K, C1, ldc1, nullptr, nullptr, 0, M1, N1, K, flags, rms_eps};
+    d4::GemmArgs b{A2, lda2, W2, K, C2, ldc2, nullptr, nullptr, 0, M2, N2, K, flags, rms_eps};
+    return d4::gemm_pair(a, b, static_cast<hipStream_t>(stream));
 }
 
 int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,

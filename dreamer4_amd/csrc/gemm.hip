@@ -764,6 +764,39 @@ static int gemm_v3(const GemmArgs& p, hipStream_t stream) {
     return launch_v3(best, p, stream);
 }
 
+// Two independent non-transposed fp32 GEMMs (the attention pool's query and key projections): ONE grid on the LDS-DMA family when both calls
+// would have run there anyway (same family, same k order, same bits as the two separate launches), else one after the other.  The tile
+// configuration is the one chosen for the larger problem.  D4_GEMM_PAIR=0 disables the grouping.
+int gemm_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
+    std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
+    static const bool on = !(getenv("D4_GEMM_PAIR") && atoi(getenv("D4_GEMM_PAIR")) == 0);
+    GemmArgs a = a_in, b = b_in;
+    const bool fp32_rule = (!a.Wb || (a.wplane > 0 && a.N < 2048)) && (!b.Wb || (b.wplane > 0 && b.N < 2048));     // neither goes to a bf16 / split-operand kernel
+    if (on && fp32_rule && g_forced_cfg < 0 && a.M > 0 && b.M > 0 && a.K == b.K && use_v2(a) && use_v2(b) && !gemm_skinny_applicable(a) &&
+        !gemm_skinny_applicable(b) && gemm2_pair_applicable(a, b)) {
+        a.Wb = nullptr; a.wplane = 0; b.Wb = nullptr; b.wplane = 0;
+        const GemmArgs& big = (double)a.M * a.N >= (double)b.M * b.N ? a : b;
+        tune_cache_load();
+        auto it = g_tuned2.find(TuneKey{big.M, big.N, big.K, big.flags, big.batch});
+        const int c = it != g_tuned2.end() ? it->second : heuristic_v2(big);
+        if (gemm2_pair_config_ok(c) && gemm2_config_valid(c, a) && gemm2_config_valid(c, b)) {
+            const int cls = N_TILE_CFG + c;
+            const bool timed = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
+            if (!timed) return gemm2_pair_launch(c, a, b, stream);
+            ProfRec rec{};
+            rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+            rec.M = a.M + b.M; rec.N = big.N; rec.K = big.K; rec.flags = big.flags; rec.batch = 2;
+            gemm2_config_tile(c, &rec.bm, &rec.bn);
+            rec.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
+            if (int rc = gemm2_pair_launch(c, a, b, stream, rec.a, rec.b)) return rc;
+            g_prof.push_back(rec);
+            return 0;
+        }
+    }
+    if (int rc = gemm(a_in, stream)) return rc;
+    return gemm(b_in, stream);
+}
+
 // The dispatcher's process-global state (tile choices per shape, the tuning-cache file, the profiling log and its event pool, the static
 // per-instantiation attribute flags) is guarded by ONE recursive mutex taken at this entry: ctypes releases the GIL, and two engines may be
 // driven from two host threads (tools/two_stream_rollout.py).  Launches are asynchronous, so the lock is held for microseconds except

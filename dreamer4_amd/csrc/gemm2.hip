@@ -41,7 +41,7 @@ __device__ __forceinline__ int chunk_swizzle(int row) {
 }
 
 template <int WGM, int WGN, int TM, int TN, int NS, int BK, bool RMS>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm2_body(GemmArgs& p, int bid, const int bz) {
     static_assert(BK == 16 || BK == 32, "k-tile");
     constexpr int CH = BK / 4;                      // 16-byte chunks per tile row
     constexpr int RPP = 64 / CH;                    // rows per 1 KB DMA piece (8 or 16)
@@ -60,7 +60,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
     const int wm = wave / WGN, wn = wave % WGN;
 
     // XCD-aware block order (as gemm_kernel): consecutive blocks on one XCD share an A row-panel
-    int bid = blockIdx.x;
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     {
         const int nblk = nbm * nbn, nx = 8;
@@ -68,7 +67,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
     }
     const int bm0 = (bid / nbn) * BM, bn0 = (bid % nbn) * BN;
-    const int bz = blockIdx.y;
     p.A += bz * p.strideA; p.W += bz * p.strideW; p.C += bz * p.strideC;
     if (p.R) p.R += bz * p.strideC;
 
@@ -305,6 +303,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
     }
 }
 
+template <int WGM, int WGN, int TM, int TN, int NS, int BK, bool RMS>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm2_kernel(GemmArgs p) {
+    gemm2_body<WGM, WGN, TM, TN, NS, BK, RMS>(p, blockIdx.x, blockIdx.y);
+}
+
+// Two independent GEMMs in ONE grid (blocks [0, nblk_a) work on `a`, the rest on `b`): launch ramp and tail are paid once.  Used for the
+// attention pool's query and key projections (same K, same epilogue class); each problem keeps its own XCD-aware tile order and the bits of
+// every output are those of the separate launches (same body, same k order).
+template <int WGM, int WGN, int TM, int TN, int NS, int BK, bool RMS>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm2_pair_kernel(GemmArgs a, GemmArgs b, int nblk_a) {
+    const int bid = blockIdx.x;
+    if (bid < nblk_a) gemm2_body<WGM, WGN, TM, TN, NS, BK, RMS>(a, bid, 0);
+    else gemm2_body<WGM, WGN, TM, TN, NS, BK, RMS>(b, bid - nblk_a, 0);
+}
+
 // ---- configurations -------------------------------------------------------------------------------------------
 // name          waves   wave tile   block tile  BK  LDS ring     blocks (waves) / CU
 // 64x64         2 x 2     32 x 32     64 x 64   32  3 x 16 KB    3 (12)
@@ -354,6 +367,46 @@ static int launch2(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEven
     else hipLaunchKernelGGL(k, grid, block, lds, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
+}
+
+template <int WGM, int WGN, int TM, int TN, int NS, int BK>
+static int launch2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
+    const size_t lds = (size_t)(NS * (BM + BN) * BK + BM) * sizeof(float);
+    const bool rms = (a.flags & GEMM_RMS_ROWSCALE) != 0;
+    auto k = rms ? gemm2_pair_kernel<WGM, WGN, TM, TN, NS, BK, true> : gemm2_pair_kernel<WGM, WGN, TM, TN, NS, BK, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[rms]) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[rms] = true;
+    }
+    const int na = cdiv(a.M, BM) * cdiv(a.N, BN), nb = cdiv(b.M, BM) * cdiv(b.N, BN);
+    const dim3 grid(na + nb), block(WGM * WGN * 64);
+    if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, a, b, na);
+    else hipLaunchKernelGGL(k, grid, block, lds, stream, a, b, na);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+bool gemm2_pair_config_ok(int c) { return c == V2_64x64 || c == V2_128x64_8 || c == V2_128x64_k16 || c == V2_32x64 || c == V2_32x32 || c == V2_64x32; }
+
+bool gemm2_pair_applicable(const GemmArgs& a, const GemmArgs& b) {
+    const int fa = a.flags & ~GEMM_RMS_ROWSCALE, fb = b.flags & ~GEMM_RMS_ROWSCALE;
+    return gemm2_applicable(a) && gemm2_applicable(b) && a.batch <= 1 && b.batch <= 1 && ((a.flags ^ b.flags) & GEMM_RMS_ROWSCALE) == 0 &&
+           !(fa & GEMM_SWIGLU) && !(fb & GEMM_SWIGLU) && a.M > 0 && b.M > 0;
+}
+
+int gemm2_pair_launch(int c, const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    D4_REQUIRE(gemm2_pair_applicable(a, b) && gemm2_config_valid(c, a) && gemm2_config_valid(c, b), "gemm2 pair: configuration %d is not valid for these calls", c);
+    switch (c) {
+        case V2_64x64: return launch2_pair<2, 2, 2, 2, 3, 32>(a, b, stream, ea, eb);
+        case V2_128x64_8: return launch2_pair<4, 2, 2, 2, 3, 32>(a, b, stream, ea, eb);
+        case V2_128x64_k16: return launch2_pair<4, 2, 2, 2, 4, 16>(a, b, stream, ea, eb);
+        case V2_32x64: return launch2_pair<2, 2, 1, 2, 3, 32>(a, b, stream, ea, eb);
+        case V2_32x32: return launch2_pair<2, 2, 1, 1, 3, 32>(a, b, stream, ea, eb);
+        case V2_64x32: return launch2_pair<4, 1, 1, 2, 3, 32>(a, b, stream, ea, eb);
+    }
+    return 2;       // the remaining configurations are not instantiated in pair form
 }
 
 int gemm2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {

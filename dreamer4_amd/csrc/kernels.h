@@ -65,6 +65,10 @@ int gemm2_configs();
 const char* gemm2_config_name(int c);
 void gemm2_config_tile(int c, int* bm, int* bn);
 int gemm2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+bool gemm2_pair_config_ok(int c);
+bool gemm2_pair_applicable(const GemmArgs& a, const GemmArgs& b);     // two independent GEMMs in one grid (gemm2_pair_kernel)
+int gemm2_pair_launch(int c, const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+int gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream);   // gemm.hip: one launch when the pair form applies, else two
 bool gemm_skinny_applicable(const GemmArgs& p);            // M <= 16 rows: VALU kernel that streams W once (gemm_skinny.hip)
 int gemm_skinny(const GemmArgs& p, hipStream_t stream);
 bool gemm_skinny_pair_applicable(const GemmArgs& a, const GemmArgs& b);   // two few-row GEMMs of equal K in one launch

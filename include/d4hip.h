@@ -256,6 +256,11 @@ int d4_debug_buffer(d4_engine* e, const char* name, float** ptr);
 /* ---- single-kernel entry points (parity tests call the same launchers the engine uses) ---- */
 int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,
             const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
+/* Two independent Linear layers of equal in-features (the AttentionPool's query and key projections, dreamer4.py:2143-2160) in ONE
+ * launch: C1 = f(A1 W1^T), C2 = f(A2 W2^T), W row-major [N][K] (ldw = K), `flags` as d4_gemm (row scale only).  Bit-identical to two
+ * d4_gemm calls; falls back to them when the grouped form does not apply. */
+int d4_gemm_pair(const float* A1, int lda1, const float* W1, float* C1, int ldc1, int M1, int N1, const float* A2, int lda2, const float* W2, float* C2,
+                 int ldc2, int M2, int N2, int K, int flags, float rms_eps, void* stream);
 /* strided-batch form (the AttentionPool's per-head value projection, D4:2143-2177): problem b reads A + b*strideA,
  * W + b*strideW and writes C (and R) + b*strideC   (strides in elements). */
 int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,

@@ -271,6 +271,24 @@ def test_gemm_split_operands_non_finite_and_subnormal_operands(lib):
     assert o2[0, keep].abs().max().item() <= K * 1e-40 * 8.
 
 
+@pytest.mark.parametrize('M1,M2,N1,N2,flags', [(3584, 3 * 3584, 256, 256, 1), (3584, 11 * 3584, 256, 256, 1), (1000, 4097, 272, 512, 0), (40, 5000, 256, 256, 1)])
+def test_gemm_pair_is_bit_identical_to_two_launches(lib, M1, M2, N1, N2, flags):
+    """gemm2_pair_kernel (the attention pool's query + key projections in one grid): every output bit equals the separate launches'."""
+    K = 512
+    g = torch.Generator(device='cuda').manual_seed(21)
+    A1 = torch.randn(M1, K, device='cuda', generator=g); A2 = torch.randn(M2, K, device='cuda', generator=g)
+    W1 = torch.randn(N1, K, device='cuda', generator=g) / K ** 0.5; W2 = torch.randn(N2, K, device='cuda', generator=g) / K ** 0.5
+    eps = 1.1920929e-07
+    r1 = torch.full((M1, N1), float('nan'), device='cuda'); r2 = torch.full((M2, N2), float('nan'), device='cuda')
+    _lib.check(lib.d4_gemm(_lib.ptr(A1), K, _lib.ptr(W1), K, _lib.ptr(r1), N1, None, None, N1, M1, N1, K, flags, eps, stream()))
+    _lib.check(lib.d4_gemm(_lib.ptr(A2), K, _lib.ptr(W2), K, _lib.ptr(r2), N2, None, None, N2, M2, N2, K, flags, eps, stream()))
+    o1 = torch.full((M1, N1), float('nan'), device='cuda'); o2 = torch.full((M2, N2), float('nan'), device='cuda')
+    _lib.check(lib.d4_gemm_pair(_lib.ptr(A1), K, _lib.ptr(W1), _lib.ptr(o1), N1, M1, N1, _lib.ptr(A2), K, _lib.ptr(W2), _lib.ptr(o2), N2, M2, N2, K, flags, eps, stream()))
+    assert torch.equal(o1, r1) and torch.equal(o2, r2)
+    X = A2.double() * torch.rsqrt(A2.double().pow(2).mean(-1, keepdim=True) + eps) if flags & 1 else A2.double()
+    assert torch.allclose(o2.double(), X @ W2.double().t(), atol=2e-5, rtol=1e-5)
+
+
 def test_gemm_rejects_misaligned_operands(lib):
     A = torch.randn(8, 34, device='cuda')
     with pytest.raises(_lib.D4Error, match='multiples of 4'):
