@@ -93,15 +93,19 @@ SYMBOLS = {
     'd4_ff_workspace_bytes': (C.c_size_t, [_I, _I, _I]),
     'd4_ff_forward': (_I, [_P] * 6 + [_I, _I, _I, _P, _P, C.c_size_t, _P]),
     'd4_ff_backward': (_I, [_P] * 6 + [_I, _I, _I] + [_P] * 6 + [_P, C.c_size_t, _P]),
+    'd4_ff_backward_saved': (_I, [_P] * 6 + [_I, _I, _I] + [_P] * 6 + [_P, C.c_size_t, _P]),
     'd4_attn_workspace_bytes': (C.c_size_t, [_I] * 5),
     'd4_space_attn_forward': (_I, [_P] * 11 + [_I] * 5 + [_F, _I, _I, _P, _P, C.c_size_t, _P]),
     'd4_space_attn_backward': (_I, [_P] * 12 + [_I] * 5 + [_F, _I, _I] + [_P] * 11 + [_P, C.c_size_t, _P]),
+    'd4_space_attn_backward_saved': (_I, [_P] * 12 + [_I] * 5 + [_F, _I, _I] + [_P] * 11 + [_P, C.c_size_t, _P]),
     'd4_time_attn_workspace_bytes': (C.c_size_t, [_I] * 6),
     'd4_time_attn_forward': (_I, [_P] * 12 + [_I] * 6 + [_F, _I, _P, _P, C.c_size_t, _P]),
     'd4_time_attn_backward': (_I, [_P] * 13 + [_I] * 6 + [_F, _I] + [_P] * 11 + [_P, C.c_size_t, _P]),
+    'd4_time_attn_backward_saved': (_I, [_P] * 13 + [_I] * 6 + [_F, _I] + [_P] * 11 + [_P, C.c_size_t, _P]),
     'd4_cross_attn_workspace_bytes': (C.c_size_t, [_I] * 7),
     'd4_cross_attn_forward': (_I, [_P] * 10 + [_I] * 8 + [_F, _P, _P, C.c_size_t, _P]),
     'd4_cross_attn_backward': (_I, [_P] * 11 + [_I] * 8 + [_F] + [_P] * 10 + [_P, C.c_size_t, _P]),
+    'd4_cross_attn_backward_saved': (_I, [_P] * 11 + [_I] * 8 + [_F] + [_P] * 10 + [_P, C.c_size_t, _P]),
     'd4_encoder_forward': (_I, [_P, _P, _I, _I, _P, _P]),
     'd4_euler_step': (_I, [_P, _P, _L, _F, _F, _P]),
     'd4_rollout': (_I, [_P, C.POINTER(RolloutIO), _P]),

@@ -489,9 +489,11 @@ int d4_ff_forward(const float* x, const float* norm_w, const float* w_in, const 
     return gemm_b(w.u, Ip, w.w2p, Ip, y, dim, b_out, rows, dim, Ip, 0, s);
 }
 
-int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+// `reuse`: the workspace is the one the matching forward call ran in and still holds its intermediates (normalised input, padded weight
+// images, pre-activation h, hidden u): nothing is recomputed.  Otherwise the forward up to u is recomputed from x first.
+static int ff_backward_impl(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
                    int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
-                   float* workspace, size_t workspace_bytes, void* stream) {
+                   float* workspace, size_t workspace_bytes, void* stream, bool reuse) {
     D4_REQUIRE(x && dy && norm_w && w_in && b_in && w_out && dx && d_norm_w && d_w_in && d_b_in && d_w_out && d_b_out && workspace, "d4_ff_backward: null argument");
     D4_REQUIRE(dim % 4 == 0 && ((uintptr_t)workspace % 256) == 0, "d4_ff_backward: dim must be a multiple of 4 and the workspace 256-byte aligned");
     D4_REQUIRE(workspace_bytes >= d4_ff_workspace_bytes(rows, dim, inner), "d4_ff_backward: workspace too small");
@@ -500,7 +502,7 @@ int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const f
     const int R = rows, D = dim, I = inner, Ip = (inner + 3) / 4 * 4;
     const FfWs w = ff_ws(workspace, R, D, I);
     int rc;
-    if ((rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, R, D, I, s))) return rc;
+    if (!reuse && (rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, R, D, I, s))) return rc;
     // y = u W2^T + b2
     if ((rc = colsum(dy, D, R, D, d_b_out, s))) return rc;
     if ((rc = gemm_dw(dy, D, w.u, Ip, w.dw2p, Ip, D, Ip, R, w.part, s))) return rc;                                    // dW2 = dy^T u
@@ -518,6 +520,17 @@ int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const f
     // xn = rmsnorm(x) * gamma
     if ((rc = rmsnorm_bwd(x, w.dxn, norm_w, w.tg, dx, R, D, RMS_EPS, s))) return rc;
     return colsum(w.tg, D, R, D, d_norm_w, s);
+}
+
+int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+                   int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
+                   float* workspace, size_t workspace_bytes, void* stream) {
+    return ff_backward_impl(x, dy, norm_w, w_in, b_in, w_out, rows, dim, inner, dx, d_norm_w, d_w_in, d_b_in, d_w_out, d_b_out, workspace, workspace_bytes, stream, false);
+}
+int d4_ff_backward_saved(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+                         int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
+                         float* workspace, size_t workspace_bytes, void* stream) {
+    return ff_backward_impl(x, dy, norm_w, w_in, b_in, w_out, rows, dim, inner, dx, d_norm_w, d_w_in, d_b_in, d_w_out, d_b_out, workspace, workspace_bytes, stream, true);
 }
 
 size_t d4_attn_workspace_bytes(int frames, int tokens, int dim, int heads, int dim_head) {
@@ -564,7 +577,8 @@ int attn_block_forward(const float* x, const float* residual_values, const AttnP
 struct AttnGrads { float *dx, *d_rv, *d_norm_w, *d_wq, *d_wk, *d_wv, *d_wo, *d_wg, *d_wm, *d_bm, *d_gamma; };
 
 int attn_block_backward(const float* x, const float* residual_values, const float* dy, const AttnParams& prm, int rows, const AttnGeom& g, int dim,
-                        int heads, int dim_head, float softclamp, int belief, const AttnGrads& o, float* workspace, size_t workspace_bytes, hipStream_t s) {
+                        int heads, int dim_head, float softclamp, int belief, const AttnGrads& o, float* workspace, size_t workspace_bytes, hipStream_t s,
+                        bool reuse = false) {
     D4_REQUIRE(x && dy && prm.norm_w && prm.wq && prm.wk && prm.wv && prm.wo && prm.wg && prm.gamma && workspace, "attention backward: null argument");
     D4_REQUIRE(o.dx && o.d_norm_w && o.d_wq && o.d_wk && o.d_wv && o.d_wo && o.d_wg && o.d_gamma, "attention backward: null gradient output");
     D4_REQUIRE(!residual_values || (prm.wm && prm.bm && o.d_rv && o.d_wm && o.d_bm), "attention backward: residual values need the mix projection and its gradients");
@@ -574,7 +588,7 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
     const int R = rows, D = dim, hd = heads * dim_head;
     const bool has_rv = residual_values != nullptr;
     const AttnWs w = attn_ws(workspace, R, g.groups, D, heads, dim_head);
-    if ((rc = attn_project(w, x, prm, R, D, heads, dim_head, has_rv, s))) return rc;
+    if (!reuse && (rc = attn_project(w, x, prm, R, D, heads, dim_head, has_rv, s))) return rc;     // reuse: the forward's xn / wcat / proj are still there
     // out = o3 Wo^T
     if ((rc = gemm_b(dy, D, prm.wo, hd, w.d_o3, hd, nullptr, R, hd, D, GEMM_TRANS_B, s))) return rc;                    // d_o3 = dy Wo
     AttnBwdArgs a{w.proj, w.P, residual_values, prm.gamma, w.d_o3, w.o3, w.dproj, o.d_rv, w.gpart, g.groups, g.items, heads, w.hp4, softclamp, g.num_special, belief};
@@ -672,11 +686,11 @@ int d4_cross_attn_forward(const float* q_tokens, const float* ctx, const float* 
     return gemm_b(w.o3, hd, wo, hd, y, dim, nullptr, Rq, dim, hd, 0, s);
 }
 
-int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,
+static int cross_attn_backward_impl(const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,
                            const float* wk, const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk,
                            int ctx_item_major, int dim, int dim_ctx, int heads, int dim_head, float softclamp,
                            float* d_q_tokens, float* d_ctx, float* d_norm_w, float* d_norm_ctx_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
-                           float* d_w_gates, float* d_k_gamma, float* workspace, size_t workspace_bytes, void* stream) {
+                           float* d_w_gates, float* d_k_gamma, float* workspace, size_t workspace_bytes, void* stream, bool reuse) {
     D4_REQUIRE(q_tokens && ctx && dy && norm_w && wq && wk && wv && wo && w_gates && k_gamma && workspace, "d4_cross_attn_backward: null argument");
     D4_REQUIRE(d_q_tokens && d_ctx && d_norm_w && d_wq && d_wk && d_wv && d_wo && d_w_gates && d_k_gamma && (!norm_ctx_w || d_norm_ctx_w),
                "d4_cross_attn_backward: null gradient output");
@@ -687,7 +701,7 @@ int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float*
     const int Rq = groups * nq, Rk = groups * nk, D = dim, Dc = dim_ctx, hd = heads * dim_head;
     const XWs w = x_ws(workspace, Rq, Rk, groups, D, Dc, heads, dim_head);
     const XParams prm{norm_w, norm_ctx_w, wq, wk, wv, wo, w_gates, k_gamma};
-    if ((rc = x_project(w, q_tokens, ctx, prm, Rq, Rk, D, Dc, heads, dim_head, s))) return rc;
+    if (!reuse && (rc = x_project(w, q_tokens, ctx, prm, Rq, Rk, D, Dc, heads, dim_head, s))) return rc;
     if ((rc = gemm_b(dy, D, wo, hd, w.d_o3, hd, nullptr, Rq, hd, D, GEMM_TRANS_B, s))) return rc;
     XAttnArgs a{w.projq, w.Pq, w.projk, w.Pk, k_gamma, w.d_o3, w.o3, w.dprojq, w.dprojk, w.gpart, groups, nq, nk, heads, ctx_item_major, softclamp};
     if ((rc = xattn_core(a, dim_head, s))) return rc;
@@ -716,6 +730,16 @@ int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float*
     return gemm_b(w.dprojk, w.Pk, w.wkv, Dc, d_ctx, Dc, nullptr, Rk, Dc, w.Pk, GEMM_TRANS_B, s);
 }
 
+#define D4_XBWD_PARAMS const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,          \
+                       const float* wk, const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk,        \
+                       int ctx_item_major, int dim, int dim_ctx, int heads, int dim_head, float softclamp, float* d_q_tokens, float* d_ctx,             \
+                       float* d_norm_w, float* d_norm_ctx_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo, float* d_w_gates, float* d_k_gamma,    \
+                       float* workspace, size_t workspace_bytes, void* stream
+#define D4_XBWD_ARGS q_tokens, ctx, dy, norm_w, norm_ctx_w, wq, wk, wv, wo, w_gates, k_gamma, groups, nq, nk, ctx_item_major, dim, dim_ctx, heads, dim_head, \
+                     softclamp, d_q_tokens, d_ctx, d_norm_w, d_norm_ctx_w, d_wq, d_wk, d_wv, d_wo, d_w_gates, d_k_gamma, workspace, workspace_bytes, stream
+int d4_cross_attn_backward(D4_XBWD_PARAMS) { return cross_attn_backward_impl(D4_XBWD_ARGS, false); }
+int d4_cross_attn_backward_saved(D4_XBWD_PARAMS) { return cross_attn_backward_impl(D4_XBWD_ARGS, true); }
+
 size_t d4_time_attn_workspace_bytes(int batch, int frames, int tokens, int dim, int heads, int dim_head) {
     return attn_ws(nullptr, batch * frames * tokens, batch * tokens, dim, heads, dim_head).total * sizeof(float);
 }
@@ -743,6 +767,19 @@ int d4_space_attn_backward(const float* x, const float* residual_values, const f
                                static_cast<hipStream_t>(stream));
 }
 
+int d4_space_attn_backward_saved(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                           const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                           int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
+                           float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                           float* workspace, size_t workspace_bytes, void* stream) {
+    const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
+    const AttnGeom g{frames, tokens, 1, tokens, 1, 0, num_special, nullptr};
+    const AttnGrads o{dx, d_residual_values, d_norm_w, d_wq, d_wk, d_wv, d_wo, d_w_gates, d_w_mix, d_b_mix, d_k_gamma};
+    return attn_block_backward(x, residual_values, dy, prm, frames * tokens, g, dim, heads, dim_head, softclamp, belief, o, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream), true);
+}
+
 int d4_time_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
                          const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma, const float* inv_freq,
                          int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
@@ -766,6 +803,20 @@ int d4_time_attn_backward(const float* x, const float* residual_values, const fl
     const AttnGrads o{dx, d_residual_values, d_norm_w, d_wq, d_wk, d_wv, d_wo, d_w_gates, d_w_mix, d_b_mix, d_k_gamma};
     return attn_block_backward(x, residual_values, dy, prm, batch * frames * tokens, g, dim, heads, dim_head, softclamp, belief, o, workspace,
                                workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int d4_time_attn_backward_saved(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                          const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                          const float* inv_freq, int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
+                          float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                          float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                          float* workspace, size_t workspace_bytes, void* stream) {
+    D4_REQUIRE(inv_freq, "d4_time_attn_backward: null rotary frequencies");
+    const AttnParams prm{norm_w, wq, wk, wv, wo, w_gates, w_mix, b_mix, k_gamma};
+    const AttnGeom g{batch * tokens, frames, tokens, (int64_t)frames * tokens, tokens, 1, 0, inv_freq};
+    const AttnGrads o{dx, d_residual_values, d_norm_w, d_wq, d_wk, d_wv, d_wo, d_w_gates, d_w_mix, d_b_mix, d_k_gamma};
+    return attn_block_backward(x, residual_values, dy, prm, batch * frames * tokens, g, dim, heads, dim_head, softclamp, belief, o, workspace,
+                               workspace_bytes, static_cast<hipStream_t>(stream), true);
 }
 
 }  // extern "C"

@@ -207,8 +207,8 @@ def learn(model, experience, policy_optim, value_optim, only_learn_policy_value_
           use_delight_gating, delight_temperature, normalize_advantages, eps, process_group, stats):
     if not only_learn_policy_value_heads:
         # fine-tuning the whole world model (dreamer4.py:6045-6075): agent embeddings from a forward WITH gradient through the HIP trunk
-        # blocks; the learner also returns d loss / d agent_embed, which autograd carries on into the trunk.  (Data parallel: only the head
-        # buckets are all-reduced by DreamTrainer — wrap the model / reduce the trunk gradients yourself for this mode.)
+        # blocks; the learner also returns d loss / d agent_embed, which autograd carries on into the trunk.  Data parallel: the gradients of
+        # EVERY parameter (trunk and heads) are summed over the ranks in one flat bucket per loss before the optimiser steps.
         agent = agent_embed_with_grad(model, experience.to(model.device))
         losses, _, (d_pol, d_val) = run_learner(model, experience, objective, use_delight_gating, delight_temperature, normalize_advantages,
                                                 eps, process_group, stats, agent_embed=agent.detach(), want_embed_grads=True)
@@ -226,6 +226,7 @@ def learn(model, experience, policy_optim, value_optim, only_learn_policy_value_
             out = [p.grad for p in params]
             for p in params:
                 p.grad = None
+            parallel.all_reduce_grads_(out, process_group, average=stats != 'global')
             return out
 
         gpol = grads_of(policy_loss, value_optim is not None) if policy_optim is not None else None

@@ -96,18 +96,8 @@ class DreamTrainer:
         for loss, params, optim in ((pl, m.policy_head_parameters(), self.torch_optims[0]),
                                     (vl, m.value_head_parameters(), self.torch_optims[1])):
             loss.backward()
-            if parallel.collective_active(self.process_group):
-                # ONE sum all-reduce per head over a flat bucket of its gradients (as the native optimiser path: one large collective per
-                # head keeps each xGMI link busy once), also issued in a one-rank world under D4_FORCE_PG=1
-                grads = [p.grad for p in params if p.grad is not None]
-                if grads:
-                    flat = torch.cat([g.reshape(-1) for g in grads])
-                    parallel.all_reduce_sum_(flat, self.process_group)
-                    if self.stats != 'global':
-                        flat.div_(parallel.world_size(self.process_group))
-                    off = 0
-                    for g in grads:
-                        g.copy_(flat[off:off + g.numel()].view_as(g)); off += g.numel()
+            # ONE sum all-reduce per head over a flat bucket of its gradients (as the native optimiser path), also in a one-rank world under D4_FORCE_PG=1
+            parallel.all_reduce_grads_([p.grad for p in params], self.process_group, average=self.stats != 'global')
             if self.max_grad_norm is not None:
                 torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
             optim.step()

@@ -3,8 +3,9 @@
 `feedforward`, `space_attention`, `time_attention` and `cross_attention` are the reference FeedForward (dreamer4/dreamer4.py:2079-2116)
 and Attention (dreamer4.py:1968-2075: within a frame, along time with rotary + causal mask, over a context) as
 `torch.autograd.Function`s over the C-ABI operators `d4_ff_* / d4_space_attn_* / d4_time_attn_* / d4_cross_attn_*` (include/d4hip.h).
-Parameters are passed in the reference's own layout (the tensors of its state_dict), gradients come back in the same layout, and the
-backward recomputes the forward intermediates, so nothing but the inputs is kept alive between the two passes.  `transformer` composes
+Parameters are passed in the reference's own layout (the tensors of its state_dict), gradients come back in the same layout.  By default a
+block keeps the workspace its forward ran in and the backward (`*_backward_saved`) recomputes nothing; with D4_TRUNK_SAVE_FORWARD=0 the
+backward recomputes the forward intermediates and nothing but the inputs is kept alive between the two passes.  `transformer` composes
 the AxialSpaceTimeTransformer (dreamer4.py:2927-3267), `world_model_prediction` the dynamics model's `get_prediction`
 (dreamer4.py:7156-7287), `dynamics_flow_losses` / `dynamics_agent_losses` the losses of the training forward (dreamer4.py:7335-7598).
 fp32, HIP device only — there is no CPU fallback.  Not used by the imagination path."""
@@ -34,6 +35,14 @@ def _prep(*ts):
     return out
 
 
+def save_forward_workspace():
+    """D4_TRUNK_SAVE_FORWARD=0: the backward of every block recomputes its forward (nothing but the inputs is kept between the passes);
+    default: each block keeps the workspace its forward ran in (normalised input, concatenated weight images, projections: 0.1-0.2 GB per
+    block at 3840 token rows — 288 GB of HBM is what makes that the default) and the backward runs on it without recomputing anything."""
+    import os
+    return os.environ.get('D4_TRUNK_SAVE_FORWARD', '1') != '0'
+
+
 def _workspace(nbytes, device):
     ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
     base = ws.data_ptr()
@@ -54,6 +63,7 @@ class _FeedForward(torch.autograd.Function):
         _lib.check(lib.d4_ff_forward(_lib.ptr(x), _lib.ptr(norm_w), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(w_out), _lib.ptr(b_out),
                                      rows, D, inner, _lib.ptr(y), wp, nbytes, _stream(x)))
         ctx.save_for_backward(x, norm_w, w_in, b_in, w_out)
+        ctx.fwd_ws = (ws, wp, nbytes) if save_forward_workspace() and any(ctx.needs_input_grad) else None
         return y
 
     @staticmethod
@@ -63,11 +73,14 @@ class _FeedForward(torch.autograd.Function):
         D, inner = x.shape[-1], w_out.shape[1]
         rows = x.numel() // D
         lib = _lib.load()
-        nbytes = lib.d4_ff_workspace_bytes(rows, D, inner)
-        ws, wp = _workspace(nbytes, x.device)
+        if ctx.fwd_ws is not None:
+            (ws, wp, nbytes), fn = ctx.fwd_ws, lib.d4_ff_backward_saved
+        else:
+            nbytes = lib.d4_ff_workspace_bytes(rows, D, inner)
+            (ws, wp), fn = _workspace(nbytes, x.device), lib.d4_ff_backward
         dx, dn, dwi, dbi, dwo = torch.empty_like(x), torch.empty_like(norm_w), torch.empty_like(w_in), torch.empty_like(b_in), torch.empty_like(w_out)
         dbo = torch.empty(D, device=x.device)
-        _lib.check(lib.d4_ff_backward(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(w_out), rows, D, inner,
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(w_out), rows, D, inner,
                                       _lib.ptr(dx), _lib.ptr(dn), _lib.ptr(dwi), _lib.ptr(dbi), _lib.ptr(dwo), _lib.ptr(dbo), wp, nbytes, _stream(x)))
         return dx, dn, dwi, dbi, dwo, dbo
 
@@ -95,6 +108,7 @@ class _SpaceAttention(torch.autograd.Function):
                                              float(softclamp or 0.), int(num_special), int(bool(belief)), _lib.ptr(y), wp, nbytes, _stream(x)))
         ctx.save_for_backward(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma)
         ctx.cfg = (float(softclamp or 0.), int(num_special), int(bool(belief)))
+        ctx.fwd_ws = (ws, wp, nbytes) if save_forward_workspace() and any(ctx.needs_input_grad) else None
         return y
 
     @staticmethod
@@ -104,12 +118,15 @@ class _SpaceAttention(torch.autograd.Function):
         F_, S, D = x.shape
         heads, dh = gamma.shape
         lib = _lib.load()
-        nbytes = lib.d4_attn_workspace_bytes(F_, S, D, heads, dh)
-        ws, wp = _workspace(nbytes, x.device)
+        if ctx.fwd_ws is not None:
+            (ws, wp, nbytes), fn = ctx.fwd_ws, lib.d4_space_attn_backward_saved
+        else:
+            nbytes = lib.d4_attn_workspace_bytes(F_, S, D, heads, dh)
+            (ws, wp), fn = _workspace(nbytes, x.device), lib.d4_space_attn_backward
         e = torch.empty_like
         dx, dn, dq, dk, dv, do, dg, dgam = e(x), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
         drv, dwm, dbm = (e(rv), e(wm), e(bm)) if rv is not None else (None, None, None)
-        _lib.check(lib.d4_space_attn_backward(
+        _lib.check(fn(
             _lib.ptr(x), _lib.ptr(rv), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(wo), _lib.ptr(wg),
             _lib.ptr(wm), _lib.ptr(bm), _lib.ptr(gamma), F_, S, D, heads, dh, *ctx.cfg,
             _lib.ptr(dx), _lib.ptr(drv), _lib.ptr(dn), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(do), _lib.ptr(dg), _lib.ptr(dwm), _lib.ptr(dbm),
@@ -144,6 +161,7 @@ class _TimeAttention(torch.autograd.Function):
                                             float(softclamp or 0.), int(bool(belief)), _lib.ptr(y), wp, nbytes, _stream(x)))
         ctx.save_for_backward(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq)
         ctx.cfg = (float(softclamp or 0.), int(bool(belief)))
+        ctx.fwd_ws = (ws, wp, nbytes) if save_forward_workspace() and any(ctx.needs_input_grad) else None
         return y
 
     @staticmethod
@@ -153,12 +171,15 @@ class _TimeAttention(torch.autograd.Function):
         B, T, S, D = x.shape
         heads, dh = gamma.shape
         lib = _lib.load()
-        nbytes = lib.d4_time_attn_workspace_bytes(B, T, S, D, heads, dh)
-        ws, wp = _workspace(nbytes, x.device)
+        if ctx.fwd_ws is not None:
+            (ws, wp, nbytes), fn = ctx.fwd_ws, lib.d4_time_attn_backward_saved
+        else:
+            nbytes = lib.d4_time_attn_workspace_bytes(B, T, S, D, heads, dh)
+            (ws, wp), fn = _workspace(nbytes, x.device), lib.d4_time_attn_backward
         e = torch.empty_like
         dx, dn, dq, dk, dv, do, dg, dgam = e(x), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
         drv, dwm, dbm = (e(rv), e(wm), e(bm)) if rv is not None else (None, None, None)
-        _lib.check(lib.d4_time_attn_backward(
+        _lib.check(fn(
             _lib.ptr(x), _lib.ptr(rv), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv), _lib.ptr(wo), _lib.ptr(wg),
             _lib.ptr(wm), _lib.ptr(bm), _lib.ptr(gamma), _lib.ptr(inv_freq), B, T, S, D, heads, dh, *ctx.cfg,
             _lib.ptr(dx), _lib.ptr(drv), _lib.ptr(dn), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(do), _lib.ptr(dg), _lib.ptr(dwm), _lib.ptr(dbm),
@@ -194,6 +215,7 @@ class _CrossAttention(torch.autograd.Function):
                                              float(softclamp or 0.), _lib.ptr(y), wp, nbytes, _stream(q_tokens)))
         ctx_.save_for_backward(q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma)
         ctx_.cfg = (G, nq, nk, int(bool(item_major)), D, Dc, heads, dh, float(softclamp or 0.))
+        ctx_.fwd_ws = (ws, wp, nbytes) if save_forward_workspace() and any(ctx_.needs_input_grad) else None
         return y
 
     @staticmethod
@@ -202,12 +224,15 @@ class _CrossAttention(torch.autograd.Function):
         (dy,) = _prep(dy)
         G, nq, nk, item_major, D, Dc, heads, dh, softclamp = ctx_.cfg
         lib = _lib.load()
-        nbytes = lib.d4_cross_attn_workspace_bytes(G, nq, nk, D, Dc, heads, dh)
-        ws, wp = _workspace(nbytes, q_tokens.device)
+        if ctx_.fwd_ws is not None:
+            (ws, wp, nbytes), fn = ctx_.fwd_ws, lib.d4_cross_attn_backward_saved
+        else:
+            nbytes = lib.d4_cross_attn_workspace_bytes(G, nq, nk, D, Dc, heads, dh)
+            (ws, wp), fn = _workspace(nbytes, q_tokens.device), lib.d4_cross_attn_backward
         e = torch.empty_like
         dq_t, dc, dn, dq, dk, dv, do, dg, dgam = e(q_tokens), e(context), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
         dnc = e(norm_ctx_w) if norm_ctx_w is not None else None
-        _lib.check(lib.d4_cross_attn_backward(
+        _lib.check(fn(
             _lib.ptr(q_tokens), _lib.ptr(context), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(norm_ctx_w), _lib.ptr(wq), _lib.ptr(wk), _lib.ptr(wv),
             _lib.ptr(wo), _lib.ptr(wg), _lib.ptr(gamma), G, nq, nk, item_major, D, Dc, heads, dh, softclamp,
             _lib.ptr(dq_t), _lib.ptr(dc), _lib.ptr(dn), _lib.ptr(dnc), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(do), _lib.ptr(dg), _lib.ptr(dgam),

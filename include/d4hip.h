@@ -280,11 +280,17 @@ int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_str
 /* ---- trunk backward, first slice (SURVEY.md 8f-3 groundwork; not on the imagination path) ----
  * FeedForward block (dreamer4.py:2079-2116) on the reference parameter layout: y = proj_out(a * silu(g)) with [a | g] = proj_in(RMSNorm(x));
  * x / y / dy / dx [rows][dim], norm_w [dim], w_in [2*inner][dim], b_in [2*inner], w_out [dim][inner], b_out [dim].  The backward
- * recomputes the forward intermediates (nothing is saved between the two calls).  workspace: 256-byte aligned device memory. */
+ * recomputes the forward intermediates (nothing is saved between the two calls).  workspace: 256-byte aligned device memory.
+ * Every `*_backward_saved` entry (FeedForward and the three attention blocks below) takes the SAME arguments as its `*_backward` but requires
+ * `workspace` to be the very buffer the matching `*_forward` call ran in, untouched since: the forward intermediates it holds (normalised input,
+ * concatenated weight images, projections) are used as they are and nothing is recomputed (one GEMM in four of a block's backward). */
 size_t d4_ff_workspace_bytes(int rows, int dim, int inner);
 int d4_ff_forward(const float* x, const float* norm_w, const float* w_in, const float* b_in, const float* w_out, const float* b_out,
                   int rows, int dim, int inner, float* y, float* workspace, size_t workspace_bytes, void* stream);
 int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
+                   int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
+                   float* workspace, size_t workspace_bytes, void* stream);
+int d4_ff_backward_saved(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
                    int rows, int dim, int inner, float* dx, float* d_norm_w, float* d_w_in, float* d_b_in, float* d_w_out, float* d_b_out,
                    float* workspace, size_t workspace_bytes, void* stream);
 /* Space attention block (Attention.forward, dreamer4.py:1968-2075, self attention within a frame): x / y [frames*tokens][dim],
@@ -297,6 +303,12 @@ int d4_space_attn_forward(const float* x, const float* residual_values, const fl
                           int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
                           float* y, float* workspace, size_t workspace_bytes, void* stream);
 int d4_space_attn_backward(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                           const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                           int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
+                           float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                           float* workspace, size_t workspace_bytes, void* stream);
+int d4_space_attn_backward_saved(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
                            const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
                            int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int num_special, int belief,
                            float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
@@ -316,6 +328,12 @@ int d4_time_attn_backward(const float* x, const float* residual_values, const fl
                           float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
                           float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
                           float* workspace, size_t workspace_bytes, void* stream);
+int d4_time_attn_backward_saved(const float* x, const float* residual_values, const float* dy, const float* norm_w, const float* wq, const float* wk,
+                          const float* wv, const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
+                          const float* inv_freq, int batch, int frames, int tokens, int dim, int heads, int dim_head, float softclamp, int belief,
+                          float* dx, float* d_residual_values, float* d_norm_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                          float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
+                          float* workspace, size_t workspace_bytes, void* stream);
 /* Cross-attention block (Attention.forward with a context: the AttentionPool over the layer hiddens dreamer4.py:2143-2177, the final
  * special-token cross attention :3227-3234, the learned-query pools :2179-2210): q_tokens [groups*nq][dim], ctx [groups*nk][dim_ctx] with key
  * j of group g at row g*nk + j, or at row j*groups + g when ctx_item_major (the stack of hiddens); norm_ctx_w may be null (context not
@@ -325,6 +343,11 @@ int d4_cross_attn_forward(const float* q_tokens, const float* ctx, const float* 
                           const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk, int ctx_item_major,
                           int dim, int dim_ctx, int heads, int dim_head, float softclamp, float* y, float* workspace, size_t workspace_bytes, void* stream);
 int d4_cross_attn_backward(const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,
+                           const float* wk, const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk,
+                           int ctx_item_major, int dim, int dim_ctx, int heads, int dim_head, float softclamp,
+                           float* d_q_tokens, float* d_ctx, float* d_norm_w, float* d_norm_ctx_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,
+                           float* d_w_gates, float* d_k_gamma, float* workspace, size_t workspace_bytes, void* stream);
+int d4_cross_attn_backward_saved(const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,
                            const float* wk, const float* wv, const float* wo, const float* w_gates, const float* k_gamma, int groups, int nq, int nk,
                            int ctx_item_major, int dim, int dim_ctx, int heads, int dim_head, float softclamp,
                            float* d_q_tokens, float* d_ctx, float* d_norm_w, float* d_norm_ctx_w, float* d_wq, float* d_wk, float* d_wv, float* d_wo,

@@ -164,10 +164,18 @@ def test_cross_attention_forward_and_backward_vs_oracle_autograd(G, nq, nk, D, D
 
 @pytest.mark.parametrize('kw,b,t', [(dict(dim=64, dim_latent=8, num_latent_tokens=4, depth=4, time_block_every=2, attn_heads=2, attn_dim_head=32, num_discrete_actions=4), 2, 5),
                                     (dict(dim=128, dim_latent=16, num_latent_tokens=8, num_spatial_tokens=4, depth=5, time_block_every=4, attn_heads=2, attn_dim_head=64,
-                                          num_discrete_actions=4), 3, 4)])
-def test_trunk_forward_and_backward_vs_oracle_autograd(kw, b, t):
+                                          num_discrete_actions=4), 3, 4),
+                                    # BASELINE config 2's architecture at the shape bench.py's train_flow_step times (15 tokens per frame, 16 frames)
+                                    (dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8, attn_dim_head=64, num_spatial_tokens=4,
+                                          num_register_tokens=8, num_discrete_actions=4), 2, 16)])
+@pytest.mark.parametrize('save_forward', ['1', '0'])
+def test_trunk_forward_and_backward_vs_oracle_autograd(kw, b, t, save_forward, monkeypatch):
     """The whole AxialSpaceTimeTransformer (dreamer4.py:2927-3267) as a composition of the HIP forward + backward blocks, against float64
-    autograd of the oracle's `transformer`: output, d tokens and the gradient of every trunk parameter."""
+    autograd of the oracle's `transformer`: output, d tokens and the gradient of every trunk parameter — with the blocks keeping their
+    forward workspace (`*_backward_saved`, the default) and with the backward recomputing the forward (D4_TRUNK_SAVE_FORWARD=0)."""
+    monkeypatch.setenv('D4_TRUNK_SAVE_FORWARD', save_forward)
+    if kw['dim'] == 512 and save_forward == '0':
+        pytest.skip('the recompute form is covered at the small shapes')
     from dreamer4_amd import DynamicsWorldModel
     from util import oracle_config, randomize_weights
     torch.manual_seed(1)

@@ -98,6 +98,12 @@ DP_SCRIPT = textwrap.dedent('''
     # one flat bucket per head: sum all-reduce of per-rank gradients scaled by the GLOBAL count == full-batch gradient
     g = torch.full((7,), float(r + 1)); parallel.all_reduce_sum_(g); assert g.tolist() == [3.0] * 7
     m = torch.tensor([float(r)]); parallel.all_reduce_max_(m); assert m.item() == 1.0
+    # the whole-model form (learn_from_experience(only_learn_policy_value_heads=False) / torch optimisers): every parameter gradient,
+    # trunk included, through ONE flat bucket; None gradients are skipped, shapes survive, `average` divides by the world size
+    grads = [torch.full((2, 3), float(r + 1)), None, torch.arange(4.) * (r + 1)]
+    parallel.all_reduce_grads_(grads); assert grads[0].tolist() == [[3.0] * 3] * 2 and grads[1] is None and grads[2].tolist() == [0., 3., 6., 9.]
+    grads = [torch.full((5,), float(r + 1))]; parallel.all_reduce_grads_(grads, average=True); assert grads[0].tolist() == [1.5] * 5
+    assert parallel.collective_active()
     parallel.barrier()
     os.write(1, ('DP_OK_' + str(r) + '|').encode())
 ''')
