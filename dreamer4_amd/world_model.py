@@ -945,9 +945,11 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
 
         # ---- early exit once every trajectory has terminated (dreamer4.py:6681): the engine always runs all
         # frames (no host sync inside the rollout); frames past the reference's break are dropped here, also from the cache.
+        # A call that generates ONE frame (the env-wrapper pattern, dreamer4/env.py:445-483) cannot be shortened — a terminal sampled at the
+        # only new frame gives lens = T — so it never waits for the device here: the host goes on preparing the next call while this one runs.
         Tp = T
         terminals_b = terminals.bool()
-        if sample_terminals and bool(terminals_b.all()):
+        if sample_terminals and F_ > 1 and bool(terminals_b.all()):
             Tp = int(lens.max().item())
         Fp = Tp - P
         new_cache = None
