@@ -182,7 +182,7 @@ def cfg4_env_latency(device, horizon=50):
 def train_flow_step(device, B=16, T=16, reps=4):
     """SURVEY.md 8(f-3), secondary numbers: one dynamics TRAINING step at config 2's architecture — DynamicsWorldModel.forward without
     signal levels (flow + shortcut losses, D4:6956-7003, 7335-7431) + backward through the HIP trunk blocks (dreamer4_amd/trunk_ops.py),
-    B x T frames of 15 tokens.  A first measured version (the blocks recompute their forward in the backward): no roofline is claimed."""
+    B x T frames of 15 tokens.  The blocks keep their forward workspace (nothing is recomputed in the backward)."""
     from dreamer4_amd import DynamicsWorldModel
     from dreamer4_amd.synthetic import randomize_weights
     torch.manual_seed(0)
@@ -201,10 +201,11 @@ def train_flow_step(device, B=16, T=16, reps=4):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
         out[f'{name}_ms_per_step'] = round(1e3 * dt, 2)
         out[f'{name}_frames_per_sec'] = round(B * T / dt, 1)
-    # GEMM work of one flow-only step: forward + its recomputation inside the backward operators + dX + dW = 4 x the forward's 2MNK
-    # (66.5 MFLOP per token, SURVEY.md 8d, + the learned-query pools) -> a lower bound on the executed flops, against the fp32 matrix peak
+    # GEMM work of one flow-only step: forward + dX + dW = 3 x the forward's 2MNK (66.5 MFLOP per token, SURVEY.md 8d, + the learned-query
+    # pools; the blocks keep their forward workspace, so nothing is recomputed: round 2 executed 4 x) -> a lower bound on the executed flops,
+    # against the fp32 matrix peak
     fwd_flop = 66.5e6 * B * T * 15 + 11.5e9 * (B * T) / 256.
-    out['flow_only_gemm_tflops'] = round(4. * fwd_flop / (out['flow_only_ms_per_step'] * 1e-3) / 1e12, 1)
+    out['flow_only_gemm_tflops'] = round(3. * fwd_flop / (out['flow_only_ms_per_step'] * 1e-3) / 1e12, 1)
     out['flow_only_frac_of_fp32_matrix_peak'] = round(out['flow_only_gemm_tflops'] / PEAK_FP32_MFMA_TFLOPS, 3)
     out['workload'] = f'cfg2 architecture, training forward + backward, B={B} x T={T} frames x 15 tokens = {B * T * 15} token rows, fp32'
 

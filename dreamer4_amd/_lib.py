@@ -130,6 +130,7 @@ SYMBOLS = {
     'd4_split_bf16x3': (_I, [_P, _P, _L, _L, _P]),
     'd4_gemm_split': (_I, [_P, _I, _P, _L, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     'd4_rmsnorm': (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
+    'd4_rmsnorm_backward': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     'd4_hl_gauss_scalar': (_I, [_P, _I, _P, _P, _I, _I, _P]),
     'd4_gae': (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
 }

@@ -1386,6 +1386,14 @@ int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, i
     return d4::rmsnorm_rows(x, ldx, gamma, y, ldy, rows, dim, eps, static_cast<hipStream_t>(stream));
 }
 
+int d4_rmsnorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* d_gamma, float* scratch, int rows, int dim, float eps, void* stream) {
+    D4_REQUIRE(x && dy && gamma && dx && d_gamma && scratch, "d4_rmsnorm_backward: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows == 0) return 0;
+    if (int rc = d4::rmsnorm_bwd(x, dy, gamma, scratch, dx, rows, dim, eps, s)) return rc;
+    return d4::colsum(scratch, dim, rows, dim, d_gamma, s);
+}
+
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows, int bins, void* stream) {
     return d4::hl_gauss_scalar(logits, ld, centers, out, 1, rows, bins, static_cast<hipStream_t>(stream));
 }

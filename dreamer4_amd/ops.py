@@ -98,3 +98,398 @@ def gae(rewards: torch.Tensor, values: torch.Tensor, lens: torch.Tensor | None, 
 @gae.register_fake
 def _(rewards, values, lens, is_truncated, terminals, gamma, lam):
     return torch.empty_like(rewards, dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ autograd for rmsnorm / linear
+@custom_op('d4hip::rmsnorm_backward', mutates_args=())
+def rmsnorm_backward(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor, eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    _need_gpu(x, dy, weight)
+    lib = _lib.load()
+    D = x.shape[-1]
+    x2, dy2 = x.float().contiguous().view(-1, D), dy.float().contiguous().view(-1, D)
+    dx, dw, scratch = torch.empty_like(x2), torch.empty(D, device=x.device), torch.empty_like(x2)
+    _lib.check(lib.d4_rmsnorm_backward(_lib.ptr(x2), _lib.ptr(dy2), _lib.ptr(weight.float().contiguous()), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(scratch),
+                                       x2.shape[0], D, eps, _stream(x)))
+    return dx.view(x.shape), dw
+
+
+@rmsnorm_backward.register_fake
+def _(x, dy, weight, eps):
+    return torch.empty_like(x, dtype=torch.float32), torch.empty_like(weight, dtype=torch.float32)
+
+
+def _rmsnorm_setup(ctx, inputs, output):
+    x, weight, eps = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.eps = eps
+
+
+def _rmsnorm_bwd(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dx, dw = torch.ops.d4hip.rmsnorm_backward(x, dy, weight, ctx.eps)
+    return dx, dw, None
+
+
+rmsnorm.register_autograd(_rmsnorm_bwd, setup_context=_rmsnorm_setup)
+
+
+@custom_op('d4hip::linear_backward', mutates_args=())
+def linear_backward(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """Gradients of y = x @ weight^T: dx = dy @ weight, dweight = dy^T @ x (d4_gemm with transposed operands)."""
+    _need_gpu(x, dy, weight)
+    lib = _lib.load()
+    K, N = x.shape[-1], weight.shape[0]
+    x2, dy2, w = x.float().contiguous().view(-1, K), dy.float().contiguous().view(-1, N), weight.float().contiguous()
+    M = x2.shape[0]
+    dx, dw = torch.empty_like(x2), torch.empty_like(w)
+    # dx[m][k] = sum_n dy[m][n] W[n][k]: "W(k, n)" read from W[n * K + k] -> TRANS_B
+    _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(w), K, _lib.ptr(dx), K, None, None, 0, M, K, N, _lib.GEMM_TRANS_B, 0., _stream(x)))
+    # dw[n][k] = sum_m dy[m][n] x[m][k]: both operands indexed by the contraction first -> TRANS_A | TRANS_B
+    _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(x2), K, _lib.ptr(dw), K, None, None, 0, N, K, M, _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B, 0., _stream(x)))
+    return dx.view(x.shape), dw
+
+
+@linear_backward.register_fake
+def _(x, dy, weight):
+    return torch.empty_like(x, dtype=torch.float32), torch.empty_like(weight, dtype=torch.float32)
+
+
+def _linear_setup(ctx, inputs, output):
+    x, weight, bias, residual, flags, eps = inputs
+    if flags != 0:
+        raise _lib.D4Error('d4hip::linear is differentiable only without fused epilogue flags (use the block operators for the fused forms)')
+    ctx.save_for_backward(x, weight)
+    ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+
+
+def _linear_bwd(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dx, dw = torch.ops.d4hip.linear_backward(x, dy, weight)
+    db = dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_bias else None
+    return dx, dw, db, (dy if ctx.has_res else None), None, None
+
+
+linear.register_autograd(_linear_bwd, setup_context=_linear_setup)
+
+
+# ------------------------------------------------------------------------------------------------ differentiable trunk blocks
+# FeedForward (D4:2079-2116) and Attention (D4:1968-2075: within a frame / along time / over a context — the last one covers AttentionPool,
+# the special-token cross attention and LearnedQueriesAttentionPool) as dispatcher-visible ops with registered autograd.  Every forward
+# also returns the uint8 workspace it ran in (empty when D4_TRUNK_SAVE_FORWARD=0): the backward op runs on it without recomputing the
+# forward (`d4_*_backward_saved`), or recomputes it when the workspace is empty.  Parameters and gradients in the reference's layout.
+def _save_ws():
+    import os
+    return os.environ.get('D4_TRUNK_SAVE_FORWARD', '1') != '0'
+
+
+def _ws_new(nbytes, device):
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _ws_ptr(ws):
+    base = ws.data_ptr()
+    return C.c_void_p(base + (-base) % 256)
+
+
+def _f32c(*ts):
+    out = []
+    for t in ts:
+        if t is None:
+            out.append(None)
+            continue
+        if t.dtype != torch.float32:
+            raise _lib.D4Error('d4hip trunk blocks are fp32')
+        out.append(t.contiguous())
+    return out
+
+
+def _opt(t):                      # custom ops cannot return None: an absent gradient is an empty tensor
+    return None if t is None or t.numel() == 0 else t
+
+
+@custom_op('d4hip::swiglu_ff', mutates_args=())
+def swiglu_ff(x: torch.Tensor, norm_w: torch.Tensor, w_in: torch.Tensor, b_in: torch.Tensor, w_out: torch.Tensor,
+              b_out: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    _need_gpu(x)
+    x, norm_w, w_in, b_in, w_out, b_out = _f32c(x, norm_w, w_in, b_in, w_out, b_out)
+    D, inner = x.shape[-1], w_out.shape[1]
+    assert w_in.shape == (2 * inner, D) and w_out.shape == (D, inner) and b_in.shape == (2 * inner,) and b_out.shape == (D,)
+    rows = x.numel() // D
+    lib = _lib.load()
+    nbytes = lib.d4_ff_workspace_bytes(rows, D, inner)
+    ws = _ws_new(nbytes, x.device)
+    y = torch.empty_like(x)
+    _lib.check(lib.d4_ff_forward(_lib.ptr(x), _lib.ptr(norm_w), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(w_out), _lib.ptr(b_out),
+                                 rows, D, inner, _lib.ptr(y), _ws_ptr(ws), nbytes, _stream(x)))
+    return y, (ws if _save_ws() else ws.new_empty(0))
+
+
+@swiglu_ff.register_fake
+def _(x, norm_w, w_in, b_in, w_out, b_out):
+    return torch.empty_like(x), x.new_empty(0, dtype=torch.uint8)
+
+
+@custom_op('d4hip::swiglu_ff_backward', mutates_args=())
+def swiglu_ff_backward(x: torch.Tensor, dy: torch.Tensor, norm_w: torch.Tensor, w_in: torch.Tensor, b_in: torch.Tensor, w_out: torch.Tensor,
+                       ws: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    x, dy, norm_w, w_in, b_in, w_out = _f32c(x, dy, norm_w, w_in, b_in, w_out)
+    D, inner = x.shape[-1], w_out.shape[1]
+    rows = x.numel() // D
+    lib = _lib.load()
+    nbytes = lib.d4_ff_workspace_bytes(rows, D, inner)
+    fn = lib.d4_ff_backward_saved
+    if ws.numel() == 0:
+        ws, fn = _ws_new(nbytes, x.device), lib.d4_ff_backward
+    dx, dn, dwi, dbi, dwo = torch.empty_like(x), torch.empty_like(norm_w), torch.empty_like(w_in), torch.empty_like(b_in), torch.empty_like(w_out)
+    dbo = torch.empty(D, device=x.device)
+    _lib.check(fn(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(norm_w), _lib.ptr(w_in), _lib.ptr(b_in), _lib.ptr(w_out), rows, D, inner,
+                  _lib.ptr(dx), _lib.ptr(dn), _lib.ptr(dwi), _lib.ptr(dbi), _lib.ptr(dwo), _lib.ptr(dbo), _ws_ptr(ws), nbytes, _stream(x)))
+    return dx, dn, dwi, dbi, dwo, dbo
+
+
+@swiglu_ff_backward.register_fake
+def _(x, dy, norm_w, w_in, b_in, w_out, ws):
+    e = torch.empty_like
+    return e(x), e(norm_w), e(w_in), e(b_in), e(w_out), x.new_empty(x.shape[-1])
+
+
+def _ff_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:5], output[1])
+
+
+def _ff_bwd(ctx, dy, _dws):
+    x, norm_w, w_in, b_in, w_out, ws = ctx.saved_tensors
+    return torch.ops.d4hip.swiglu_ff_backward(x, dy, norm_w, w_in, b_in, w_out, ws)
+
+
+swiglu_ff.register_autograd(_ff_bwd, setup_context=_ff_setup)
+
+
+def _attn_self(time_form, x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, num_special, belief):
+    _need_gpu(x)
+    x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq = _f32c(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq)
+    heads, dh = gamma.shape
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    P = _lib.ptr
+    if time_form:
+        B, T, S, D = x.shape
+        assert wq.shape == (heads * dh, D) and wo.shape == (D, heads * dh) and wg.shape == (heads, D) and inv_freq.shape == (dh // 2,)
+        assert rv is None or rv.shape == (B, T, S, heads, dh)
+        nbytes = lib.d4_time_attn_workspace_bytes(B, T, S, D, heads, dh)
+        ws = _ws_new(nbytes, x.device)
+        _lib.check(lib.d4_time_attn_forward(P(x), P(rv), P(norm_w), P(wq), P(wk), P(wv), P(wo), P(wg), P(wm), P(bm), P(gamma), P(inv_freq), B, T, S, D, heads, dh,
+                                            float(softclamp), int(belief), P(y), _ws_ptr(ws), nbytes, _stream(x)))
+    else:
+        F_, S, D = x.shape
+        assert wq.shape == (heads * dh, D) and wo.shape == (D, heads * dh) and wg.shape == (heads, D)
+        assert rv is None or rv.shape == (F_, S, heads, dh)
+        nbytes = lib.d4_attn_workspace_bytes(F_, S, D, heads, dh)
+        ws = _ws_new(nbytes, x.device)
+        _lib.check(lib.d4_space_attn_forward(P(x), P(rv), P(norm_w), P(wq), P(wk), P(wv), P(wo), P(wg), P(wm), P(bm), P(gamma), F_, S, D, heads, dh,
+                                             float(softclamp), int(num_special), int(belief), P(y), _ws_ptr(ws), nbytes, _stream(x)))
+    return y, (ws if _save_ws() else ws.new_empty(0))
+
+
+def _attn_self_backward(time_form, x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, num_special, belief, ws):
+    x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq = _f32c(x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq)
+    heads, dh = gamma.shape
+    lib = _lib.load()
+    e = torch.empty_like
+    dx, dn, dq, dk, dv, do, dg, dgam = e(x), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
+    drv, dwm, dbm = (e(rv), e(wm), e(bm)) if rv is not None else (None, None, None)
+    P = _lib.ptr
+    saved = ws.numel() > 0
+    if time_form:
+        B, T, S, D = x.shape
+        nbytes = lib.d4_time_attn_workspace_bytes(B, T, S, D, heads, dh)
+        if not saved:
+            ws = _ws_new(nbytes, x.device)
+        fn = lib.d4_time_attn_backward_saved if saved else lib.d4_time_attn_backward
+        _lib.check(fn(P(x), P(rv), P(dy), P(norm_w), P(wq), P(wk), P(wv), P(wo), P(wg), P(wm), P(bm), P(gamma), P(inv_freq), B, T, S, D, heads, dh,
+                      float(softclamp), int(belief), P(dx), P(drv), P(dn), P(dq), P(dk), P(dv), P(do), P(dg), P(dwm), P(dbm), P(dgam),
+                      _ws_ptr(ws), nbytes, _stream(x)))
+    else:
+        F_, S, D = x.shape
+        nbytes = lib.d4_attn_workspace_bytes(F_, S, D, heads, dh)
+        if not saved:
+            ws = _ws_new(nbytes, x.device)
+        fn = lib.d4_space_attn_backward_saved if saved else lib.d4_space_attn_backward
+        _lib.check(fn(P(x), P(rv), P(dy), P(norm_w), P(wq), P(wk), P(wv), P(wo), P(wg), P(wm), P(bm), P(gamma), F_, S, D, heads, dh,
+                      float(softclamp), int(num_special), int(belief), P(dx), P(drv), P(dn), P(dq), P(dk), P(dv), P(do), P(dg), P(dwm), P(dbm), P(dgam),
+                      _ws_ptr(ws), nbytes, _stream(x)))
+    z = lambda: x.new_empty(0)                 # (fresh tensors: the outputs of an op may not alias each other)
+    return dx, (drv if drv is not None else z()), dn, dq, dk, dv, do, dg, (dwm if dwm is not None else z()), (dbm if dbm is not None else z()), dgam
+
+
+_T = torch.Tensor
+_G11 = tuple[_T, _T, _T, _T, _T, _T, _T, _T, _T, _T, _T]
+
+
+@custom_op('d4hip::attn_block_space', mutates_args=())
+def attn_block_space(x: _T, rv: _T | None, norm_w: _T, wq: _T, wk: _T, wv: _T, wo: _T, wg: _T, wm: _T | None, bm: _T | None, gamma: _T,
+                     softclamp: float, num_special: int, belief: bool) -> tuple[_T, _T]:
+    """Attention.forward within each frame (D4:1968-2075): x (frames, tokens, dim); rv = residual values (frames, tokens, heads, dim_head)."""
+    return _attn_self(False, x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, None, softclamp, num_special, belief)
+
+
+@attn_block_space.register_fake
+def _(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, softclamp, num_special, belief):
+    return torch.empty_like(x), x.new_empty(0, dtype=torch.uint8)
+
+
+@custom_op('d4hip::attn_block_space_backward', mutates_args=())
+def attn_block_space_backward(x: _T, rv: _T | None, dy: _T, norm_w: _T, wq: _T, wk: _T, wv: _T, wo: _T, wg: _T, wm: _T | None, bm: _T | None, gamma: _T,
+                              softclamp: float, num_special: int, belief: bool, ws: _T) -> _G11:
+    return _attn_self_backward(False, x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, None, softclamp, num_special, belief, ws)
+
+
+def _fake_g11(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma):
+    e = torch.empty_like
+    z = lambda: x.new_empty(0)
+    return e(x), (e(rv) if rv is not None else z()), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), (e(wm) if wm is not None else z()), (e(bm) if bm is not None else z()), e(gamma)
+
+
+@attn_block_space_backward.register_fake
+def _(x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, softclamp, num_special, belief, ws):
+    return _fake_g11(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma)
+
+
+def _space_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:11], output[1])
+    ctx.cfg = inputs[11:14]
+
+
+def _space_bwd(ctx, dy, _dws):
+    *t, ws = ctx.saved_tensors
+    x, rv = t[0], t[1]
+    g = torch.ops.d4hip.attn_block_space_backward(x, rv, dy, *t[2:], *ctx.cfg, ws)
+    return (g[0], _opt(g[1]), *g[2:8], _opt(g[8]), _opt(g[9]), g[10], None, None, None)
+
+
+attn_block_space.register_autograd(_space_bwd, setup_context=_space_setup)
+
+
+@custom_op('d4hip::attn_block_time', mutates_args=())
+def attn_block_time(x: _T, rv: _T | None, norm_w: _T, wq: _T, wk: _T, wv: _T, wo: _T, wg: _T, wm: _T | None, bm: _T | None, gamma: _T, inv_freq: _T,
+                    softclamp: float, belief: bool) -> tuple[_T, _T]:
+    """The trunk's time layers (D4:3176-3215): causal attention along time per token column with rotary positions, training form (no KV
+    cache): x (batch, frames, tokens, dim)."""
+    return _attn_self(True, x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, 0, belief)
+
+
+@attn_block_time.register_fake
+def _(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, belief):
+    return torch.empty_like(x), x.new_empty(0, dtype=torch.uint8)
+
+
+@custom_op('d4hip::attn_block_time_backward', mutates_args=())
+def attn_block_time_backward(x: _T, rv: _T | None, dy: _T, norm_w: _T, wq: _T, wk: _T, wv: _T, wo: _T, wg: _T, wm: _T | None, bm: _T | None, gamma: _T,
+                             inv_freq: _T, softclamp: float, belief: bool, ws: _T) -> _G11:
+    return _attn_self_backward(True, x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, 0, belief, ws)
+
+
+@attn_block_time_backward.register_fake
+def _(x, rv, dy, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma, inv_freq, softclamp, belief, ws):
+    return _fake_g11(x, rv, norm_w, wq, wk, wv, wo, wg, wm, bm, gamma)
+
+
+def _time_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:12], output[1])
+    ctx.cfg = inputs[12:14]
+
+
+def _time_bwd(ctx, dy, _dws):
+    *t, ws = ctx.saved_tensors
+    g = torch.ops.d4hip.attn_block_time_backward(t[0], t[1], dy, *t[2:12], *ctx.cfg, ws)
+    return (g[0], _opt(g[1]), *g[2:8], _opt(g[8]), _opt(g[9]), g[10], None, None, None)
+
+
+attn_block_time.register_autograd(_time_bwd, setup_context=_time_setup)
+
+
+@custom_op('d4hip::attn_block_cross', mutates_args=())
+def attn_block_cross(q_tokens: _T, context: _T, norm_w: _T, norm_ctx_w: _T | None, wq: _T, wk: _T, wv: _T, wo: _T, wg: _T, gamma: _T, item_major: bool,
+                     softclamp: float) -> tuple[_T, _T]:
+    """Attention.forward with a context (D4:1968-2075) = AttentionPool (context = the item-major stack of layer hiddens, D4:2143-2177), the
+    special-token cross attention (D4:3227-3234) and LearnedQueriesAttentionPool (D4:2179-2210): q_tokens (groups, nq, dim)."""
+    _need_gpu(q_tokens)
+    q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma = _f32c(q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma)
+    G, nq, D = q_tokens.shape
+    nk, Dc = (context.shape[0], context.shape[2]) if item_major else (context.shape[1], context.shape[2])
+    assert (context.shape[1] if item_major else context.shape[0]) == G, 'context groups do not match the queries'
+    heads, dh = gamma.shape
+    assert wq.shape == (heads * dh, D) and wk.shape == (heads * dh, Dc) and wv.shape == (heads * dh, Dc) and wo.shape == (D, heads * dh)
+    lib = _lib.load()
+    nbytes = lib.d4_cross_attn_workspace_bytes(G, nq, nk, D, Dc, heads, dh)
+    ws = _ws_new(nbytes, q_tokens.device)
+    y = torch.empty_like(q_tokens)
+    P = _lib.ptr
+    _lib.check(lib.d4_cross_attn_forward(P(q_tokens), P(context), P(norm_w), P(norm_ctx_w), P(wq), P(wk), P(wv), P(wo), P(wg), P(gamma), G, nq, nk,
+                                         int(item_major), D, Dc, heads, dh, float(softclamp), P(y), _ws_ptr(ws), nbytes, _stream(q_tokens)))
+    return y, (ws if _save_ws() else ws.new_empty(0))
+
+
+@attn_block_cross.register_fake
+def _(q_tokens, context, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma, item_major, softclamp):
+    return torch.empty_like(q_tokens), q_tokens.new_empty(0, dtype=torch.uint8)
+
+
+_G10 = tuple[_T, _T, _T, _T, _T, _T, _T, _T, _T, _T]
+
+
+@custom_op('d4hip::attn_block_cross_backward', mutates_args=())
+def attn_block_cross_backward(q_tokens: _T, context: _T, dy: _T, norm_w: _T, norm_ctx_w: _T | None, wq: _T, wk: _T, wv: _T, wo: _T, wg: _T, gamma: _T,
+                              item_major: bool, softclamp: float, ws: _T) -> _G10:
+    q_tokens, context, dy, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma = _f32c(q_tokens, context, dy, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma)
+    G, nq, D = q_tokens.shape
+    nk, Dc = (context.shape[0], context.shape[2]) if item_major else (context.shape[1], context.shape[2])
+    heads, dh = gamma.shape
+    lib = _lib.load()
+    nbytes = lib.d4_cross_attn_workspace_bytes(G, nq, nk, D, Dc, heads, dh)
+    saved = ws.numel() > 0
+    if not saved:
+        ws = _ws_new(nbytes, q_tokens.device)
+    fn = lib.d4_cross_attn_backward_saved if saved else lib.d4_cross_attn_backward
+    e = torch.empty_like
+    dq_t, dc, dn, dq, dk, dv, do, dg, dgam = e(q_tokens), e(context), e(norm_w), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
+    dnc = e(norm_ctx_w) if norm_ctx_w is not None else None
+    P = _lib.ptr
+    _lib.check(fn(P(q_tokens), P(context), P(dy), P(norm_w), P(norm_ctx_w), P(wq), P(wk), P(wv), P(wo), P(wg), P(gamma), G, nq, nk, int(item_major), D, Dc,
+                  heads, dh, float(softclamp), P(dq_t), P(dc), P(dn), P(dnc), P(dq), P(dk), P(dv), P(do), P(dg), P(dgam), _ws_ptr(ws), nbytes, _stream(q_tokens)))
+    return dq_t, dc, dn, (dnc if dnc is not None else q_tokens.new_empty(0)), dq, dk, dv, do, dg, dgam
+
+
+@attn_block_cross_backward.register_fake
+def _(q_tokens, context, dy, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma, item_major, softclamp, ws):
+    e = torch.empty_like
+    return e(q_tokens), e(context), e(norm_w), (e(norm_ctx_w) if norm_ctx_w is not None else q_tokens.new_empty(0)), e(wq), e(wk), e(wv), e(wo), e(wg), e(gamma)
+
+
+def _cross_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:10], output[1])
+    ctx.cfg = inputs[10:12]
+
+
+def _cross_bwd(ctx, dy, _dws):
+    *t, ws = ctx.saved_tensors
+    g = torch.ops.d4hip.attn_block_cross_backward(t[0], t[1], dy, *t[2:10], *ctx.cfg, ws)
+    return (g[0], g[1], g[2], _opt(g[3]), *g[4:10], None, None)
+
+
+attn_block_cross.register_autograd(_cross_bwd, setup_context=_cross_setup)
+
+
+@custom_op('d4hip::flow_euler_step', mutates_args=())
+def flow_euler_step(x: torch.Tensor, pred: torch.Tensor, one_minus_t: float, dt: float) -> torch.Tensor:
+    """The x-space shortcut / Euler update of the denoising loop (D4:6567-6580): x + (pred - x) / (1 - t) * dt, as a new tensor."""
+    _need_gpu(x, pred)
+    out = x.float().contiguous().clone()
+    _lib.check(_lib.load().d4_euler_step(_lib.ptr(out), _lib.ptr(pred.float().contiguous()), out.numel(), one_minus_t, dt, _stream(x)))
+    return out
+
+
+@flow_euler_step.register_fake
+def _(x, pred, one_minus_t, dt):
+    return torch.empty_like(x, dtype=torch.float32)

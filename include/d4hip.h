@@ -354,6 +354,9 @@ int d4_cross_attn_backward_saved(const float* q_tokens, const float* ctx, const 
                            float* d_w_gates, float* d_k_gamma, float* workspace, size_t workspace_bytes, void* stream);
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim,
                float eps, void* stream);
+/* backward of nn.RMSNorm (autograd of y = x / rms(x) * gamma): dx [rows][dim], d_gamma [dim]; scratch = rows * dim floats. */
+int d4_rmsnorm_backward(const float* x, const float* dy, const float* gamma, float* dx, float* d_gamma, float* scratch, int rows, int dim, float eps,
+                        void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,
                        int bins, void* stream);
 int d4_gae(const float* rewards, const float* values, const int64_t* lens, const uint8_t* is_truncated,

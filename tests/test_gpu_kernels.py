@@ -326,6 +326,32 @@ def test_gae_matches_the_reference_fixture(lib):
     assert torch.allclose(out.cpu(), t(g['gae_returns']), atol=1e-6)
 
 
+def test_torch_library_rmsnorm_and_linear_are_differentiable(lib):
+    """torch.ops.d4hip.rmsnorm / linear carry registered autograd (d4_rmsnorm_backward, d4_gemm with transposed operands): gradients match
+    torch's own autograd of F.rms_norm / F.linear; the fused-epilogue forms of `linear` refuse to be differentiated; flow_euler_step == the formula."""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(5, 37, 64, device='cuda', generator=g); w = torch.randn(64, device='cuda', generator=g)
+    W = torch.randn(96, 64, device='cuda', generator=g) / 8; b = torch.randn(96, device='cuda', generator=g)
+    dy = torch.randn(5, 37, 96, device='cuda', generator=g)
+    eps = 1.1920929e-07
+    leaves = [t.clone().requires_grad_() for t in (x, w, W, b)]
+    y = torch.ops.d4hip.linear(torch.ops.d4hip.rmsnorm(leaves[0], leaves[1], eps), leaves[2], leaves[3], None, 0, 0.)
+    y.backward(dy)
+    ref_leaves = [t.clone().double().requires_grad_() for t in (x, w, W, b)]
+    yr = torch.nn.functional.linear(torch.nn.functional.rms_norm(ref_leaves[0], (64,), ref_leaves[1], eps), ref_leaves[2], ref_leaves[3])
+    yr.backward(dy.double())
+    assert torch.allclose(y.double(), yr, atol=1e-4, rtol=1e-4)
+    for a, r, name in zip(leaves, ref_leaves, ('dx', 'd gamma', 'dW', 'db')):
+        scale = r.grad.abs().max().item()
+        assert (a.grad.double() - r.grad).abs().max().item() <= 2e-5 * max(scale, 1.), name
+    xs = x.clone().requires_grad_()
+    with pytest.raises(_lib.D4Error, match='differentiable only without'):
+        torch.ops.d4hip.linear(xs, W, b, None, _lib.GEMM_SILU, 0.)
+    pred = torch.randn_like(x)
+    out = torch.ops.d4hip.flow_euler_step(x, pred, 0.75, 0.25)
+    assert torch.allclose(out, x + (pred - x) / 0.75 * 0.25, atol=1e-5)
+
+
 def test_torch_library_ops_run_the_hip_kernels_and_trace_without_graph_breaks(lib):
     x = torch.randn(37, 64, device='cuda'); w = torch.randn(64, device='cuda'); W = torch.randn(96, 64, device='cuda'); b = torch.randn(96, device='cuda')
 

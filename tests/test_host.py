@@ -123,13 +123,27 @@ def test_custom_ops_are_registered_with_the_dispatcher_and_traceable():
     """SURVEY.md 8b: the single-kernel entry points are torch.library ops (fake implementations let torch.compile trace them);
     on CPU tensors they raise instead of falling back."""
     import dreamer4_amd  # noqa: F401
-    for name in ('rmsnorm', 'linear', 'hl_gauss_to_scalar', 'gae'):
-        assert hasattr(torch.ops.d4hip, name)
+    for name in ('rmsnorm', 'linear', 'hl_gauss_to_scalar', 'gae', 'rmsnorm_backward', 'linear_backward', 'swiglu_ff', 'swiglu_ff_backward',
+                 'attn_block_space', 'attn_block_space_backward', 'attn_block_time', 'attn_block_time_backward', 'attn_block_cross',
+                 'attn_block_cross_backward', 'flow_euler_step'):
+        assert hasattr(torch.ops.d4hip, name), name
     from torch._subclasses.fake_tensor import FakeTensorMode
     with FakeTensorMode():
         x = torch.empty(3, 5, 64); w = torch.empty(128, 64)
         y = torch.ops.d4hip.linear(x, w, None, None, 4, 1e-6)           # SiLU-GLU pairs halve the width
         assert y.shape == (3, 5, 64)
+        # the trunk blocks (FeedForward, attention within a frame / over a context): output + the forward workspace
+        n, wi, bi, wo, bo = torch.empty(64), torch.empty(340, 64), torch.empty(340), torch.empty(64, 170), torch.empty(64)
+        y, ws = torch.ops.d4hip.swiglu_ff(x, n, wi, bi, wo, bo)
+        assert y.shape == x.shape and ws.dtype == torch.uint8
+        g = torch.ops.d4hip.swiglu_ff_backward(x, y, n, wi, bi, wo, ws)
+        assert [t.shape for t in g] == [x.shape, n.shape, wi.shape, bi.shape, wo.shape, bo.shape]
+        hq, gam = torch.empty(128, 64), torch.empty(2, 64)
+        y, ws = torch.ops.d4hip.attn_block_space(x, None, n, hq, hq, hq, torch.empty(64, 128), torch.empty(2, 64), None, None, gam, 50., 1, True)
+        assert y.shape == x.shape
+        g = torch.ops.d4hip.attn_block_space_backward(x, None, y, n, hq, hq, hq, torch.empty(64, 128), torch.empty(2, 64), None, None, gam, 50., 1, True, ws)
+        assert g[0].shape == x.shape and g[1].numel() == 0 and g[10].shape == gam.shape
+        assert torch.ops.d4hip.flow_euler_step(x, x, 0.5, 0.25).shape == x.shape
         assert torch.ops.d4hip.rmsnorm(x, torch.empty(64), 1e-6).shape == x.shape
         assert torch.ops.d4hip.hl_gauss_to_scalar(torch.empty(7, 255), torch.empty(255)).shape == (7,)
     with pytest.raises(D4Error, match='no CPU fallback'):
