@@ -1382,6 +1382,16 @@ int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C,
     return d4::gemm_bf16(g, static_cast<hipStream_t>(stream));
 }
 
+int d4_cvt_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) { return d4::cvt_f32_to_bf16(src, dst, n, static_cast<hipStream_t>(stream)); }
+
+int d4_gemm_bf16a(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
+                  int M, int N, int K, int flags, float rms_eps, int config, void* stream) {
+    d4::GemmArgs g{nullptr, lda, nullptr, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.Ab = Ab; g.Wb = Wb; g.Cb = Cb;
+    D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a: call not supported (K %% 64, lda / ldw %% 8, 16-byte aligned operands)");
+    return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
+}
+
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim, float eps, void* stream) {
     return d4::rmsnorm_rows(x, ldx, gamma, y, ldy, rows, dim, eps, static_cast<hipStream_t>(stream));
 }

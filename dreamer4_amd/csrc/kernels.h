@@ -31,6 +31,10 @@ struct GemmArgs {
     // strided batch (blockIdx.y): A += b * strideA, W += b * strideW, C/R += b * strideC   (elements)
     int batch = 1; int64_t strideA = 0, strideW = 0, strideC = 0;      // algorithmic flops of this launch when padding makes 2MNK an over-count (profiling only)
     const uint16_t* Wb = nullptr;      // bf16 image of W (same [N][ldw] layout): when set the call runs on the bf16 MFMA kernel (gemm_bf16.hip)
+    const uint16_t* Ab = nullptr;      // bf16 image of A (same [M][lda] layout, written by the producer): with Wb set the call runs on the
+                                       // bf16-activation kernel (gemm_bf16a.hip) and never touches the fp32 A
+    uint16_t* Cb = nullptr;            // optional bf16 copy of the output ([M][ldc]; SiLU-GLU: [M][N/2] at ldc), for the next GEMM's Ab
+    uint16_t* C2b = nullptr;           // ... and of the row-compacted second output ([rows][ldc2])
     int64_t wplane = 0;                // > 0: Wb holds THREE bf16 planes (W = W1 + W2 + W3, plane stride in elements) and the call runs as
                                        // an fp32 GEMM on the bf16 matrix cores (split operands, six products: gemm_x3.hip)
 };
@@ -47,6 +51,12 @@ const char* gemm_bf16_dma_config_name(int c);
 int gemm_bf16_dma_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);
 int gemm_bf16_force_config(int id);                          // test / microbenchmark hook; returns the number of configurations
 int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
+// bf16 GEMM with bf16 activations, LDS-DMA ring (gemm_bf16a.hip): p.Ab / p.Wb in, fp32 C (+ bf16 copy p.Cb) out
+bool gemm_bf16a_applicable(const GemmArgs& p);
+bool gemm_bf16a_config_valid(int c, const GemmArgs& p);
+int gemm_bf16a_configs();
+int gemm_bf16a_rule(const GemmArgs& p);
+int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 void gemm_bf16_profile_enable(int stride);
 int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count);
 // third fp32 family (gemm_x3.hip): fp32 operands split into three bf16 numbers, six bf16 MFMA products, fp32 accumulate (fp32 accuracy)

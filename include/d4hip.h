@@ -269,6 +269,12 @@ int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, 
 /* the bf16 MFMA kernel alone: A fp32 [M][lda] (rounded to bf16 on the way in), Wb bf16 [N][ldw] (raw 16-bit patterns), C fp32 */
 int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream);
+/* The same Linear with the activations already in bf16 (the producer's bf16 copy): Ab bf16 [M][lda], Wb bf16 [N][ldw], C fp32 [M][ldc], Cb (optional)
+ * = bf16(C) at the same leading dimension for the next layer.  K % 64 == 0, lda / ldw % 8 == 0.  LDS-DMA ring kernel (csrc/gemm_bf16a.hip); `config`
+ * = -1: tile by the shape rule, else one of its configurations.  d4_cvt_bf16: fp32 -> bf16 (round to nearest even), n elements. */
+int d4_gemm_bf16a(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
+                  int M, int N, int K, int flags, float rms_eps, int config, void* stream);
+int d4_cvt_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
 /* fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip; the trunk's default `Linear` arithmetic): every fp32 operand is the exact sum of three
  * bf16 numbers and a product is accumulated from its six leading bf16 x bf16 terms in fp32 — fp32 accuracy (error against float64 no
  * larger than the f32-input MFMA kernels'), 6/16 of their matrix-pipe time.  d4_split_bf16x3 writes the three planes of W
