@@ -47,6 +47,46 @@ def test_gemm_bf16_kernel(M, N, K, flags):
     assert err <= tol, f'M{M} N{N} K{K} flags{flags}: err {err:.3e} > {tol:.3e}'
 
 
+@pytest.mark.parametrize('M,N,K,flags', [(128, 128, 64, 0), (1792, 1024, 512, 0), (200, 300, 128, 1), (1920, 2752, 1024, 5), (45, 388, 64, 3), (1792, 1552, 1024, 1),
+                                         (17, 64, 2752, 0)])
+def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
+    """gemm_bf16a.hip (d4_gemm_bf16a): both operands bf16 in HBM, LDS-DMA ring, v_mfma_f32_16x16x32_bf16.  Every tile configuration against a
+    float64 product of the SAME bf16 operands (row scale from the bf16 activations), all epilogues, partial tiles; the bf16 copy of the output
+    equals the rounded fp32 output."""
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(0)
+    Ab = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16).contiguous()
+    Wb = torch.randn(N, K, device='cuda', generator=g).to(torch.bfloat16).contiguous()
+    b = torch.randn(N, device='cuda', generator=g)
+    swiglu = bool(flags & _lib.GEMM_SWIGLU)
+    R = None if swiglu else torch.randn(M, N, device='cuda', generator=g)
+    Nout = N // 2 if swiglu else N
+    eps = 1.1920929e-07
+    Ad = Ab.double()
+    ref = (Ad * torch.rsqrt(Ad.pow(2).mean(-1, keepdim=True) + eps) if flags & _lib.GEMM_RMS_ROWSCALE else Ad) @ Wb.double().t() + b.double()
+    if flags & _lib.GEMM_SILU:
+        ref = torch.nn.functional.silu(ref)
+    if swiglu:
+        r = ref.reshape(M, N // 64, 2, 32)
+        ref = (r[:, :, 0] * torch.nn.functional.silu(r[:, :, 1])).reshape(M, N // 2)
+    if R is not None:
+        ref = ref + R.double()
+    tol = 3e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
+    ran = 0
+    for cfg in (-1, 0, 1, 2, 3, 4, 5):
+        out = torch.full((M, Nout), float('nan'), device='cuda'); outb = torch.zeros(M, Nout, device='cuda', dtype=torch.bfloat16)
+        rc = lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(outb), _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, cfg, stream())
+        if rc != 0:
+            assert swiglu and cfg in (1, 2, 4), lib.d4_last_error()       # the SiLU-GLU pairing needs a wave tile of 64 columns
+            continue
+        ran += 1
+        assert (out.double() - ref).abs().max().item() <= tol, (cfg, (out.double() - ref).abs().max().item(), tol)
+        assert torch.equal(outb, out.to(torch.bfloat16)), cfg
+    assert ran >= 4
+    with pytest.raises(_lib.D4Error, match='not supported'):
+        _lib.check(lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, None, None, None, 0, M, N, 96, 0, eps, -1, stream()))
+
+
 @pytest.mark.parametrize('M,N,K,flags', [(3584, 512, 512, 0), (200, 300, 96, 1), (1920, 2752, 1024, 5), (1920, 1552, 1024, 1), (130, 64, 2752, 0)])
 def test_gemm_bf16_lds_dma_form_matches_the_register_staged_form(M, N, K, flags):
     """The experimental LDS-DMA form (gemm_bf16_dma.hip, opt-in D4_BF16_DMA=1): every tile configuration walks k in the register-staged
