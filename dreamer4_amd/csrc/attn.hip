@@ -233,6 +233,145 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same self attention (<= 16 tokens of one frame, head dim 64) on the matrix pipe — round 3.  The LDS-staged kernel above is
+// INSTRUCTION-bound, not memory-bound (rocprofv3: 33 k wave-cycles per wave, ~1100 issued instructions per wave x 4 waves per (frame, head), most of
+// them per-token scalar work replicated over lanes): it runs at 0.21 of the HBM rate it could stream at.  Here ONE wave owns a (frame, head):
+//   * q, k, v, value residual are read as float4 per lane in the MFMA operand layout (lane = (token = l & 15, feature quarter kq = l >> 4):
+//     features 16 s + 4 kq .. + 3 for s = 0..3), so the 16 x 16 score matrix is 16 v_mfma_f32_16x16x4_f32 and P.V another 16 — exact fp32 FMAs;
+//   * the key l2-norm is a per-key scale of the score COLUMN ((gamma + 1) goes onto q, sqrt(dh) cancels against the query scale), so no key is
+//     ever rewritten; S^T = K Q^T is computed, whose accumulator layout (lane holds P[i = l & 15][4 kq .. + 3]) IS the A-operand layout of P.V;
+//   * per-token reductions (|k|, |v|) are 16 FMAs + two cross-row shuffles for all 16 tokens at once; softmax is 4 values per lane + two shuffles.
+// ~10x fewer issued instructions per (frame, head); V' (the mixed values) is the only LDS-staged operand.
+constexpr int SM_LDV = 68;
+__global__ __launch_bounds__(256) void space_attn_mfma_kernel(SmallAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float Vs_all[4][16 * SM_LDV];
+    __shared__ __attribute__((aligned(16))) float kinv_all[4][16];
+    __shared__ __attribute__((aligned(16))) float vinv_all[4][16];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + w;
+    if (unit >= p.groups * p.heads) return;
+    const int g = unit / p.heads, h = unit % p.heads;
+    float* Vs = Vs_all[w];
+    float* kinv_s = kinv_all[w];
+    float* vinv_s = vinv_all[w];
+    const int n = p.nk;
+    const int tok = lane & 15, kq = lane >> 4;
+    const bool row_ok = tok < n;
+    const int hoff = h * 64 + 4 * kq;
+
+    // ---- operand loads: row `tok`, features 16 s + 4 kq .. + 3
+    const float* qp = p.q + g * p.q_group_stride + (int64_t)tok * p.q_item_stride + hoff;
+    const float* kp = p.k + g * p.k_group_stride + (int64_t)tok * p.k_item_stride + hoff;
+    const float* vp = p.v + g * p.v_group_stride + (int64_t)tok * p.v_item_stride + hoff;
+    const float* rp = p.vres ? p.vres + g * p.r_group_stride + (int64_t)tok * p.r_item_stride + hoff : nullptr;
+    f32x4 q4[4], k4[4], v4[4], r4[4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        q4[s] = row_ok ? *reinterpret_cast<const f32x4*>(qp + 16 * s) : zero;
+        k4[s] = row_ok ? *reinterpret_cast<const f32x4*>(kp + 16 * s) : zero;
+        v4[s] = row_ok ? *reinterpret_cast<const f32x4*>(vp + 16 * s) : zero;
+        r4[s] = (row_ok && rp) ? *reinterpret_cast<const f32x4*>(rp + 16 * s) : zero;
+    }
+    float wmix = 0.f;
+    if (p.vres && row_ok) wmix = sigmoidf(p.mix[g * p.m_group_stride + (int64_t)tok * p.m_item_stride + h]);
+    float gate_logit[4] = {0.f, 0.f, 0.f, 0.f};             // the head gates of this lane's four output rows: requested with the operands
+    if (p.gate) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * kq + r < n) gate_logit[r] = p.gate[g * p.g_group_stride + (int64_t)(4 * kq + r) * p.g_item_stride + h];
+    }
+    // (gamma + 1) onto q: score = sum_f q_f (gamma_f + 1) k_f / |k|   (the sqrt(dh) of the key scale cancels the 1 / sqrt(dh) of the query scale)
+    float ksq = 0.f, vsq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.k_gamma + h * 64 + 16 * s + 4 * kq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q4[s][e] *= gm[e] + 1.f;
+            ksq = __builtin_fmaf(k4[s][e], k4[s][e], ksq);
+            if (p.vres) v4[s][e] = lerp_torch(v4[s][e], r4[s][e], wmix);
+            vsq = __builtin_fmaf(v4[s][e], v4[s][e], vsq);
+        }
+        *reinterpret_cast<f32x4*>(Vs + tok * SM_LDV + 16 * s + 4 * kq) = v4[s];
+    }
+    ksq += __shfl_xor(ksq, 16); ksq += __shfl_xor(ksq, 32);
+    vsq += __shfl_xor(vsq, 16); vsq += __shfl_xor(vsq, 32);
+    if (kq == 0) {
+        kinv_s[tok] = 1.f / fmaxf(sqrtf(ksq), 1e-12f);
+        vinv_s[tok] = 1.f / fmaxf(sqrtf(vsq), 1e-12f);
+    }
+    // ---- S^T = K Q'^T: A operand = K rows (key j = l & 15), B operand = Q' rows (query i = l & 15); acc[r] = S[i = l & 15][j = 4 kq + r]
+    f32x4 st = zero;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[s][e], q4[s][e], st, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                       // this wave's LDS writes (V', 1/|k|, 1/|v|) are read back by this wave only
+    const f32x4 kinv = *reinterpret_cast<const f32x4*>(kinv_s + 4 * kq);
+    const int i = tok;
+    const bool ordinary_q = p.mask_special > 0 && i < n - p.mask_special;
+    float sc[4], m = -FLT_MAX;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = 4 * kq + r;
+        float v = st[r] * kinv[r];
+        if (p.softclamp > 0.f) v = tanhf(v / p.softclamp) * p.softclamp;
+        const bool valid = j < n && i < n && !(ordinary_q && j >= n - p.mask_special);
+        sc[r] = valid ? v : -FLT_MAX;
+        m = fmaxf(m, sc[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+    f32x4 pr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pr[r] = sc[r] > -FLT_MAX ? expf(sc[r] - m) : 0.f; l += pr[r]; }
+    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+    const float linv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] *= linv;
+
+    // ---- out = P V': A operand = P (lane holds P[i = l & 15][4 kq + e]), B operand = V'[j = 4 kq + e][d0 + (l & 15)] from LDS
+    f32x4 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        o[t] = zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[e], Vs[(4 * kq + e) * SM_LDV + 16 * t + tok], o[t], 0, 0, 0);
+    }
+    // o[t][r] = out[i = 4 kq + r][d = 16 t + (l & 15)]
+    const f32x4 vinv = *reinterpret_cast<const f32x4*>(vinv_s + 4 * kq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = 4 * kq + r;
+        if (qi >= n) continue;                                              // (uniform over each 16-lane row group)
+        float vn[4], dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            vn[t] = Vs[qi * SM_LDV + 16 * t + tok] * vinv[r];
+            dot = __builtin_fmaf(o[t][r], vn[t], dot);
+        }
+        if (p.belief) dot = row_sum16(dot);
+        int orank = qi;
+        if (p.q_hi > 0) {
+            if (qi >= p.q_lo && qi < p.q_hi) orank = qi - p.q_lo;
+            else if (p.q_last && qi == n - 1) orank = p.q_hi - p.q_lo;
+            else continue;
+        }
+        const float gate = p.gate ? sigmoidf(gate_logit[r]) : 1.f;
+        float* op = p.out + g * p.o_group_stride + (int64_t)orank * p.o_item_stride + h * 64 + tok;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = o[t][r];
+            if (p.belief) v -= dot * vn[t];
+            op[16 * t] = v * gate;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Attention over up to ATTN_MAXK keys per (group, head) with head dim 64: the space layers of the video tokenizer's decoder
 // (~100 tokens per frame: patches + latents, D4:3654-3668).  One 4-wave block per (group, head):
 //   phase 1  the keys are prepared ONCE, cooperatively, into LDS: value-residual lerp on V, K l2-norm * (gamma + 1) * sqrt(dh), 1 / |v|
@@ -356,7 +495,14 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
         // algorithmic bytes: q, k, v (+ value residual) rows of every (frame, head) read once, the kept query rows written once
         const int nq_out = p.q_hi > 0 ? (p.q_hi - p.q_lo + p.q_last) : p.nq;
         const double sp_bytes = 4.0 * p.groups * p.heads * (p.dh * ((double)p.nk * (p.vres ? 4 : 3) + nq_out) + 2.0 * p.nk);
-        if (p.dh == 64) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
+        // head dim 64 with 16-byte aligned rows: one wave per (frame, head) on the matrix pipe (D4_SPACE_ATTN_MFMA=0: the LDS-staged VALU form)
+        static const bool mfma_on = !(getenv("D4_SPACE_ATTN_MFMA") && atoi(getenv("D4_SPACE_ATTN_MFMA")) == 0);
+        auto al4 = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
+        const bool mfma_ok = mfma_on && p.dh == 64 && al4(p.q, p.q_group_stride, p.q_item_stride) && al4(p.k, p.k_group_stride, p.k_item_stride) &&
+                             al4(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4(p.vres, p.r_group_stride, p.r_item_stride)) &&
+                             ((uintptr_t)p.k_gamma % 16) == 0;
+        if (mfma_ok) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_mfma_kernel, dim3(cdiv(waves, 4)), block, 0, stream, p);
+        else if (p.dh == 64) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
         else if (p.dh == 32) hipLaunchKernelGGL(space_attn_kernel<32>, dim3(waves), block, 0, stream, p);
         else hipLaunchKernelGGL(space_attn_kernel<16>, dim3(waves), block, 0, stream, p);
         D4_LAUNCH_CHECK();
