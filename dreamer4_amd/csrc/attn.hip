@@ -242,11 +242,15 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
 //     ever rewritten; S^T = K Q^T is computed, whose accumulator layout (lane holds P[i = l & 15][4 kq .. + 3]) IS the A-operand layout of P.V;
 //   * per-token reductions (|k|, |v|) are 16 FMAs + two cross-row shuffles for all 16 tokens at once; softmax is 4 values per lane + two shuffles.
 // ~10x fewer issued instructions per (frame, head); V' (the mixed values) is the only LDS-staged operand.
+// The kernel is a template over the number of 16-row query tiles QT and key tiles KT: <1, 1> is the within-frame self attention (value residual,
+// special-token mask, belief projection, restricted query set), <1, 2> / <2, 1> / <1, 1> the small cross forms (learned-query pools in / out with up
+// to 32 latents or queries, the agent token's cross attention).
 constexpr int SM_LDV = 68;
-__global__ __launch_bounds__(256) void space_attn_mfma_kernel(SmallAttnArgs p) {
-    __shared__ __attribute__((aligned(16))) float Vs_all[4][16 * SM_LDV];
-    __shared__ __attribute__((aligned(16))) float kinv_all[4][16];
-    __shared__ __attribute__((aligned(16))) float vinv_all[4][16];
+template <int QT, int KT>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(SmallAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float Vs_all[4][KT * 16 * SM_LDV];
+    __shared__ __attribute__((aligned(16))) float kinv_all[4][KT * 16];
+    __shared__ __attribute__((aligned(16))) float vinv_all[4][KT * 16];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * 4 + w;
     if (unit >= p.groups * p.heads) return;
@@ -254,119 +258,143 @@ __global__ __launch_bounds__(256) void space_attn_mfma_kernel(SmallAttnArgs p) {
     float* Vs = Vs_all[w];
     float* kinv_s = kinv_all[w];
     float* vinv_s = vinv_all[w];
-    const int n = p.nk;
+    const int nq = p.nq, nk = p.nk;
     const int tok = lane & 15, kq = lane >> 4;
-    const bool row_ok = tok < n;
     const int hoff = h * 64 + 4 * kq;
-
-    // ---- operand loads: row `tok`, features 16 s + 4 kq .. + 3
-    const float* qp = p.q + g * p.q_group_stride + (int64_t)tok * p.q_item_stride + hoff;
-    const float* kp = p.k + g * p.k_group_stride + (int64_t)tok * p.k_item_stride + hoff;
-    const float* vp = p.v + g * p.v_group_stride + (int64_t)tok * p.v_item_stride + hoff;
-    const float* rp = p.vres ? p.vres + g * p.r_group_stride + (int64_t)tok * p.r_item_stride + hoff : nullptr;
-    f32x4 q4[4], k4[4], v4[4], r4[4];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- operand loads: token row 16 tile + tok, features 16 s + 4 kq .. + 3
+    f32x4 q4[QT][4], k4[KT][4];
+    float gate_logit[QT][4];                 // the head gates of this lane's output rows: requested with the operands
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        q4[s] = row_ok ? *reinterpret_cast<const f32x4*>(qp + 16 * s) : zero;
-        k4[s] = row_ok ? *reinterpret_cast<const f32x4*>(kp + 16 * s) : zero;
-        v4[s] = row_ok ? *reinterpret_cast<const f32x4*>(vp + 16 * s) : zero;
-        r4[s] = (row_ok && rp) ? *reinterpret_cast<const f32x4*>(rp + 16 * s) : zero;
+    for (int qt = 0; qt < QT; ++qt) {
+        const int i = 16 * qt + tok;
+        const float* qp = p.q + g * p.q_group_stride + (int64_t)i * p.q_item_stride + hoff;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) q4[qt][s] = i < nq ? *reinterpret_cast<const f32x4*>(qp + 16 * s) : zero;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = 16 * qt + 4 * kq + r;
+            gate_logit[qt][r] = (p.gate && qi < nq) ? p.gate[g * p.g_group_stride + (int64_t)qi * p.g_item_stride + h] : 0.f;
+        }
     }
-    float wmix = 0.f;
-    if (p.vres && row_ok) wmix = sigmoidf(p.mix[g * p.m_group_stride + (int64_t)tok * p.m_item_stride + h]);
-    float gate_logit[4] = {0.f, 0.f, 0.f, 0.f};             // the head gates of this lane's four output rows: requested with the operands
-    if (p.gate) {
+    f32x4 gm[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * kq + r < n) gate_logit[r] = p.gate[g * p.g_group_stride + (int64_t)(4 * kq + r) * p.g_item_stride + h];
+    for (int s = 0; s < 4; ++s) gm[s] = *reinterpret_cast<const f32x4*>(p.k_gamma + h * 64 + 16 * s + 4 * kq);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const int j = 16 * kt + tok;
+        const bool ok = j < nk;
+        const float* kp = p.k + g * p.k_group_stride + (int64_t)j * p.k_item_stride + hoff;
+        const float* vp = p.v + g * p.v_group_stride + (int64_t)j * p.v_item_stride + hoff;
+        const float* rp = p.vres ? p.vres + g * p.r_group_stride + (int64_t)j * p.r_item_stride + hoff : nullptr;
+        f32x4 v4[4], r4[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            k4[kt][s] = ok ? *reinterpret_cast<const f32x4*>(kp + 16 * s) : zero;
+            v4[s] = ok ? *reinterpret_cast<const f32x4*>(vp + 16 * s) : zero;
+            r4[s] = (ok && rp) ? *reinterpret_cast<const f32x4*>(rp + 16 * s) : zero;
+        }
+        float wmix = 0.f;
+        if (p.vres && ok) wmix = sigmoidf(p.mix[g * p.m_group_stride + (int64_t)j * p.m_item_stride + h]);
+        float ksq = 0.f, vsq = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ksq = __builtin_fmaf(k4[kt][s][e], k4[kt][s][e], ksq);
+                if (p.vres) v4[s][e] = lerp_torch(v4[s][e], r4[s][e], wmix);
+                vsq = __builtin_fmaf(v4[s][e], v4[s][e], vsq);
+            }
+            *reinterpret_cast<f32x4*>(Vs + j * SM_LDV + 16 * s + 4 * kq) = v4[s];
+        }
+        ksq += __shfl_xor(ksq, 16); ksq += __shfl_xor(ksq, 32);
+        vsq += __shfl_xor(vsq, 16); vsq += __shfl_xor(vsq, 32);
+        if (kq == 0) {
+            kinv_s[j] = 1.f / fmaxf(sqrtf(ksq), 1e-12f);
+            vinv_s[j] = 1.f / fmaxf(sqrtf(vsq), 1e-12f);
+        }
     }
     // (gamma + 1) onto q: score = sum_f q_f (gamma_f + 1) k_f / |k|   (the sqrt(dh) of the key scale cancels the 1 / sqrt(dh) of the query scale)
-    float ksq = 0.f, vsq = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.k_gamma + h * 64 + 16 * s + 4 * kq);
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            q4[s][e] *= gm[e] + 1.f;
-            ksq = __builtin_fmaf(k4[s][e], k4[s][e], ksq);
-            if (p.vres) v4[s][e] = lerp_torch(v4[s][e], r4[s][e], wmix);
-            vsq = __builtin_fmaf(v4[s][e], v4[s][e], vsq);
-        }
-        *reinterpret_cast<f32x4*>(Vs + tok * SM_LDV + 16 * s + 4 * kq) = v4[s];
-    }
-    ksq += __shfl_xor(ksq, 16); ksq += __shfl_xor(ksq, 32);
-    vsq += __shfl_xor(vsq, 16); vsq += __shfl_xor(vsq, 32);
-    if (kq == 0) {
-        kinv_s[tok] = 1.f / fmaxf(sqrtf(ksq), 1e-12f);
-        vinv_s[tok] = 1.f / fmaxf(sqrtf(vsq), 1e-12f);
-    }
-    // ---- S^T = K Q'^T: A operand = K rows (key j = l & 15), B operand = Q' rows (query i = l & 15); acc[r] = S[i = l & 15][j = 4 kq + r]
-    f32x4 st = zero;
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[s][e], q4[s][e], st, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) q4[qt][s][e] *= gm[s][e] + 1.f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                       // this wave's LDS writes (V', 1/|k|, 1/|v|) are read back by this wave only
-    const f32x4 kinv = *reinterpret_cast<const f32x4*>(kinv_s + 4 * kq);
-    const int i = tok;
-    const bool ordinary_q = p.mask_special > 0 && i < n - p.mask_special;
-    float sc[4], m = -FLT_MAX;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int j = 4 * kq + r;
-        float v = st[r] * kinv[r];
-        if (p.softclamp > 0.f) v = tanhf(v / p.softclamp) * p.softclamp;
-        const bool valid = j < n && i < n && !(ordinary_q && j >= n - p.mask_special);
-        sc[r] = valid ? v : -FLT_MAX;
-        m = fmaxf(m, sc[r]);
-    }
-    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
-    f32x4 pr;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pr[r] = sc[r] > -FLT_MAX ? expf(sc[r] - m) : 0.f; l += pr[r]; }
-    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
-    const float linv = l > 0.f ? 1.f / l : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] *= linv;
 
-    // ---- out = P V': A operand = P (lane holds P[i = l & 15][4 kq + e]), B operand = V'[j = 4 kq + e][d0 + (l & 15)] from LDS
-    f32x4 o[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        o[t] = zero;
+    for (int qt = 0; qt < QT; ++qt) {
+        // ---- S^T = K Q'^T per key tile: A operand = K rows (key 16 kt + (l & 15)), B operand = Q' rows; acc[r] = S[i = 16 qt + (l & 15)][j = 16 kt + 4 kq + r]
+        const int i = 16 * qt + tok;
+        const bool ordinary_q = p.mask_special > 0 && i < nq - p.mask_special;
+        f32x4 pr[KT];
+        float m = -FLT_MAX;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[e], Vs[(4 * kq + e) * SM_LDV + 16 * t + tok], o[t], 0, 0, 0);
-    }
-    // o[t][r] = out[i = 4 kq + r][d = 16 t + (l & 15)]
-    const f32x4 vinv = *reinterpret_cast<const f32x4*>(vinv_s + 4 * kq);
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x4 st = zero;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = 4 * kq + r;
-        if (qi >= n) continue;                                              // (uniform over each 16-lane row group)
-        float vn[4], dot = 0.f;
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kt][s][e], q4[qt][s][e], st, 0, 0, 0);
+            const f32x4 kinv = *reinterpret_cast<const f32x4*>(kinv_s + 16 * kt + 4 * kq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * kt + 4 * kq + r;
+                float v = st[r] * kinv[r];
+                if (p.softclamp > 0.f) v = tanhf(v / p.softclamp) * p.softclamp;
+                const bool valid = j < nk && i < nq && !(ordinary_q && j >= nk - p.mask_special);
+                pr[kt][r] = valid ? v : -FLT_MAX;
+                m = fmaxf(m, pr[kt][r]);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pr[kt][r] = pr[kt][r] > -FLT_MAX ? expf(pr[kt][r] - m) : 0.f; l += pr[kt][r]; }
+        l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+        const float linv = l > 0.f ? 1.f / l : 0.f;
+
+        // ---- out = P V': A operand = P (lane holds P[i][16 kt + 4 kq + e]), B operand = V'[16 kt + 4 kq + e][16 t + (l & 15)] from LDS
+        f32x4 o[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            vn[t] = Vs[qi * SM_LDV + 16 * t + tok] * vinv[r];
-            dot = __builtin_fmaf(o[t][r], vn[t], dot);
-        }
-        if (p.belief) dot = row_sum16(dot);
-        int orank = qi;
-        if (p.q_hi > 0) {
-            if (qi >= p.q_lo && qi < p.q_hi) orank = qi - p.q_lo;
-            else if (p.q_last && qi == n - 1) orank = p.q_hi - p.q_lo;
-            else continue;
-        }
-        const float gate = p.gate ? sigmoidf(gate_logit[r]) : 1.f;
-        float* op = p.out + g * p.o_group_stride + (int64_t)orank * p.o_item_stride + h * 64 + tok;
+            o[t] = zero;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = o[t][r];
-            if (p.belief) v -= dot * vn[t];
-            op[16 * t] = v * gate;
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[kt][e] * linv, Vs[(16 * kt + 4 * kq + e) * SM_LDV + 16 * t + tok], o[t], 0, 0, 0);
+        }
+        // o[t][r] = out[i = 16 qt + 4 kq + r][d = 16 t + (l & 15)]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = 16 * qt + 4 * kq + r;
+            if (qi >= nq) continue;                                             // (uniform over each 16-lane row group)
+            float vn[4] = {0.f, 0.f, 0.f, 0.f}, dot = 0.f;
+            if (p.belief) {                                                     // self attention only (nq == nk): the query's own mixed value row
+                const float vinv = vinv_s[qi];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    vn[t] = Vs[qi * SM_LDV + 16 * t + tok] * vinv;
+                    dot = __builtin_fmaf(o[t][r], vn[t], dot);
+                }
+                dot = row_sum16(dot);
+            }
+            int orank = qi;
+            if (p.q_hi > 0) {
+                if (qi >= p.q_lo && qi < p.q_hi) orank = qi - p.q_lo;
+                else if (p.q_last && qi == nq - 1) orank = p.q_hi - p.q_lo;
+                else continue;
+            }
+            const float gate = p.gate ? sigmoidf(gate_logit[qt][r]) : 1.f;
+            float* op = p.out + g * p.o_group_stride + (int64_t)orank * p.o_item_stride + h * 64 + tok;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) op[16 * t] = (o[t][r] - dot * vn[t]) * gate;
         }
     }
 }
@@ -501,7 +529,7 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
         const bool mfma_ok = mfma_on && p.dh == 64 && al4(p.q, p.q_group_stride, p.q_item_stride) && al4(p.k, p.k_group_stride, p.k_item_stride) &&
                              al4(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4(p.vres, p.r_group_stride, p.r_item_stride)) &&
                              ((uintptr_t)p.k_gamma % 16) == 0;
-        if (mfma_ok) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_mfma_kernel, dim3(cdiv(waves, 4)), block, 0, stream, p);
+        if (mfma_ok) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, (attn_mfma_kernel<1, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
         else if (p.dh == 64) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
         else if (p.dh == 32) hipLaunchKernelGGL(space_attn_kernel<32>, dim3(waves), block, 0, stream, p);
         else hipLaunchKernelGGL(space_attn_kernel<16>, dim3(waves), block, 0, stream, p);
@@ -509,6 +537,12 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
         return 0;
     }
     // algorithmic bytes: a batch-independent operand (group stride 0) is counted once
+    static const bool mfma_small_on = !(getenv("D4_SPACE_ATTN_MFMA") && atoi(getenv("D4_SPACE_ATTN_MFMA")) == 0);
+    auto al4s = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
+    const bool mfma_small = mfma_small_on && p.dh == 64 && p.nq <= 32 && p.nk <= 32 && (p.nq <= 16 || p.nk <= 16) && p.q_hi == 0 &&
+                            al4s(p.q, p.q_group_stride, p.q_item_stride) && al4s(p.k, p.k_group_stride, p.k_item_stride) &&
+                            al4s(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4s(p.vres, p.r_group_stride, p.r_item_stride)) &&
+                            ((uintptr_t)p.k_gamma % 16) == 0;
     const double sm_bytes = 4.0 * p.heads * p.dh * ((p.q_group_stride ? (double)p.groups : 1.0) * p.nq + (p.k_group_stride ? (double)p.groups : 1.0) * p.nk * 2 + (double)p.groups * p.nq);
 #define D4_SMALL_ATTN(NK)                                                                                       \
     do {                                                                                                          \
@@ -516,7 +550,12 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
         else if (p.dh == 32) hipLaunchKernelGGL((small_attn_kernel<NK, 32>), dim3(waves), block, 0, stream, p);   \
         else hipLaunchKernelGGL((small_attn_kernel<NK, 16>), dim3(waves), block, 0, stream, p);                   \
     } while (0)
-    if (p.nk <= 16) D4_SMALL_ATTN(16);
+    if (mfma_small) {         // one wave per (group, head) on the matrix pipe (attn_mfma_kernel): up to 32 x 16 or 16 x 32 (queries x keys)
+        if (p.nq <= 16 && p.nk <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
+        else if (p.nq <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 2>), dim3(cdiv(waves, 4)), block, 0, stream, p);
+        else D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<2, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
+    }
+    else if (p.nk <= 16) D4_SMALL_ATTN(16);
     else if (p.nk <= 32) D4_SMALL_ATTN(32);
     else D4_SMALL_ATTN(64);
 #undef D4_SMALL_ATTN
