@@ -275,7 +275,7 @@ def main():
     names = [n + (', *> fp32 by split operands on the bf16 MFMA' if sp else ', *> fp32 MFMA') for n, sp in zip(raw_names, is_split)]
     # warm-up: first-use tile autotuning of every GEMM shape happens here; the last warm-up step is also used to find the
     # dominant tile configuration (all configurations event-timed), so that the timed region only carries events for it
-    dom, warm_classes, warm_exec, glue_measured = None, None, (0., 0.), None
+    dom, warm_classes, warm_exec, glue_measured, fused_flops = None, None, (0., 0.), None, 0.
     for w in range(args.warmup):
         last = timing and w == args.warmup - 1
         if last:
@@ -288,12 +288,15 @@ def main():
             lib.d4_profile_enable(0)
             lib.d4_profile_glue_enable(0)
             ng = lib.d4_profile_glue_classes()
-            gms = (C.c_double * ng)(); gby = (C.c_double * ng)(); gcnt = (C.c_int64 * ng)()
+            gms = (C.c_double * ng)(); gby = (C.c_double * ng)(); gcnt = (C.c_int64 * ng)(); gfl = (C.c_double * ng)()
+            _lib.check(lib.d4_profile_glue_read_flops(gfl, ng))
             _lib.check(lib.d4_profile_glue_read(gms, gby, gcnt, ng))
+            fused_flops = sum(gfl[i] for i in range(ng))          # GEMM work done inside the per-frame fused kernels (frame_fused.hip)
             glue_measured = {lib.d4_profile_glue_class_name(i).decode(): dict(
                 hbm_gbs=round(gby[i] / max(gms[i], 1e-9) / 1e6, 1), frac_of_8tbs=round(gby[i] / max(gms[i], 1e-9) / 1e6 / 8000., 3),
                 avg_us=round(1e3 * gms[i] / gcnt[i], 2), launches=int(gcnt[i]), ms_per_step=round(gms[i], 2),
-                algorithmic_mb_per_launch=round(gby[i] / gcnt[i] / 1e6, 2)) for i in range(ng) if gcnt[i]}
+                algorithmic_mb_per_launch=round(gby[i] / gcnt[i] / 1e6, 2),
+                **({'matrix_gflop_per_launch': round(gfl[i] / gcnt[i] / 1e9, 2)} if gfl[i] > 0 else {})) for i in range(ng) if gcnt[i]}
             ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
             _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
             dom = max(range(ncls), key=lambda i: ms[i])
@@ -365,7 +368,9 @@ def main():
         if warm_classes is not None:
             roofline['executed_gemm_tflop_per_step'] = round(warm_exec[0] / 1e12, 2)
             roofline['executed_tflops_inside_gemm_kernels'] = round(warm_exec[0] / max(warm_exec[1], 1e-9) / 1e9, 2)
-            roofline['executed_tflops_over_the_whole_step'] = round(warm_exec[0] / (1e-3 * (sum(gen_ms) + sum(learn_ms)) / len(gen_ms)) / 1e12, 2)
+            # whole-step figure: the GEMM launches' flops + the matrix work the per-frame fused kernels do in place of GEMM launches
+            roofline['executed_gemm_tflop_per_step_incl_fused'] = round((warm_exec[0] + fused_flops) / 1e12, 2)
+            roofline['executed_tflops_over_the_whole_step'] = round((warm_exec[0] + fused_flops) / (1e-3 * (sum(gen_ms) + sum(learn_ms)) / len(gen_ms)) / 1e12, 2)
             roofline['executed_frac_of_fp32_matrix_peak_whole_step'] = round(roofline['executed_tflops_over_the_whole_step'] / PEAK_FP32_MFMA_TFLOPS, 4)
             roofline['note'] = ('fp32 throughout; the gemm_x3_kernel classes are fp32 GEMMs run as 6 bf16 MFMA products per fp32 product (operands split exactly '
                                 'into three bf16 numbers, fp32 accumulation; error vs float64 below the f32-input MFMA kernels\'), bound = 2500 / 6 TFLOP/s; '

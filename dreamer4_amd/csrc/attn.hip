@@ -12,16 +12,12 @@
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
+#include "attn_mfma.h"
+#include "pool_mix_row.h"
 #include <float.h>
 #include <stdlib.h>
 
 namespace d4 {
-
-__device__ __forceinline__ float lerp_torch(float a, float b, float w) {
-    // at::native::lerp: two-branch form
-    float d = b - a;
-    return (fabsf(w) < 0.5f) ? a + w * d : b - d * (1.f - w);
-}
 
 // Generic form: one block (4 waves) per (group, head).  Wave w prepares keys w, w+4, ... (value-residual mix, key l2-norm)
 // into LDS, then owns queries w, w+4, ...; scores are wave reductions, so they live in SGPRs.
@@ -245,7 +241,6 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
 // The kernel is a template over the number of 16-row query tiles QT and key tiles KT: <1, 1> is the within-frame self attention (value residual,
 // special-token mask, belief projection, restricted query set), <1, 2> / <2, 1> / <1, 1> the small cross forms (learned-query pools in / out with up
 // to 32 latents or queries, the agent token's cross attention).
-constexpr int SM_LDV = 68;
 template <int QT, int KT>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(SmallAttnArgs p) {
     __shared__ __attribute__((aligned(16))) float Vs_all[4][KT * 16 * SM_LDV];
@@ -255,148 +250,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(SmallAttnArgs p) {
     const int unit = blockIdx.x * 4 + w;
     if (unit >= p.groups * p.heads) return;
     const int g = unit / p.heads, h = unit % p.heads;
-    float* Vs = Vs_all[w];
-    float* kinv_s = kinv_all[w];
-    float* vinv_s = vinv_all[w];
-    const int nq = p.nq, nk = p.nk;
-    const int tok = lane & 15, kq = lane >> 4;
-    const int hoff = h * 64 + 4 * kq;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-
-    // ---- operand loads: token row 16 tile + tok, features 16 s + 4 kq .. + 3
-    f32x4 q4[QT][4], k4[KT][4];
-    float gate_logit[QT][4];                 // the head gates of this lane's output rows: requested with the operands
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int i = 16 * qt + tok;
-        const float* qp = p.q + g * p.q_group_stride + (int64_t)i * p.q_item_stride + hoff;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) q4[qt][s] = i < nq ? *reinterpret_cast<const f32x4*>(qp + 16 * s) : zero;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = 16 * qt + 4 * kq + r;
-            gate_logit[qt][r] = (p.gate && qi < nq) ? p.gate[g * p.g_group_stride + (int64_t)qi * p.g_item_stride + h] : 0.f;
-        }
-    }
-    f32x4 gm[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) gm[s] = *reinterpret_cast<const f32x4*>(p.k_gamma + h * 64 + 16 * s + 4 * kq);
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int j = 16 * kt + tok;
-        const bool ok = j < nk;
-        const float* kp = p.k + g * p.k_group_stride + (int64_t)j * p.k_item_stride + hoff;
-        const float* vp = p.v + g * p.v_group_stride + (int64_t)j * p.v_item_stride + hoff;
-        const float* rp = p.vres ? p.vres + g * p.r_group_stride + (int64_t)j * p.r_item_stride + hoff : nullptr;
-        f32x4 v4[4], r4[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            k4[kt][s] = ok ? *reinterpret_cast<const f32x4*>(kp + 16 * s) : zero;
-            v4[s] = ok ? *reinterpret_cast<const f32x4*>(vp + 16 * s) : zero;
-            r4[s] = (ok && rp) ? *reinterpret_cast<const f32x4*>(rp + 16 * s) : zero;
-        }
-        float wmix = 0.f;
-        if (p.vres && ok) wmix = sigmoidf(p.mix[g * p.m_group_stride + (int64_t)j * p.m_item_stride + h]);
-        float ksq = 0.f, vsq = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ksq = __builtin_fmaf(k4[kt][s][e], k4[kt][s][e], ksq);
-                if (p.vres) v4[s][e] = lerp_torch(v4[s][e], r4[s][e], wmix);
-                vsq = __builtin_fmaf(v4[s][e], v4[s][e], vsq);
-            }
-            *reinterpret_cast<f32x4*>(Vs + j * SM_LDV + 16 * s + 4 * kq) = v4[s];
-        }
-        ksq += __shfl_xor(ksq, 16); ksq += __shfl_xor(ksq, 32);
-        vsq += __shfl_xor(vsq, 16); vsq += __shfl_xor(vsq, 32);
-        if (kq == 0) {
-            kinv_s[j] = 1.f / fmaxf(sqrtf(ksq), 1e-12f);
-            vinv_s[j] = 1.f / fmaxf(sqrtf(vsq), 1e-12f);
-        }
-    }
-    // (gamma + 1) onto q: score = sum_f q_f (gamma_f + 1) k_f / |k|   (the sqrt(dh) of the key scale cancels the 1 / sqrt(dh) of the query scale)
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q4[qt][s][e] *= gm[s][e] + 1.f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                       // this wave's LDS writes (V', 1/|k|, 1/|v|) are read back by this wave only
-
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        // ---- S^T = K Q'^T per key tile: A operand = K rows (key 16 kt + (l & 15)), B operand = Q' rows; acc[r] = S[i = 16 qt + (l & 15)][j = 16 kt + 4 kq + r]
-        const int i = 16 * qt + tok;
-        const bool ordinary_q = p.mask_special > 0 && i < nq - p.mask_special;
-        f32x4 pr[KT];
-        float m = -FLT_MAX;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            f32x4 st = zero;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kt][s][e], q4[qt][s][e], st, 0, 0, 0);
-            const f32x4 kinv = *reinterpret_cast<const f32x4*>(kinv_s + 16 * kt + 4 * kq);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = 16 * kt + 4 * kq + r;
-                float v = st[r] * kinv[r];
-                if (p.softclamp > 0.f) v = tanhf(v / p.softclamp) * p.softclamp;
-                const bool valid = j < nk && i < nq && !(ordinary_q && j >= nk - p.mask_special);
-                pr[kt][r] = valid ? v : -FLT_MAX;
-                m = fmaxf(m, pr[kt][r]);
-            }
-        }
-        m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pr[kt][r] = pr[kt][r] > -FLT_MAX ? expf(pr[kt][r] - m) : 0.f; l += pr[kt][r]; }
-        l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
-        const float linv = l > 0.f ? 1.f / l : 0.f;
-
-        // ---- out = P V': A operand = P (lane holds P[i][16 kt + 4 kq + e]), B operand = V'[16 kt + 4 kq + e][16 t + (l & 15)] from LDS
-        f32x4 o[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            o[t] = zero;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[kt][e] * linv, Vs[(16 * kt + 4 * kq + e) * SM_LDV + 16 * t + tok], o[t], 0, 0, 0);
-        }
-        // o[t][r] = out[i = 16 qt + 4 kq + r][d = 16 t + (l & 15)]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = 16 * qt + 4 * kq + r;
-            if (qi >= nq) continue;                                             // (uniform over each 16-lane row group)
-            float vn[4] = {0.f, 0.f, 0.f, 0.f}, dot = 0.f;
-            if (p.belief) {                                                     // self attention only (nq == nk): the query's own mixed value row
-                const float vinv = vinv_s[qi];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    vn[t] = Vs[qi * SM_LDV + 16 * t + tok] * vinv;
-                    dot = __builtin_fmaf(o[t][r], vn[t], dot);
-                }
-                dot = row_sum16(dot);
-            }
-            int orank = qi;
-            if (p.q_hi > 0) {
-                if (qi >= p.q_lo && qi < p.q_hi) orank = qi - p.q_lo;
-                else if (p.q_last && qi == nq - 1) orank = p.q_hi - p.q_lo;
-                else continue;
-            }
-            const float gate = p.gate ? sigmoidf(gate_logit[qt][r]) : 1.f;
-            float* op = p.out + g * p.o_group_stride + (int64_t)orank * p.o_item_stride + h * 64 + tok;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) op[16 * t] = (o[t][r] - dot * vn[t]) * gate;
-        }
-    }
+    float* op = p.out + g * p.o_group_stride + h * 64;
+    const int64_t ois = p.o_item_stride;
+    attn_mfma_unit<QT, KT>(p, g, h, lane, Vs_all[w], kinv_all[w], vinv_all[w],
+                           [&](int orank, int t, int tok, float v) { op[(int64_t)orank * ois + 16 * t + tok] = v; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -581,118 +438,9 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     const int m = blockIdx.x * 4 + wslot;
     if (m >= p.M) return;
     const int lane = threadIdx.x & 63;
-    float* ps = psh[wslot];
-
-    // gate_h = sigmoid(RMSNorm(x) . gate_w[h]) scales the whole head output, so it is applied once after the mix; for the
-    // in-loop pools x IS the last hidden row of the loop.  (gate weights: staged once per block in LDS, see above)
-    const bool x_is_last_hidden = p.x == p.hid + (int64_t)(L - 1) * p.M * D && p.ldx == D;
-    float glog[PH] = {0.f, 0.f, 0.f, 0.f};
-
-    // scores: the 4 heads x 64 features of a key row are exactly one float4 per lane (head = lane / 16), so the
-    // per-head reductions are 16-lane DPP row reductions and all four heads are scored at once
-    const int hh = lane >> 4;
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
-    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + lane * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) g4[e] = (g4[e] + 1.f) * 8.f;
-    float mxl = -FLT_MAX;
-    for (int l = 0; l < L; ++l) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
-        const float nrm = sqrtf(row_sum16(kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3]));
-        const float inv = 1.f / fmaxf(nrm, 1e-12f);
-        const float sc = row_sum16(q4[0] * (kv[0] * inv * g4[0]) + q4[1] * (kv[1] * inv * g4[1]) +
-                                   q4[2] * (kv[2] * inv * g4[2]) + q4[3] * (kv[3] * inv * g4[3])) * 0.125f;
-        mxl = fmaxf(mxl, sc);
-        if ((lane & 15) == 0) ps[l * PH + hh] = sc;
-    }
-    float mx[PH];
-#pragma unroll
-    for (int h = 0; h < PH; ++h) mx[h] = readlane_f(mxl, h * 16);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float den[PH];
-#pragma unroll
-    for (int h = 0; h < PH; ++h) {
-        float d = 0.f;
-        for (int l = 0; l < L; ++l) d += expf(ps[l * PH + h] - mx[h]);
-        den[h] = d;
-    }
-    f32x4 acc[PH][ITER];
-#pragma unroll
-    for (int h = 0; h < PH; ++h)
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // hidden rows are software-pipelined one ahead: the next row's loads are in flight while this row is reduced / mixed
-    f32x4 vn[ITER];
-    auto load_row = [&](int l, f32x4 (&dst)[ITER]) {
-        const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)l * p.M + m) * D);
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int c4 = lane + 64 * i;
-            dst[i] = c4 < nf4 ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    load_row(0, vn);
-    for (int l = 0; l < L; ++l) {
-        f32x4 v[ITER];
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            v[i] = vn[i];
-            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-        }
-        if (l + 1 < L) load_row(l + 1, vn);
-        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
-#pragma unroll
-        for (int h = 0; h < PH; ++h) {
-            const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * rstd;
-#pragma unroll
-            for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
-        }
-        if (l == L - 1 && x_is_last_hidden) {
-#pragma unroll
-            for (int h = 0; h < PH; ++h) {
-                float d = 0.f;
-#pragma unroll
-                for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += v[i][0] * g[0] + v[i][1] * g[1] + v[i][2] * g[2] + v[i][3] * g[3]; }
-                glog[h] = wave_sum(d) * rstd;
-            }
-        }
-    }
-    if (!x_is_last_hidden) {
-        const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx);
-        f32x4 xv[ITER];
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int c4 = lane + 64 * i;
-            xv[i] = c4 < nf4 ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-            ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
-        }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
-#pragma unroll
-        for (int h = 0; h < PH; ++h) {
-            float d = 0.f;
-#pragma unroll
-            for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += xv[i][0] * g[0] + xv[i][1] * g[1] + xv[i][2] * g[2] + xv[i][3] * g[3]; }
-            glog[h] = wave_sum(d) * rstd;
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < PH; ++h) {
-        const float gate = sigmoidf(glog[h]);
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) acc[h][i] = acc[h][i] * gate;
-    }
-#pragma unroll
-    for (int h = 0; h < PH; ++h) {
-        f32x4* ur = reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D);
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < nf4) ur[c4] = acc[h][i];
-        }
-    }
+    pool_mix_row<ITER>(p, m, lane, psh[wslot], gws, [&](int h, int c4, const f32x4& v) {
+        reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = v;
+    });
 }
 
 // Few token rows (BASELINE config 4's decode regime: one trajectory = 11 rows): one BLOCK per token row, its four waves split the L

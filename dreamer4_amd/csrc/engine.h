@@ -104,6 +104,9 @@ struct d4_engine {
     std::vector<float*> proj_w, proj_b;
     std::vector<d4::FfPrep> ffp;           // depth layers + special ff at index depth
     std::vector<float*> pq_w, pkv_w;
+    // tiled images ([N / 16][K / 4][16][4]) of the small projections the per-frame fused kernels stream (frame_fused.hip); empty vectors:
+    // the configuration does not take that path
+    std::vector<float*> wo_t, pv_t, po_t;
     float *cq_w, *ckv_w;
     float *lin_kv_w, *lin_q, *lin_gate, *lout_kv_w, *lout_q, *lout_gate, *qtmp;
     float *lout_w;                         // [dl][hd] = to_latent_pred.2.weight @ to_latent_pred.1.attn.to_out.weight

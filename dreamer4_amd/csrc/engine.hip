@@ -53,6 +53,16 @@ int engine_layout(d4_engine* e, bool assign) {
         e->pq_w[p] = fl((size_t)(hp + e->php) * D);
         e->pkv_w[p] = fl((size_t)2 * hp * D);
     }
+    // per-frame fused tails (frame_fused.hip): 8 heads x 64 and, for the pool tail, dim 512 with 4 pool heads — dynamics mode only
+    e->wo_t.clear(); e->pv_t.clear(); e->po_t.clear();
+    if (!e->encoder && !e->decoder && c.attn_dim_head == 64 && c.attn_heads == 8 && D % 32 == 0 && D >= 256) {
+        e->wo_t.assign(depth, nullptr);
+        for (int l = 0; l < depth; ++l) e->wo_t[l] = fl((size_t)D * hd);
+        if (D == 512 && c.pool_heads == 4) {
+            e->pv_t.assign(depth, nullptr); e->po_t.assign(depth, nullptr);
+            for (int p = 0; p < depth; ++p) { e->pv_t[p] = fl((size_t)hp * D); e->po_t[p] = fl((size_t)D * hp); }
+        }
+    }
     e->cq_w = fl((size_t)(hd + c.attn_heads) * D);
     e->ckv_w = fl((size_t)2 * hd * D);
     e->lin_kv_w = fl((size_t)2 * hd * dl);
@@ -441,7 +451,13 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
         if ((rc = fold_attn_rows(e->pq_w[p] + (size_t)hp * D, D, a.to_gates, a.norm, e->php, s))) return rc;
         if ((rc = fold_attn_rows(e->pkv_w[p], D, a.to_k, a.norm_ctx, hp, s))) return rc;
         if ((rc = fold_attn_rows(e->pkv_w[p] + (size_t)hp * D, D, a.to_v, a.norm_ctx, hp, s))) return rc;
+        if (!e->pv_t.empty()) {
+            if ((rc = tile16_weights(e->pkv_w[p] + (size_t)hp * D, D, e->pv_t[p], hp, D, s))) return rc;
+            if ((rc = tile16_weights(a.to_out, hp, e->po_t[p], D, hp, s))) return rc;
+        }
     }
+    for (int l = 0; l < (int)e->wo_t.size(); ++l)
+        if ((rc = tile16_weights(e->layer_attn[l].to_out, hd, e->wo_t[l], D, hd, s))) return rc;
     if (e->decoder) {
         // positional embedding of the patch grid: the normed MLP (recipe: engine.h) of the (row, column) coordinates — batch independent,
         // evaluated once here (D4:3617-3625).  Its first layer has K = 2: coordinates / weight are zero-padded to 4 columns.
@@ -580,6 +596,14 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         PoolMixArgs pm{};
         pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
+        // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
+        // D4_FRAME_FUSED=2: the mix stays its own kernel and only the tail is fused
+        if (S > 0 && M % S == 0 && !e->pv_t.empty() && (!t_bf16 || t_bf16->split) && frame_pool_tail_applicable(M / S, S, D, c.pool_heads)) {
+            static const bool tail_only = getenv("D4_FRAME_FUSED") && atoi(getenv("D4_FRAME_FUSED")) == 2;
+            if (!tail_only) return frame_pool(pm, e->pv_t[p], e->po_t[p], M / S, S, x, D, y, D, y_compact, D, e->keep_lo, e->keep_hi, has_agent, s);
+            if ((rc = pool_mix(pm, s))) return rc;
+            return frame_pool_tail(e->pool_u, e->pv_t[p], e->po_t[p], M / S, S, D, c.pool_heads, x, D, y, D, y_compact, D, e->keep_lo, e->keep_hi, has_agent, s);
+        }
         if ((rc = pool_mix(pm, s))) return rc;
         GemmArgs gv{e->pool_u, c.pool_heads * D, e->pkv_w[p] + (size_t)hp * D, D, e->pool_att, hp, nullptr, nullptr, 0, M, 64, D, 0, RMS_EPS};
         gv.batch = c.pool_heads; gv.strideA = D; gv.strideW = (int64_t)64 * D; gv.strideC = 64;
@@ -701,6 +725,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         float* P = l == 0 ? e->proj0 : e->proj;
         const int ldp = l == 0 ? e->Nproj0 : e->Nproj;
         if ((rc = gemm_simple(x_in, D, e->proj_w[l], D, P, ldp, M, ldp, D, GEMM_RMS_ROWSCALE, e->proj_b[l], nullptr, 0, s))) return rc;
+        bool fused_out = false;
         if (e->is_time[l]) {
             TimeAttnArgs ta{};
             ta.proj = P; ta.ldp = ldp; ta.vres = vres; ta.ldv = e->Nproj0; ta.k_gamma = a.k_gamma; ta.inv_freq = e->inv_freq;
@@ -730,6 +755,12 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
                 sa.q_lo = 1; sa.q_hi = 1 + ns; sa.q_last = 0;
                 sa.out = e->att_c; sa.o_group_stride = (int64_t)nkeep * hd;
             }
+            // per-frame fused form: attention of all heads of a frame, then its output projection + residual, in one kernel
+            const bool tail_compact = denoise_only && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8;
+            if (!tail_compact && !e->wo_t.empty() && (!t_bf16 || t_bf16->split) && frame_attn_out_applicable(sa, D)) {
+                if ((rc = frame_attn_out(sa, e->wo_t[l], D, x_in, D, slab(2 * l + 1), D, cslab(2 * l + 1), D, e->keep_lo, e->keep_hi, has_agent, s))) return rc;
+                fused_out = true;
+            } else
             if ((rc = small_attn(sa, s))) return rc;
         }
         // Denoise steps (no agent embedding wanted): nothing downstream reads the last layer's flow / register /
@@ -742,7 +773,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         }
         float* h1 = slab(2 * l + 1);
         float* h2 = slab(2 * l + 2);
-        if ((rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, e->keep_hi - e->keep_lo, has_agent, s))) return rc;
+        if (!fused_out && (rc = gemm_c2(e->att, hd, a.to_out, hd, h1, D, M, D, hd, 0, nullptr, x_in, D, cslab(2 * l + 1), S, e->keep_hi - e->keep_lo, has_agent, s))) return rc;
         if ((rc = ff_block(e, e->ffp[l], e->layer_ff[l].out_b, h1, D, h2, D, M, s, cslab(2 * l + 2), S, has_agent))) return rc;
         if (l != c.depth - 1) {
             float* xc = (denoise_only && l == c.depth - 2 && !e->is_time[c.depth - 1] && S <= 16 && S >= 8) ? e->xpool_c : nullptr;
@@ -1314,6 +1345,7 @@ int d4_profile_classes(void) { return d4::gemm_profile_classes(); }
 int d4_profile_glue_enable(int mask) { return d4::glue_profile_enable(mask); }
 int d4_profile_glue_read(double* ms, double* bytes, int64_t* count, int nclass) { return d4::glue_profile_read(ms, bytes, count, nclass); }
 int d4_profile_glue_classes(void) { return d4::GL_N; }
+int d4_profile_glue_read_flops(double* flops, int nclass) { return d4::glue_profile_read_flops(flops, nclass); }
 const char* d4_profile_glue_class_name(int c) { return d4::glue_class_name(c); }
 int d4_gemm_force_config(int id) {
     if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile configuration c of the split-operand fp32 family (gemm_x3.hip)

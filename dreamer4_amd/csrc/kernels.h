@@ -129,6 +129,21 @@ struct PoolMixArgs {
 };
 int pool_mix(const PoolMixArgs& p, hipStream_t stream);
 
+// ------------------------------------------------------------------------------------ per-frame fused block tails (frame_fused.hip)
+// W [N][K] -> Wt [N / 16][K / 4][16][4]: the weight image the per-frame kernels stream (a 16-row tile is one contiguous run)
+int tile16_weights(const float* W, int ldw, float* Wt, int N, int K, hipStream_t s);
+bool frame_fused_frames_ok(int frames);
+// within-frame attention -> output projection + residual (+ row-compacted copy), one workgroup per frame
+bool frame_attn_out_applicable(const SmallAttnArgs& sa, int D);
+int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const float* resid, int ldr, float* out, int ldo, float* c2, int ldc2, int c2_lo,
+                   int c2_hi, int c2_last, hipStream_t s);
+// AttentionPool tail: per-head value projection of the mixes -> output projection + residual (+ row-compacted copy)
+bool frame_pool_tail_applicable(int frames, int S, int D, int pool_heads);
+int frame_pool(const PoolMixArgs& pm, const float* wv_t, const float* wo_t, int frames, int S, const float* resid, int ldr, float* out, int ldo, float* c2,
+               int ldc2, int c2_lo, int c2_hi, int c2_last, hipStream_t s);      // mix + tail in one kernel
+int frame_pool_tail(const float* u, const float* wv_t, const float* wo_t, int frames, int S, int D, int pool_heads, const float* resid, int ldr, float* out,
+                    int ldo, float* c2, int ldc2, int c2_lo, int c2_hi, int c2_last, hipStream_t s);
+
 // ------------------------------------------------------------------------------------ time attention
 // Causal attention along time for every token column (b, s) with a preallocated KV cache.
 //   proj rows are ordered (b, tq, s); columns: q @ 0, k @ hd, v @ 2hd, gate @ 3hd, mix @ 3hd + h.

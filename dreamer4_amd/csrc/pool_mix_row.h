@@ -1,0 +1,128 @@
+// AttentionPool core for ONE token row on one wavefront (value side restructured: see PoolMixArgs in kernels.h): shared by the stand-alone
+// kernel (attn.hip: pool_mix_kernel) and the per-frame fused pool kernel (frame_fused.hip).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+#include <float.h>
+
+namespace d4 {
+
+// ps: LMAX * 4 floats of this wave's LDS scratch; gws: the pool's head-gate weights [4][ITER * 64] float4 staged in LDS (norm gamma folded,
+// columns past D zero); store(h, c4, value): the gated mix of head h, features 4 c4 .. 4 c4 + 3 of row m.
+template <int ITER, class Store>
+__device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int lane, float* ps, const f32x4* gws, Store store) {
+    constexpr int PH = 4;
+    const int L = p.L, D = p.D;
+    const int nf4 = D / 4;
+
+    // gate_h = sigmoid(RMSNorm(x) . gate_w[h]) scales the whole head output, so it is applied once after the mix; for the
+    // in-loop pools x IS the last hidden row of the loop.  (gate weights: staged once per block in LDS, see above)
+    const bool x_is_last_hidden = p.x == p.hid + (int64_t)(L - 1) * p.M * D && p.ldx == D;
+    float glog[PH] = {0.f, 0.f, 0.f, 0.f};
+
+    // scores: the 4 heads x 64 features of a key row are exactly one float4 per lane (head = lane / 16), so the
+    // per-head reductions are 16-lane DPP row reductions and all four heads are scored at once
+    const int hh = lane >> 4;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
+    f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + lane * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g4[e] = (g4[e] + 1.f) * 8.f;
+    float mxl = -FLT_MAX;
+    for (int l = 0; l < L; ++l) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
+        const float nrm = sqrtf(row_sum16(kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3]));
+        const float inv = 1.f / fmaxf(nrm, 1e-12f);
+        const float sc = row_sum16(q4[0] * (kv[0] * inv * g4[0]) + q4[1] * (kv[1] * inv * g4[1]) +
+                                   q4[2] * (kv[2] * inv * g4[2]) + q4[3] * (kv[3] * inv * g4[3])) * 0.125f;
+        mxl = fmaxf(mxl, sc);
+        if ((lane & 15) == 0) ps[l * PH + hh] = sc;
+    }
+    float mx[PH];
+#pragma unroll
+    for (int h = 0; h < PH; ++h) mx[h] = readlane_f(mxl, h * 16);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float den[PH];
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        float d = 0.f;
+        for (int l = 0; l < L; ++l) d += expf(ps[l * PH + h] - mx[h]);
+        den[h] = d;
+    }
+    f32x4 acc[PH][ITER];
+#pragma unroll
+    for (int h = 0; h < PH; ++h)
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // hidden rows are software-pipelined one ahead: the next row's loads are in flight while this row is reduced / mixed
+    f32x4 vn[ITER];
+    auto load_row = [&](int l, f32x4 (&dst)[ITER]) {
+        const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)l * p.M + m) * D);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            dst[i] = c4 < nf4 ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    load_row(0, vn);
+    for (int l = 0; l < L; ++l) {
+        f32x4 v[ITER];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            v[i] = vn[i];
+            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+        if (l + 1 < L) load_row(l + 1, vn);
+        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * rstd;
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
+        }
+        if (l == L - 1 && x_is_last_hidden) {
+#pragma unroll
+            for (int h = 0; h < PH; ++h) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += v[i][0] * g[0] + v[i][1] * g[1] + v[i][2] * g[2] + v[i][3] * g[3]; }
+                glog[h] = wave_sum(d) * rstd;
+            }
+        }
+    }
+    if (!x_is_last_hidden) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(p.x + (int64_t)m * p.ldx);
+        f32x4 xv[ITER];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            xv[i] = c4 < nf4 ? xr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+            ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
+#pragma unroll
+        for (int h = 0; h < PH; ++h) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += xv[i][0] * g[0] + xv[i][1] * g[1] + xv[i][2] * g[2] + xv[i][3] * g[3]; }
+            glog[h] = wave_sum(d) * rstd;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        const float gate = sigmoidf(glog[h]);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) acc[h][i] = acc[h][i] * gate;
+    }
+#pragma unroll
+    for (int h = 0; h < PH; ++h)
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nf4) store(h, c4, acc[h][i]);
+        }
+}
+
+}  // namespace d4

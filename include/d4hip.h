@@ -242,6 +242,7 @@ const char* d4_profile_class_name(int c);
 int d4_profile_glue_enable(int mask);
 int d4_profile_glue_read(double* ms, double* bytes, int64_t* count, int nclass);
 int d4_profile_glue_classes(void);
+int d4_profile_glue_read_flops(double* flops, int nclass);      /* matrix work the per-frame fused classes carry; call before d4_profile_glue_read */
 const char* d4_profile_glue_class_name(int c);
 
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
