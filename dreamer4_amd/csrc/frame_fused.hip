@@ -197,7 +197,7 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
     }
     __syncthreads();
     for (int ml = wave; ml < fo.S; ml += FF_NW)
-        pool_mix_row<ITER>(pm, g * fo.S + ml, lane, psh + wave * LMAX * PH, gws,
+        pool_mix_row<ITER, true>(pm, g * fo.S + ml, lane, psh + wave * LMAX * PH, gws,
                            [&](int h, int c4, const f32x4& v) { *reinterpret_cast<f32x4*>(Us + (h * 16 + ml) * LDU + c4 * 4) = v; });
     __syncthreads();
 

@@ -9,7 +9,10 @@ namespace d4 {
 
 // ps: LMAX * 4 floats of this wave's LDS scratch; gws: the pool's head-gate weights [4][ITER * 64] float4 staged in LDS (norm gamma folded,
 // columns past D zero); store(h, c4, value): the gated mix of head h, features 4 c4 .. 4 c4 + 3 of row m.
-template <int ITER, class Store>
+// DEEP: key rows requested in batches of 8 and hidden rows 3 ahead (instead of one load per iteration / one row ahead) — for callers that run
+// few waves per SIMD (the per-frame fused kernel: 2), where a row is otherwise 2 L dependent memory round trips; with 3.5 waves per SIMD the
+// stand-alone kernel is bandwidth-bound and the deeper form measured 5 % slower there.
+template <int ITER, bool DEEP = false, class Store>
 __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int lane, float* ps, const f32x4* gws, Store store) {
     constexpr int PH = 4;
     const int L = p.L, D = p.D;
@@ -28,14 +31,24 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
 #pragma unroll
     for (int e = 0; e < 4; ++e) g4[e] = (g4[e] + 1.f) * 8.f;
     float mxl = -FLT_MAX;
-    for (int l = 0; l < L; ++l) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
-        const float nrm = sqrtf(row_sum16(kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3]));
-        const float inv = 1.f / fmaxf(nrm, 1e-12f);
-        const float sc = row_sum16(q4[0] * (kv[0] * inv * g4[0]) + q4[1] * (kv[1] * inv * g4[1]) +
-                                   q4[2] * (kv[2] * inv * g4[2]) + q4[3] * (kv[3] * inv * g4[3])) * 0.125f;
-        mxl = fmaxf(mxl, sc);
-        if ((lane & 15) == 0) ps[l * PH + hh] = sc;
+    constexpr int KB = DEEP ? 8 : 1;
+    for (int l0 = 0; l0 < L; l0 += KB) {
+        f32x4 kb[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            kb[j] = l0 + j < L ? *reinterpret_cast<const f32x4*>(p.k + ((int64_t)(l0 + j) * p.M + m) * p.ldk + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int l = l0 + j;
+            if (l >= L) break;
+            const f32x4 kv = kb[j];
+            const float nrm = sqrtf(row_sum16(kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2] + kv[3] * kv[3]));
+            const float inv = 1.f / fmaxf(nrm, 1e-12f);
+            const float sc = row_sum16(q4[0] * (kv[0] * inv * g4[0]) + q4[1] * (kv[1] * inv * g4[1]) +
+                                       q4[2] * (kv[2] * inv * g4[2]) + q4[3] * (kv[3] * inv * g4[3])) * 0.125f;
+            mxl = fmaxf(mxl, sc);
+            if ((lane & 15) == 0) ps[l * PH + hh] = sc;
+        }
     }
     float mx[PH];
 #pragma unroll
@@ -54,8 +67,9 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
     for (int h = 0; h < PH; ++h)
 #pragma unroll
         for (int i = 0; i < ITER; ++i) acc[h][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // hidden rows are software-pipelined one ahead: the next row's loads are in flight while this row is reduced / mixed
-    f32x4 vn[ITER];
+    // hidden rows are software-pipelined RD ahead: the loads of the next RD rows are in flight while this row is reduced / mixed
+    constexpr int RD = DEEP ? 3 : 1;
+    f32x4 vn[RD][ITER];
     auto load_row = [&](int l, f32x4 (&dst)[ITER]) {
         const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)l * p.M + m) * D);
 #pragma unroll
@@ -64,30 +78,37 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
             dst[i] = c4 < nf4 ? hr[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    load_row(0, vn);
-    for (int l = 0; l < L; ++l) {
-        f32x4 v[ITER];
-        float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            v[i] = vn[i];
-            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-        }
-        if (l + 1 < L) load_row(l + 1, vn);
-        const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
+    for (int j = 0; j < RD; ++j)
+        if (j < L) load_row(j, vn[j]);
+    for (int l0 = 0; l0 < L; l0 += RD) {
 #pragma unroll
-        for (int h = 0; h < PH; ++h) {
-            const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * rstd;
+        for (int j = 0; j < RD; ++j) {
+            const int l = l0 + j;
+            if (l >= L) break;
+            f32x4 v[ITER];
+            float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
-        }
-        if (l == L - 1 && x_is_last_hidden) {
+            for (int i = 0; i < ITER; ++i) {
+                v[i] = vn[j][i];
+                ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            }
+            if (l + RD < L) load_row(l + RD, vn[j]);
+            const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
 #pragma unroll
             for (int h = 0; h < PH; ++h) {
-                float d = 0.f;
+                const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * rstd;
 #pragma unroll
-                for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += v[i][0] * g[0] + v[i][1] * g[1] + v[i][2] * g[2] + v[i][3] * g[3]; }
-                glog[h] = wave_sum(d) * rstd;
+                for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
+            }
+            if (l == L - 1 && x_is_last_hidden) {
+#pragma unroll
+                for (int h = 0; h < PH; ++h) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int i = 0; i < ITER; ++i) { const f32x4 g = gws[h * (ITER * 64) + lane + 64 * i]; d += v[i][0] * g[0] + v[i][1] * g[1] + v[i][2] * g[2] + v[i][3] * g[3]; }
+                    glog[h] = wave_sum(d) * rstd;
+                }
             }
         }
     }
