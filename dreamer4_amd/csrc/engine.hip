@@ -599,7 +599,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
         // D4_FRAME_FUSED=2: the mix stays its own kernel and only the tail is fused
         if (S > 0 && M % S == 0 && !e->pv_t.empty() && (!t_bf16 || t_bf16->split) && frame_pool_tail_applicable(M / S, S, D, c.pool_heads)) {
-            static const bool tail_only = getenv("D4_FRAME_FUSED") && atoi(getenv("D4_FRAME_FUSED")) == 2;
+            const bool tail_only = frame_fused_mode() == 2;
             if (!tail_only) return frame_pool(pm, e->pv_t[p], e->po_t[p], M / S, S, x, D, y, D, y_compact, D, e->keep_lo, e->keep_hi, has_agent, s);
             if ((rc = pool_mix(pm, s))) return rc;
             return frame_pool_tail(e->pool_u, e->pv_t[p], e->po_t[p], M / S, S, D, c.pool_heads, x, D, y, D, y_compact, D, e->keep_lo, e->keep_hi, has_agent, s);
@@ -1347,6 +1347,8 @@ int d4_profile_glue_read(double* ms, double* bytes, int64_t* count, int nclass) 
 int d4_profile_glue_classes(void) { return d4::GL_N; }
 int d4_profile_glue_read_flops(double* flops, int nclass) { return d4::glue_profile_read_flops(flops, nclass); }
 const char* d4_profile_glue_class_name(int c) { return d4::glue_class_name(c); }
+int d4_frame_fused_set(int mode) { return d4::frame_fused_set(mode); }
+
 int d4_gemm_force_config(int id) {
     if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile configuration c of the split-operand fp32 family (gemm_x3.hip)
     if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1);

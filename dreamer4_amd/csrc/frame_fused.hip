@@ -238,10 +238,13 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
-static bool frame_fused_on() {
-    static const bool on = !(getenv("D4_FRAME_FUSED") && atoi(getenv("D4_FRAME_FUSED")) == 0);
-    return on;
+static int g_frame_fused = -1;         // -1: from the environment (D4_FRAME_FUSED, default 1); 0 off; 1 on; 2 tails only (the pool mix stays its own kernel)
+int frame_fused_mode() {
+    if (g_frame_fused < 0) g_frame_fused = getenv("D4_FRAME_FUSED") ? atoi(getenv("D4_FRAME_FUSED")) : 1;
+    return g_frame_fused;
 }
+int frame_fused_set(int mode) { const int old = frame_fused_mode(); g_frame_fused = mode; return old; }
+static bool frame_fused_on() { return frame_fused_mode() != 0; }
 
 // by shape only: head dim 64 x 8 heads, <= 16 tokens, at least 3/4 of the CUs get a frame (one workgroup per frame: fewer frames leave CUs
 // idle and the tiled kernels win), no more than four rounds of frames

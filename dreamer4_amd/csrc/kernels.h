@@ -133,6 +133,8 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream);
 // W [N][K] -> Wt [N / 16][K / 4][16][4]: the weight image the per-frame kernels stream (a 16-row tile is one contiguous run)
 int tile16_weights(const float* W, int ldw, float* Wt, int N, int K, hipStream_t s);
 bool frame_fused_frames_ok(int frames);
+int frame_fused_mode();                 // 0 off, 1 on (default), 2 tails only
+int frame_fused_set(int mode);          // test hook; returns the previous mode
 // within-frame attention -> output projection + residual (+ row-compacted copy), one workgroup per frame
 bool frame_attn_out_applicable(const SmallAttnArgs& sa, int D);
 int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const float* resid, int ldr, float* out, int ldo, float* c2, int ldc2, int c2_lo,

@@ -249,6 +249,9 @@ const char* d4_profile_glue_class_name(int c);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
  * split-operand fp32 family (gemm_x3.hip).
  * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
+/* Test hook for the per-frame fused block tails (csrc/frame_fused.hip; default from D4_FRAME_FUSED, 1): 0 separate kernels, 1 fused, 2 fused tails with the
+ * pool mix as its own kernel.  Returns the previous mode.  Which path runs is otherwise a rule on the call's shape. */
+int d4_frame_fused_set(int mode);
 int d4_gemm_force_config(int id);
 
 /* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */

@@ -343,6 +343,31 @@ def test_full_size_properties_at_baseline_batch():
     close(c.latents, a.latents[100:104], atol=1e-5); close(c.values, a.values[100:104], atol=1e-5)
 
 
+def test_per_frame_fused_block_tails_equal_the_separate_kernels():
+    """frame_fused.hip (within-frame attention -> output projection, attention-pool mix -> value / output projections, one workgroup per frame) is
+    taken by rule at >= 192 frames: the same rollout with the fused tails (mode 1), with the pool mix kept as its own kernel (2) and with the
+    separate kernels (0) agrees to fp32 summation order, and samples the same actions."""
+    from dreamer4_amd import DynamicsWorldModel, _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+    cfg = oracle_config(m)
+    B, T = 192, 3
+    nz = make_noise(cfg, T, B, 5)
+    outs = {}
+    prev = lib.d4_frame_fused_set(0)
+    try:
+        for mode in (0, 1, 2):
+            lib.d4_frame_fused_set(mode)
+            outs[mode] = m.generate(T, batch_size=B, return_for_policy_optimization=True, noise=nz)
+    finally:
+        lib.d4_frame_fused_set(prev)
+    for mode in (1, 2):
+        assert torch.equal(outs[mode].actions.discrete, outs[0].actions.discrete)
+        close(outs[mode].latents, outs[0].latents, atol=1e-5); close(outs[mode].agent_embed, outs[0].agent_embed, atol=5e-5)
+        close(outs[mode].values, outs[0].values, atol=1e-5)
+
+
 def test_full_size_forward_at_baseline_batch_vs_oracle():
     """One trunk evaluation at BASELINE's B=256 (M = 3840 token rows): this is the shape at which the GEMM launcher
     switches to its large-tile configurations, so the oracle comparison has to run at this size too."""
