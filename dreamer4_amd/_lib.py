@@ -27,7 +27,7 @@ class Config(C.Structure):
         ('multi_token_pred_len', C.c_int32),
         ('policy_head_mlp_depth', C.c_int32), ('value_head_mlp_depth', C.c_int32),
         ('terminal_mlp_depth', C.c_int32), ('predict_terminals', C.c_int32),
-        ('reward_num_bins', C.c_int32), ('value_num_bins', C.c_int32), ('reward_encoder_type', C.c_int32), ('matmul_bf16', C.c_int32), ('head_mlp_recipe', C.c_int32),
+        ('reward_num_bins', C.c_int32), ('value_num_bins', C.c_int32), ('reward_encoder_type', C.c_int32), ('matmul_bf16', C.c_int32), ('head_mlp_recipe', C.c_int32), ('continuous_beta_param', C.c_int32),
         ('pool_heads', C.c_int32), ('pool_dim_head', C.c_int32),
         ('gae_discount_factor', C.c_float), ('gae_lambda', C.c_float), ('ppo_eps_clip', C.c_float),
         ('policy_entropy_weight', C.c_float), ('use_delight_gating', C.c_int32),

@@ -2,7 +2,9 @@
 // discrete_continuous_embed_readout.Readout + BetaDist, D4:1172-1196, 1379-1389, 1442-1452, 1491-1494).
 // The package is absent from the image; parameterisation, tempering and the injectable sampler follow the stand-in
 // oracle/shim/discrete_continuous_embed_readout (PARITY UNPINNED against the real package):
-//   alpha = softplus(raw0) + 1, beta = softplus(raw1) + 1 (unimodal); sample ~ Beta(1 + (alpha-1)/T, 1 + (beta-1)/T) as Ga / (Ga + Gb)
+//   alpha = link(raw0) + 1, beta = link(raw1) + 1 (unimodal: both >= 1); the link is a DESCRIPTOR (d4_config.continuous_beta_param),
+//   softplus by default and exp as the other published choice — a checkpoint of the real package that turns out to use the other
+//   link needs the constructor argument, not a kernel change.  sample ~ Beta(1 + (alpha-1)/T, 1 + (beta-1)/T) as Ga / (Ga + Gb)
 //   with Marsaglia-Tsang gammas whose rejection rounds consume injected (normal, uniform) pairs.
 #pragma once
 #include "common.h"
@@ -27,8 +29,10 @@ __device__ __forceinline__ float trigammaf(float x) {
     return r + i * (1.f + 0.5f * i + i2 * (1.f / 6.f - i2 * (1.f / 30.f - i2 * (1.f / 42.f))));
 }
 
-struct BetaAB { float a, b, da, db; };        // alpha, beta and d alpha / d raw0, d beta / d raw1 (= sigmoid(raw))
-__device__ __forceinline__ BetaAB beta_ab(float r0, float r1) {
+struct BetaAB { float a, b, da, db; };        // alpha, beta and d alpha / d raw0, d beta / d raw1
+// kind: D4_BETA_SOFTPLUS_P1 (0)  alpha = softplus(raw) + 1, d alpha = sigmoid(raw);  D4_BETA_EXP_P1 (1)  alpha = exp(raw) + 1, d alpha = exp(raw)
+__device__ __forceinline__ BetaAB beta_ab(float r0, float r1, int kind) {
+    if (kind == 1) { const float e0 = expf(r0), e1 = expf(r1); return BetaAB{e0 + 1.f, e1 + 1.f, e0, e1}; }
     return BetaAB{softplusf(r0) + 1.f, softplusf(r1) + 1.f, sigmoidf(r0), sigmoidf(r1)};
 }
 

@@ -611,7 +611,7 @@ __global__ void sample_kernel(SampleArgs p) {
     // continuous actions: Beta(alpha, beta) sample (tempered) from injected gamma noise + log-prob under the untempered head
     for (int c = 0; c < p.nc; ++c) {
         const float* raw = p.cont_params + (int64_t)b * p.ld_c + 2 * c;
-        const BetaAB ab = beta_ab(raw[0], raw[1]);
+        const BetaAB ab = beta_ab(raw[0], raw[1], p.beta_param);
         const float x = beta_sample(ab.a, ab.b, p.cont_temperature, p.beta_noise + ((int64_t)b * p.nc + c) * (4 * BETA_ROUNDS));
         p.actions_cont[(int64_t)b * p.actc_stride + c] = x;
         p.log_probs_cont[(int64_t)b * p.lpc_stride + c] = beta_log_prob(ab.a, ab.b, x);

@@ -1012,6 +1012,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->Mmax = e->Fr * e->S;
     D4_REQUIRE(c.reward_encoder_type == 0 || c.reward_encoder_type == 1, "unknown reward_encoder_type %d", c.reward_encoder_type);
     D4_REQUIRE(c.head_mlp_recipe == D4_MLP_PRE_RMS || c.head_mlp_recipe == D4_MLP_POST_LAYER, "unknown head_mlp_recipe %d", c.head_mlp_recipe);
+    D4_REQUIRE(c.continuous_beta_param == D4_BETA_SOFTPLUS_P1 || c.continuous_beta_param == D4_BETA_EXP_P1, "unknown continuous_beta_param %d", c.continuous_beta_param);
     d4::mlp_dims(e->policy, c.dim, 4 * c.dim, 4 * c.dim, c.policy_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->value, c.dim, 4 * c.dim, c.value_num_bins, c.value_head_mlp_depth, c.head_mlp_recipe);
     d4::mlp_dims(e->terminal, c.dim_latent, 4 * c.dim_latent, 1, c.terminal_mlp_depth, c.head_mlp_recipe);
@@ -1320,7 +1321,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                 sa.beta_noise = io->beta_noise + (size_t)f * B * nc * 4 * 6;
                 sa.actions_cont = io->actions_cont + (size_t)cur * nc; sa.actc_stride = T * nc;
                 sa.log_probs_cont = io->log_probs_cont + (size_t)f * nc; sa.lpc_stride = F * nc;
-                sa.cont_temperature = io->continuous_temperature;
+                sa.cont_temperature = io->continuous_temperature; sa.beta_param = e->c.continuous_beta_param;
             }
             if ((rc = d4::sample_actions_terminals(sa, s))) return rc;
         } else if (term_logit) {

@@ -244,6 +244,7 @@ struct SampleArgs {
     float* log_probs_cont = nullptr; int lpc_stride = 0;    // out [B][nc]
     int nc = 0;
     float cont_temperature = 1.f;
+    int beta_param = 0;                                     // d4_config.continuous_beta_param (beta.h)
 };
 int sample_actions_terminals(const SampleArgs& p, hipStream_t s);
 // tokenizer decoder glue: video <-> patch rows ('b c t (h p1) (w p2) <-> (b t h w) (p1 p2 c)', D4:3556, 3896), token packing, coordinate grid

@@ -124,6 +124,7 @@ struct PolicyLossArgs {
     const float* cparams; int ldc;
     const float* actions_cont; const float* old_lp_cont; const float* old_cparams;
     float* dcparams;                    // [R][ldc]
+    int beta_param;                     // d4_config.continuous_beta_param
     int nc;
     int R, na, A, objective, normalize, use_gate, reverse_kl;
     float eps, clip, ent_w, gate_temp, pmpo_alpha, kl_w;
@@ -163,7 +164,7 @@ __global__ void policy_loss_kernel(PolicyLossArgs p) {
     // continuous actions: log-prob of the stored action and entropy of each Beta join the same sums  D4:6090-6111
     for (int c = 0; c < p.nc; ++c) {
         const float* raw = p.cparams + (int64_t)r * p.ldc + 2 * c;
-        const BetaAB ab = beta_ab(raw[0], raw[1]);
+        const BetaAB ab = beta_ab(raw[0], raw[1], p.beta_param);
         lp += beta_log_prob(ab.a, ab.b, p.actions_cont[(int64_t)r * p.nc + c]);
         old += p.old_lp_cont[(int64_t)r * p.nc + c];
         ent += lbetaf(ab.a, ab.b) - (ab.a - 1.f) * digammaf(ab.a) - (ab.b - 1.f) * digammaf(ab.b) + (ab.a + ab.b - 2.f) * digammaf(ab.a + ab.b);
@@ -233,7 +234,7 @@ __global__ void policy_loss_kernel(PolicyLossArgs p) {
     // gradients wrt the raw Beta parameters: d lp, d(-H) and (pmpo) the KL against the behaviour parameters
     for (int c = 0; c < p.nc; ++c) {
         const float* raw = p.cparams + (int64_t)r * p.ldc + 2 * c;
-        const BetaAB ab = beta_ab(raw[0], raw[1]);
+        const BetaAB ab = beta_ab(raw[0], raw[1], p.beta_param);
         const float a = ab.a, b = ab.b, x = p.actions_cont[(int64_t)r * p.nc + c];
         const float psi_a = digammaf(a), psi_b = digammaf(b), psi_ab = digammaf(a + b);
         const float tri_ab = trigammaf(a + b);
@@ -244,7 +245,7 @@ __global__ void policy_loss_kernel(PolicyLossArgs p) {
         gb += p.ent_w * ((b - 1.f) * trigammaf(b) - (a + b - 2.f) * tri_ab);
         if (p.objective == 2 && p.kl_w > 0.f && p.old_cparams) {
             const float* oraw = p.old_cparams + ((int64_t)r * p.nc + c) * 2;
-            const BetaAB ob = beta_ab(oraw[0], oraw[1]);
+            const BetaAB ob = beta_ab(oraw[0], oraw[1], p.beta_param);
             const float a2 = ob.a, b2 = ob.b;
             float kl, ka, kb;
             if (p.reverse_kl) {
@@ -527,7 +528,7 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
         p.old_logits = io->old_action_logits; p.ldo = A; p.adv_raw = row_a; p.mask = mask_keep; p.scal = scal;
         p.action_sizes = e->action_sizes; p.dlogits = e->l_dlogits; p.row_pl = row_pl; p.row_ent = row_ent; p.row_aux = row_aux;
         p.cparams = e->l_cparams; p.ldc = Cpad; p.actions_cont = io->actions_cont; p.old_lp_cont = io->old_log_probs_cont;
-        p.old_cparams = io->old_cont_params; p.dcparams = e->l_dcparams; p.nc = nc;
+        p.old_cparams = io->old_cont_params; p.dcparams = e->l_dcparams; p.nc = nc; p.beta_param = e->c.continuous_beta_param;
         p.R = R; p.na = na; p.A = A; p.objective = io->objective; p.normalize = normalize;
         p.use_gate = io->use_delight_gating < 0 ? c.use_delight_gating : io->use_delight_gating;
         p.reverse_kl = c.pmpo_reverse_kl;

@@ -493,7 +493,7 @@ def hl_gauss_probs(values, vrange, num_bins, sigma_to_bin_ratio=2., eps=1e-10):
 
 
 def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_discrete_actions, reward_range, reward_num_bins,
-                          policy_head_mlp_depth, terminal_mlp_depth, head_mlp_recipe='pre_rms', gae_discount_factor=0.997,
+                          policy_head_mlp_depth, terminal_mlp_depth, head_mlp_recipe='pre_rms', continuous_beta_param='softplus_p1', gae_discount_factor=0.997,
                           hl_sigma_ratio=2., hl_eps=1e-10, rewards=None, discrete_actions=None, terminals=None, lens=None,
                           continuous_actions=None):
     """The agent-token losses of the training forward (dreamer4.py:7432-7598): multi-token-prediction reward cross entropy against HL-Gauss
@@ -522,14 +522,16 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
     if (discrete_actions is not None or continuous_actions is not None) and t > 1:
         pe = _head_mlp(W, 'policy_head.', agent_embed, policy_head_mlp_depth + 2, head_mlp_recipe)
     if continuous_actions is not None and t > 1:
-        # Beta log-likelihood (dreamer4.py:7566-7597); alpha = softplus(raw0) + 1, beta = softplus(raw1) + 1: the stand-in's parameterisation
+        # Beta log-likelihood (dreamer4.py:7566-7597); alpha = link(raw0) + 1, beta = link(raw1) + 1 with the link named by
+        # `continuous_beta_param` (world_model.BETA_PARAMS: the stand-in's softplus, or exp)
         padded = F.pad(continuous_actions, (0, 0, 1, 0), value=0.)
         tgt, mask = _mtp_targets(padded, mtp)
         tgt, mask = tgt[:, 1:].clamp(1e-5, 1. - 1e-5), mask[:, 1:]
         per = []
         for i in range(mtp):
             params = torch.einsum('...d,ndt->...nt', pe, W['action_embedder.continuous_action_unembed'][:, i])
-            a, b_ = F.softplus(params[..., 0]) + 1., F.softplus(params[..., 1]) + 1.
+            link = torch.exp if continuous_beta_param == 'exp_p1' else F.softplus
+            a, b_ = link(params[..., 0]) + 1., link(params[..., 1]) + 1.
             x = tgt[:, :, i]
             lp = (a - 1.) * torch.log(x) + (b_ - 1.) * torch.log1p(-x) + torch.lgamma(a + b_) - torch.lgamma(a) - torch.lgamma(b_)
             nl = (-lp).masked_fill(~mask[:, :, i, None], 0.)

@@ -66,6 +66,11 @@ def mlp_widths(dim_in, dim, dim_out, depth):
 #   'pre_rms'     RMSNorm(d_in) -> Linear -> SiLU, no activation after the last Linear      keys layers.{i}.0.weight | layers.{i}.1.{weight,bias}
 #   'post_layer'  Linear -> LayerNorm(d_out) -> SiLU, the last layer is a bare Linear       keys layers.{i}.0.{weight,bias} | layers.{i}.1.{weight,bias} ; last: layers.{i}.{weight,bias}
 MLP_RECIPES = dict(pre_rms=0, post_layer=1)
+# Link of the Beta policy head's raw outputs (discrete_continuous_embed_readout's BetaDist with unimodal=True, dreamer4.py:1172-1173):
+# alpha = link(raw0) + 1, beta = link(raw1) + 1.  The package is absent from the image (pip offline), so — like the MLP recipe — the
+# link is a descriptor every layer honours (kernels csrc/beta.h, oracle/restate.py, oracle/shim): the default is the stand-in's softplus;
+# a checkpoint trained with the other published choice needs `continuous_beta_param='exp_p1'`, not a kernel change.
+BETA_PARAMS = dict(softplus_p1=0, exp_p1=1)
 
 
 def mlp_param_specs(recipe, widths):
@@ -165,6 +170,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         normalize_advantages=None,
         policy_entropy_weight=.01,
         head_mlp_recipe='pre_rms',
+        continuous_beta_param='softplus_p1',
         matmul_dtype='fp32',
         use_loss_normalization=False,
         latent_flow_loss_weight=1.,
@@ -175,13 +181,17 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         continuous_action_loss_weight: float | list = 1.,
         **kwargs,
     ):
-        """`head_mlp_recipe` is not a reference argument: it names the layer recipe of x_mlps_pytorch's normed MLP (see MLP_RECIPES)."""
+        """`head_mlp_recipe` and `continuous_beta_param` are not reference arguments: they name the layer recipe of x_mlps_pytorch's normed
+        MLP (MLP_RECIPES) and the link of discrete_continuous_embed_readout's Beta head (BETA_PARAMS), both third-party and unpinned."""
         config = dict(locals())
         super().__init__()
         self._record_config(config)
         if head_mlp_recipe not in MLP_RECIPES:
             raise ValueError(f'head_mlp_recipe must be one of {sorted(MLP_RECIPES)}')
         self.head_mlp_recipe = head_mlp_recipe
+        if continuous_beta_param not in BETA_PARAMS:
+            raise ValueError(f'continuous_beta_param must be one of {sorted(BETA_PARAMS)}')
+        self.continuous_beta_param = continuous_beta_param
         # (not a reference argument) arithmetic of the trunk's GEMMs:
         #   'fp32' (default)  the reference's fp32; the wide projections (SiLU-GLU input, N >= 2048) run on the bf16 matrix cores with
         #                     every fp32 operand split exactly into three bf16 numbers and six products accumulated in fp32
@@ -460,6 +470,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         c.terminal_mlp_depth, c.predict_terminals = self.terminal_mlp_depth, int(self.predict_terminals)
         c.reward_num_bins, c.value_num_bins = self.reward_num_bins, self.value_num_bins
         c.head_mlp_recipe = MLP_RECIPES[self.head_mlp_recipe]
+        c.continuous_beta_param = BETA_PARAMS[self.continuous_beta_param]
         c.reward_encoder_type = int(self.reward_encoder_type == 'symexp_two_hot')
         c.matmul_bf16 = {'fp32': 2, 'fp32_mfma': 0, 'bf16': 1}[self.matmul_dtype]
         c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
@@ -758,7 +769,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         agent = trunk_ops.dynamics_agent_losses(
             W, agent_embed, lat, multi_token_pred_len=self.multi_token_pred_len, num_discrete_actions=tuple(self.num_discrete_actions),
             reward_range=self.reward_range, reward_num_bins=self.reward_num_bins, policy_head_mlp_depth=self.policy_head_mlp_depth,
-            terminal_mlp_depth=self.terminal_mlp_depth, head_mlp_recipe=self.head_mlp_recipe, gae_discount_factor=self.gae_discount_factor,
+            terminal_mlp_depth=self.terminal_mlp_depth, head_mlp_recipe=self.head_mlp_recipe, continuous_beta_param=self.continuous_beta_param, gae_discount_factor=self.gae_discount_factor,
             hl_sigma_ratio=self.hl_sigma_ratio, hl_eps=self.hl_eps, rewards=rew, discrete_actions=da, terminals=term,
             lens=lens.to(dev) if lens is not None else None, continuous_actions=ca)
         upd = self.training if update_loss_ema is None else bool(update_loss_ema)                           # dreamer4.py:7637-7654

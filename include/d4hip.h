@@ -37,6 +37,10 @@ extern "C" {
 #define D4_MODE_ENCODER 2
 #define D4_MLP_PRE_RMS 0        /* RMSNorm -> Linear -> SiLU                        (x_mlps_pytorch create_mlp: recipe unpinned) */
 #define D4_MLP_POST_LAYER 1     /* Linear -> LayerNorm -> SiLU, bare last Linear */
+/* Link of the Beta policy head's raw outputs (discrete_continuous_embed_readout BetaDist, unimodal=True at D4:1172-1173: alpha, beta >= 1).
+ * The package is absent from the image, so the link is a descriptor like the MLP recipe (csrc/beta.h). */
+#define D4_BETA_SOFTPLUS_P1 0   /* alpha = softplus(raw0) + 1, beta = softplus(raw1) + 1 */
+#define D4_BETA_EXP_P1 1        /* alpha = exp(raw0) + 1,      beta = exp(raw1) + 1 */
 
 /* Constructor arguments of DynamicsWorldModel (supported subset; names as D4:4662-4778). */
 typedef struct d4_config {
@@ -56,6 +60,7 @@ typedef struct d4_config {
                                                    csrc/gemm_x3.hip) — the Python mirror's default; 1: bf16 MFMA (bf16-rounded weights +
                                                    activations, fp32 accumulate, fp32 norms / softmax / residual stream) */
     int32_t head_mlp_recipe;                    /* D4_MLP_PRE_RMS / D4_MLP_POST_LAYER: layer recipe of the policy / value / terminal MLPs (engine.h) */
+    int32_t continuous_beta_param;              /* D4_BETA_SOFTPLUS_P1 / D4_BETA_EXP_P1: link of the Beta head's raw parameters (csrc/beta.h) */
     int32_t pool_heads, pool_dim_head;          /* AttentionPool defaults 4 x 64 (D4:2147-2148) */
     /* learn_from_experience hyper-parameters (D4:4731-4744) */
     float gae_discount_factor, gae_lambda, ppo_eps_clip, policy_entropy_weight;

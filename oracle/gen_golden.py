@@ -103,6 +103,9 @@ CFG_CONTONLY = dict(dim=16, dim_latent=4, num_latent_tokens=3, depth=2, time_blo
                     multi_token_pred_len=1, policy_head_mlp_depth=1, value_head_mlp_depth=1)
 
 
+CFG_BETAEXP = dict(CFG_CONTONLY, num_discrete_actions=(3,), num_continuous_actions=3, continuous_beta_param='exp_p1')
+
+
 def fixture_config():
     return Config(**CFG)
 
@@ -287,6 +290,40 @@ def gen_continuous():
     out['env_beta_margin'] = np.array(worst)
     np.savez(os.path.join(OUT, 'continuous.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
     print('continuous margins', out['cached_margin'], out['cached_beta_margin'], out['only_beta_margin'], out['env_beta_margin'], 'lens', out['cached_lens'], out['only_lens'])
+
+
+def gen_beta_exp():
+    """beta_exp.npz / weights_beta_exp.npz: the Beta head with the OTHER link of its raw parameters (alpha = exp(raw) + 1; stand-in switch
+    BETA_PARAM = 'exp_p1'): rollout with tempered continuous sampling, ppo / pmpo losses and head gradients (entropy bonus and the
+    Beta KL of pmpo are the terms whose derivative changes with the link)."""
+    from oracle import restate
+    cfg = Config(**CFG_BETAEXP)
+    m = build_reference_model(cfg, seed=37)
+    with torch.no_grad():
+        m.action_embedder.discrete_action_unembed.mul_(0.3)
+    W = weights_of(m)
+    save_weights('weights_beta_exp.npz', W, CFG_BETAEXP)
+    out = {}
+
+    def beta_margin(e, nz, temperature):
+        F = e.old_action_unembeds.continuous.shape[1]
+        return restate.beta_accept_margin(e.old_action_unembeds.continuous, nz['beta'][:F].transpose(0, 1), temperature, 'exp_p1')
+
+    for seed in range(941, 990):
+        nz = make_noise(cfg, 5, 3, seed)
+        with injected(nz):
+            e = m.generate(5, batch_size=3, return_for_policy_optimization=True, continuous_temperature=0.8)
+        if beta_margin(e, nz, 0.8) >= 2e-3 and min_margin(e, nz, cfg) >= 1e-2 and int(e.lens.min()) >= 2:
+            break
+    exp_dict('cached_', e, out); noise_dict('cached_', nz, out)
+    out['cached_seed'] = np.array(seed)
+    out['cached_margin'] = np.array(min_margin(e, nz, cfg))
+    out['cached_beta_margin'] = np.array(beta_margin(e, nz, 0.8))
+    learn_into(out, m, e, ('ppo', 'pmpo'))
+    np.savez(os.path.join(OUT, 'beta_exp.npz'), **out, **{'meta_' + k: np.array(v) for k, v in META.items()})
+    a, b = restate.beta_alpha_beta(e.old_action_unembeds.continuous, 'exp_p1')
+    print('beta_exp margins', out['cached_margin'], out['cached_beta_margin'], 'lens', out['cached_lens'], 'alpha range', float(a.min()), float(a.max()),
+          'ppo', out['ppo_policy_loss'], 'pmpo', out['pmpo_policy_loss'])
 
 
 CFG_DECODE = dict(dim=32, dim_latent=8, patch_size=4, image_height=16, image_width=24, num_latent_tokens=6, decoder_depth=3, time_block_every=2,
@@ -629,7 +666,7 @@ def gen_learn_full():
     print('learn_full margin', out['exp_margin'], 'lens', out['exp_lens'])
 
 
-EXTRA = dict(learn_full=gen_learn_full, postln=gen_postln, continuous=gen_continuous, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent, train_cont=gen_train_cont)
+EXTRA = dict(learn_full=gen_learn_full, postln=gen_postln, continuous=gen_continuous, beta_exp=gen_beta_exp, decode=gen_decode, symexp=gen_symexp, encode=gen_encode, train=gen_train, train_agent=gen_train_agent, train_cont=gen_train_cont)
 
 
 def _record_third_party_sources():

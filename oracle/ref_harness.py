@@ -83,6 +83,11 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
     D4 = load_reference()
     from x_mlps_pytorch import normed_mlp
     normed_mlp.RECIPE = cfg.head_mlp_recipe             # layer recipe of the stand-in normed MLP (restored below)
+    from discrete_continuous_embed_readout import discrete_continuous_embed_readout as dcer_impl
+    if cfg.continuous_beta_param != 'softplus_p1':
+        assert hasattr(dcer_impl, 'BETA_PARAM'), 'continuous_beta_param is a switch of the stand-in package (oracle/shim), not of the real one'
+    if hasattr(dcer_impl, 'BETA_PARAM'):
+        dcer_impl.BETA_PARAM = cfg.continuous_beta_param    # link of the stand-in Beta head, read when the model builds its BetaDist
     torch.manual_seed(seed)
     m = D4.DynamicsWorldModel(
         num_continuous_actions=cfg.num_continuous_actions, reward_encoder_type=cfg.reward_encoder_type,
@@ -101,6 +106,8 @@ def build_reference_model(cfg: Config, seed=0, head_scale=True):
         pmpo_reverse_kl=cfg.pmpo_reverse_kl, pmpo_kl_div_loss_weight=cfg.pmpo_kl_div_loss_weight,
     ).eval()
     normed_mlp.RECIPE = 'pre_rms'
+    if hasattr(dcer_impl, 'BETA_PARAM'):
+        dcer_impl.BETA_PARAM = 'softplus_p1'
     post_ln = cfg.head_mlp_recipe == 'post_layer'
     if head_scale:
         with torch.no_grad():

@@ -81,6 +81,7 @@ class Config:
     num_continuous_actions: int = 0          # Beta policy head (continuous_dist_type='beta', D4:1131, 1172-1173)
     reward_encoder_type: str = 'hl_gauss'    # or 'symexp_two_hot' (D4:947-1040)
     head_mlp_recipe: str = 'pre_rms'         # layer recipe of x_mlps_pytorch's normed MLP: 'pre_rms' | 'post_layer' (see mlp())
+    continuous_beta_param: str = 'softplus_p1'   # link of the Beta head's raw parameters: 'softplus_p1' | 'exp_p1' (see beta_alpha_beta())
 
     def __post_init__(self):
         if isinstance(self.num_discrete_actions, int):
@@ -591,8 +592,12 @@ def policy_cont_params(cfg, W, policy_embed):
     return torch.einsum('...d,ndt->...nt', policy_embed, un)
 
 
-def beta_alpha_beta(params):
-    return F.softplus(params[..., 0]) + 1., F.softplus(params[..., 1]) + 1.      # unimodal=True  D4:1172-1173
+def beta_alpha_beta(params, kind='softplus_p1'):
+    """alpha, beta of BetaDist(unimodal=True) D4:1172-1173: link(raw) + 1.  The link lives in the third-party package (absent, unpinned):
+    a descriptor, like the MLP recipe — softplus (the stand-in's default) or exp."""
+    assert kind in ('softplus_p1', 'exp_p1'), kind
+    link = torch.exp if kind == 'exp_p1' else F.softplus
+    return link(params[..., 0]) + 1., link(params[..., 1]) + 1.
 
 
 def gamma_from_noise(shape_param, noise):
@@ -613,10 +618,10 @@ def gamma_from_noise(shape_param, noise):
     return out.clamp(min=1e-30)
 
 
-def beta_accept_margin(params, noise, temperature=1.):
+def beta_accept_margin(params, noise, temperature=1., kind='softplus_p1'):
     """Smallest |log u - bound| over the rejection rounds that decided a draw: exact agreement of the accept / reject decisions
     between fp32 implementations is only well posed when this is comfortably above their rounding differences."""
-    a, b = beta_alpha_beta(params)
+    a, b = beta_alpha_beta(params, kind)
     t = max(float(temperature), 1e-10)
     best = float('inf')
     for shape, nz in ((1. + (a - 1.) / t, noise[..., 0, :, :]), (1. + (b - 1.) / t, noise[..., 1, :, :])):
@@ -635,30 +640,30 @@ def beta_accept_margin(params, noise, temperature=1.):
     return best
 
 
-def sample_continuous(params, noise, temperature=1.):
+def sample_continuous(params, noise, temperature=1., kind='softplus_p1'):
     """Readout.sample_continuous D4:1379-1383: Beta(1 + (alpha-1)/T, 1 + (beta-1)/T) as a ratio of gammas; noise (..., nc, 2, rounds, 2)."""
-    a, b = beta_alpha_beta(params)
+    a, b = beta_alpha_beta(params, kind)
     t = max(float(temperature), 1e-10)
     a, b = 1. + (a - 1.) / t, 1. + (b - 1.) / t
     ga, gb = gamma_from_noise(a, noise[..., 0, :, :]), gamma_from_noise(b, noise[..., 1, :, :])
     return ga / (ga + gb)
 
 
-def beta_log_prob(params, x):
-    a, b = beta_alpha_beta(params)
+def beta_log_prob(params, x, kind='softplus_p1'):
+    a, b = beta_alpha_beta(params, kind)
     return (a - 1.) * torch.log(x) + (b - 1.) * torch.log1p(-x) + torch.lgamma(a + b) - torch.lgamma(a) - torch.lgamma(b)
 
 
-def beta_entropy(params):
-    a, b = beta_alpha_beta(params)
+def beta_entropy(params, kind='softplus_p1'):
+    a, b = beta_alpha_beta(params, kind)
     lbeta = torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
     return lbeta - (a - 1.) * torch.digamma(a) - (b - 1.) * torch.digamma(b) + (a + b - 2.) * torch.digamma(a + b)
 
 
-def beta_kl(p_params, q_params):
+def beta_kl(p_params, q_params, kind='softplus_p1'):
     """KL(Beta_p || Beta_q)  (torch.distributions.kl._kl_beta_beta)."""
-    a1, b1 = beta_alpha_beta(p_params)
-    a2, b2 = beta_alpha_beta(q_params)
+    a1, b1 = beta_alpha_beta(p_params, kind)
+    a2, b2 = beta_alpha_beta(q_params, kind)
     lb = lambda a, b: torch.lgamma(a) + torch.lgamma(b) - torch.lgamma(a + b)
     return (lb(a2, b2) - lb(a1, b1) + (a1 - a2) * torch.digamma(a1) + (b1 - b2) * torch.digamma(b1)
             + (a2 - a1 + b2 - b1) * torch.digamma(a1 + b1))
@@ -719,7 +724,7 @@ def dynamics_agent_losses(cfg: Config, W, agent_embed, latents, rewards=None, ac
         per = []
         for i in range(mtp):
             params = torch.einsum('...d,ndt->...nt', pe, W['action_embedder.continuous_action_unembed'][:, i])
-            nl = (-beta_log_prob(params, tgt[:, :, i])).masked_fill(~mask[:, :, i, None], 0.)
+            nl = (-beta_log_prob(params, tgt[:, :, i], cfg.continuous_beta_param)).masked_fill(~mask[:, :, i, None], 0.)
             per.append(nl[lm].mean() if lm is not None else nl.mean())
         out['continuous_actions'] = torch.stack(per)
     if actions is not None and t > 1:
@@ -852,9 +857,9 @@ def generate(cfg: Config, W, time_steps, *, num_steps=4, batch_size=1, noise, ta
             log_probs.append(discrete_log_probs(cfg, logits, a))
         if nc > 0:
             cp = policy_cont_params(cfg, W, pe)                                    # b 1 nc 2
-            ca = sample_continuous(cp, noise['beta'][f][:, None], continuous_temperature)
+            ca = sample_continuous(cp, noise['beta'][f][:, None], continuous_temperature, cfg.continuous_beta_param)
             cont_actions = torch.cat((cont_actions, ca), dim=1)
-            cont_log_probs.append(beta_log_prob(cp, ca))
+            cont_log_probs.append(beta_log_prob(cp, ca, cfg.continuous_beta_param))
         values.append(bins_to_scalar(cfg, value_head_bins(cfg, W, one), cfg.value_range, cfg.value_num_bins))
 
         latents = torch.cat((latents, x), dim=1)
@@ -1055,7 +1060,7 @@ def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, 
         lps.append(dlp); ents.append(dent); olds.append(exp['log_probs'])
     if nc > 0:
         cparams = policy_cont_params(cfg, W, pe)
-        lps.append(beta_log_prob(cparams, exp['actions_cont'][:, -Tn:])); ents.append(beta_entropy(cparams)); olds.append(exp['log_probs_cont'])
+        lps.append(beta_log_prob(cparams, exp['actions_cont'][:, -Tn:], cfg.continuous_beta_param)); ents.append(beta_entropy(cparams, cfg.continuous_beta_param)); olds.append(exp['log_probs_cont'])
     lp = torch.cat(lps, dim=-1).sum(dim=-1)
     ent = torch.cat(ents, dim=-1)
     old_lp = torch.cat(olds, dim=-1).sum(dim=-1)
@@ -1096,7 +1101,7 @@ def learn_losses(cfg: Config, W, exp, objective='ppo', use_delight_gating=None, 
             if nc > 0:
                 new_p, old_p = cparams, exp['old_cont_params']
                 src, tgt = (old_p, new_p) if cfg.pmpo_reverse_kl else (new_p, old_p)
-                kl_loss = kl_loss + masked_mean(beta_kl(src, tgt).sum(dim=-1), mask)
+                kl_loss = kl_loss + masked_mean(beta_kl(src, tgt, cfg.continuous_beta_param).sum(dim=-1), mask)
             policy_loss = policy_loss + kl_loss * cfg.pmpo_kl_div_loss_weight
     else:
         raise ValueError(objective)

@@ -4,7 +4,9 @@ description of the package — a Beta policy head whose two raw outputs per acti
 adding 1 so that alpha, beta >= 1 — and from the reference's call sites (dreamer4.py:1172-1196, 1379-1389, 1442-1452,
 1491-1494, 4923, 5737).  What is ASSUMED, in one place each:
 
-  * parameterisation   alpha = softplus(raw[..., 0]) + (1 if unimodal else eps), beta likewise from raw[..., 1]
+  * parameterisation   alpha = link(raw[..., 0]) + (1 if unimodal else eps), beta likewise from raw[..., 1]; the link is the module
+                       switch BETA_PARAM — 'softplus_p1' (softplus, default) or 'exp_p1' (exp) — read when a BetaDist is built, the
+                       descriptor the restatement (Config.continuous_beta_param) and the kernels (d4_config.continuous_beta_param) share
   * sampling           a draw of Beta(alpha_T, beta_T), alpha_T = 1 + (alpha - 1) / T (the density raised to 1 / T and
                        renormalised), realised as Ga / (Ga + Gb) with Marsaglia-Tsang gammas — see `sample` for why
   * native range       (0, 1); `rescale` is the affine map between two ranges
@@ -15,6 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch.distributions import Beta
 
+BETA_PARAM = 'softplus_p1'      # link of the raw parameters; set by oracle/ref_harness.build_reference_model around construction
 GAMMA_ROUNDS = 6      # rejection rounds provided per gamma draw (acceptance >= 0.95 per round for shape >= 1)
 
 
@@ -54,10 +57,12 @@ def gamma_from_noise(shape_param, noise):
 class BetaDist:
     def __init__(self, unimodal=False, eps=1e-6):
         self.unimodal, self.eps = unimodal, eps
+        assert BETA_PARAM in ('softplus_p1', 'exp_p1')
+        self.link = torch.exp if BETA_PARAM == 'exp_p1' else F.softplus
 
     def alpha_beta(self, params):
         base = 1. if self.unimodal else self.eps
-        return F.softplus(params[..., 0]) + base, F.softplus(params[..., 1]) + base
+        return self.link(params[..., 0]) + base, self.link(params[..., 1]) + base
 
     def dist(self, params):
         return Beta(*self.alpha_beta(params))

@@ -20,6 +20,7 @@ def oracle_config(m) -> Config:
         pmpo_pos_to_neg_weight=m.pmpo_pos_to_neg_weight, pmpo_reverse_kl=m.pmpo_reverse_kl,
         pmpo_kl_div_loss_weight=m.pmpo_kl_div_loss_weight,
         num_continuous_actions=getattr(m, 'num_continuous_actions', 0), head_mlp_recipe=getattr(m, 'head_mlp_recipe', 'pre_rms'),
+        continuous_beta_param=getattr(m, 'continuous_beta_param', 'softplus_p1'),
         reward_encoder_type=getattr(m, 'reward_encoder_type', 'hl_gauss'),
     )
 
@@ -99,7 +100,7 @@ def golden_model(weights='weights.npz', **extra):
     if 'value_range' in kw:
         venc['reward_range'] = tuple(kw.pop('value_range'))
     kw['num_discrete_actions'] = tuple(kw['num_discrete_actions']) if isinstance(kw['num_discrete_actions'], (tuple, list)) else kw['num_discrete_actions']
-    for key in ('head_mlp_recipe', 'reward_encoder_type'):
+    for key in ('head_mlp_recipe', 'reward_encoder_type', 'continuous_beta_param'):
         if key in kw:
             kw[key] = str(kw[key])
     kw = {k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in kw.items()}
