@@ -126,6 +126,7 @@ SYMBOLS = {
     'd4_profile_glue_class_name': (C.c_char_p, [_I]),
     'd4_debug_buffer': (_I, [_P, C.c_char_p, C.POINTER(_P)]),
     'd4_gemm': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    'd4_gemm_tn': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, C.c_int64, _I, _I, _P]),
     'd4_gemm_pair': (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'd4_gemm_batched': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _L, _L, _L, _P]),
     'd4_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -56,6 +56,9 @@ static int gemm_b(const float* A, int lda, const float* W, int ldw, float* C, in
 // without it these GEMMs run on a quarter of the CUs and were half of a training step (tools/train_step_time.py).
 constexpr size_t DW_PART_FLOATS = (size_t)8 << 20;          // partial-product scratch per workspace (32 MB)
 static int gemm_dw(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* part, hipStream_t s) {
+    // operands read straight into the MFMA layout, k split inside the workgroup and over slices (gemm_tn.hip); the transposed-operand form of
+    // the general GEMM below remains for leading dimensions that are not multiples of 4
+    if (gemm_tn_applicable(A, lda, B, ldb, C, ldc, M, N, K)) return gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, part, part ? DW_PART_FLOATS : 0, s);
     const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
     int S = (int)((1024 + tiles - 1) / tiles);
     if (S > K / 256) S = K / 256;

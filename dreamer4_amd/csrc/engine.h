@@ -7,6 +7,7 @@
 #include <vector>
 
 namespace d4 {
+constexpr size_t L_DWPART_FLOATS = (size_t)8 << 20;   // learner: scratch for the k-slice partial products of the weight-gradient GEMMs (32 MB)
 
 struct Bound { const float* p; float* g; int64_t n; };
 
@@ -122,7 +123,7 @@ struct d4_engine {
     int* fstate;                           // device frame state {t0} read by the time-attention kernels under graph replay
     int64_t* tasks_dev;                    // engine-owned copy of the task ids (stable address for captured graphs)
     float* cache;
-    float *agent_c, *hbuf[2], *hnorm, *rlogits, *term_pool, *term_logit, *splitk;
+    float *agent_c, *hbuf[2], *hnorm, *rlogits, *term_pool, *term_logit, *splitk, *l_dwpart = nullptr;
 
     // ---- learner (workspace; sized by max_learn_rows)
     int LR = 0;

@@ -160,6 +160,7 @@ int engine_layout(d4_engine* e, bool assign) {
         // saved per layer: x (input), xhat (normalised * gamma input of the linear), z (pre-activation)
         e->l_save = fl(e->policy.save_floats(R) + e->value.save_floats(R));
         for (int i = 0; i < 4; ++i) e->l_tmp[i] = fl(R * maxdim);
+        e->l_dwpart = fl(L_DWPART_FLOATS);       // partial products of the weight-gradient GEMMs' k-slices (gemm_tn.hip)
         e->l_cparams = fl(R * (size_t)(2 * e->nc + 4)); e->l_dcparams = fl(R * (size_t)(2 * e->nc + 4)); e->l_cu_g = fl((size_t)(2 * e->nc + 4) * 4 * D);
         e->l_logits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
         e->l_dlogits = fl(R * (size_t)((e->A + 3) / 4 * 4 + 4));
@@ -1387,6 +1388,11 @@ int d4_gemm_pair(const float* A1, int lda1, const float* W1, float* C1, int ldc1
     d4::GemmArgs a{A1, lda1, W1, K, C1, ldc1, nullptr, nullptr, 0, M1, N1, K, flags, rms_eps};
     d4::GemmArgs b{A2, lda2, W2, K, C2, ldc2, nullptr, nullptr, 0, M2, N2, K, flags, rms_eps};
     return d4::gemm_pair(a, b, static_cast<hipStream_t>(stream));
+}
+
+int d4_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* part, int64_t part_floats,
+               int tile_n, int slices, void* stream) {
+    return d4::gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, part, (size_t)part_floats, static_cast<hipStream_t>(stream), tile_n, slices);
 }
 
 int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,

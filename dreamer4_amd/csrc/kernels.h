@@ -212,6 +212,11 @@ int euler_step(float* x, int ldx, const float* pred, int ldp, int B, int n_el, f
 int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
 // y[m][n] = act(sum_s part[s][m][n] + bias[n])   (split-K combine, fixed order)
 int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy, hipStream_t s);
+// weight-gradient GEMM C[M][N] = A^T B with A [K][lda], B [K][ldb] row-major (contraction over rows), operands read straight into the MFMA
+// layout (gemm_tn.hip); `part` = scratch for the k-slices' partial products (part_floats floats) or null; forced_* = 0: the shape rule
+bool gemm_tn_applicable(const float* A, int lda, const float* B, int ldb, const float* C, int ldc, int M, int N, int K);
+int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* part, size_t part_floats, hipStream_t s,
+            int forced_tn = 0, int forced_slices = 0);
 int prep_eval_inputs(int32_t* sig, int64_t* pact, const int64_t* actions_hist, int B, int Tq, int na, int frame_base,
                      int hist_stride, int sig_val, int ctx_sig, hipStream_t s, float* pcont = nullptr, const float* cont_hist = nullptr, int nc = 0);
 int fill_sig(int32_t* sig, int n, int value, hipStream_t s);

@@ -414,6 +414,13 @@ static inline dim3 grid1d(int64_t n) {
     return dim3((unsigned)g);
 }
 
+// dW[M][N] = A^T B over R rows (weight gradient of a head Linear)
+static int gemm_dw_l(d4_engine* e, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int R, hipStream_t s) {
+    if (gemm_tn_applicable(A, lda, B, ldb, C, ldc, M, N, R)) return gemm_tn(A, lda, B, ldb, C, ldc, M, N, R, e->l_dwpart, e->l_dwpart ? L_DWPART_FLOATS : 0, s);
+    GemmArgs g{A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, M, N, R, GEMM_TRANS_A | GEMM_TRANS_B, 0.f};
+    return gemm(g, s);
+}
+
 static int gemm_l(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K, int flags, hipStream_t s) {
     GemmArgs g{A, lda, W, ldw, C, ldc, nullptr, nullptr, 0, M, N, K, flags, 0.f};
     return gemm(g, s);
@@ -452,7 +459,7 @@ static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, co
         if ((rc = colsum(dzp, ldd, R, dout_i, m.db[i], s))) return rc;
         const float* lin_in = pre ? sxh[i] : sx[i];
         // dW[n][k] = sum_r dz[r][n] * lin_in[r][k]
-        if ((rc = gemm_l(dzp, ldd, lin_in, din, m.dw[i], din, dout_i, din, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        if ((rc = gemm_dw_l(e, dzp, ldd, lin_in, din, m.dw[i], din, dout_i, din, R, s))) return rc;
         if (!pre) {
             // dx[r][k] = sum_n dz[r][n] * W[n][k] is the previous layer's activation gradient directly
             if (i > 0 && (rc = gemm_l(dzp, ldd, m.w[i], din, dy, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
@@ -573,14 +580,14 @@ int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
         D4_REQUIRE(e->action_unembed_grad, "learner: discrete_action_unembed was bound without a gradient buffer");
         if ((rc = fill_f32(e->action_unembed_grad, 0.f, (int64_t)A * mtp4d, s))) return rc;
         // dU0[a][k] = sum_r dlogits[r][a] * pe[r][k]
-        if ((rc = gemm_l(e->l_dlogits, Apad, pe_saved, 4 * D, e->action_unembed_grad, mtp4d, A, 4 * D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        if ((rc = gemm_dw_l(e, e->l_dlogits, Apad, pe_saved, 4 * D, e->action_unembed_grad, mtp4d, A, 4 * D, R, s))) return rc;
         // dpe[r][k] = sum_a dlogits[r][a] * U0[a][k]      (K = Apad; pad rows of U0 are never read: mask K to A)
         if ((rc = gemm_l(e->l_dlogits, Apad, e->action_unembed, mtp4d, dpe, 4 * D, R, 4 * D, A, GEMM_TRANS_B, s))) return rc;
     }
     if (nc > 0) {
         D4_REQUIRE(e->cont_unembed_grad, "learner: continuous_action_unembed was bound without a gradient buffer");
         // d cu_w[j][k] = sum_r dcparams[r][j] * pe[r][k], scattered back into the [nc][mtp][4D][2] layout (other heads: zero)
-        if ((rc = gemm_l(e->l_dcparams, Cpad, pe_saved, 4 * D, e->l_cu_g, 4 * D, 2 * nc, 4 * D, R, GEMM_TRANS_A | GEMM_TRANS_B, s))) return rc;
+        if ((rc = gemm_dw_l(e, e->l_dcparams, Cpad, pe_saved, 4 * D, e->l_cu_g, 4 * D, 2 * nc, 4 * D, R, s))) return rc;
         if ((rc = cunembed_scatter_grad(e->l_cu_g, e->cont_unembed_grad, nc, c.multi_token_pred_len, 4 * D, s))) return rc;
         // dpe (+)= dcparams . cu_w
         if ((rc = gemm_l(e->l_dcparams, Cpad, e->cu_w, 4 * D, dpe, 4 * D, R, 4 * D, 2 * nc, GEMM_TRANS_B | (na > 0 ? GEMM_ACCUMULATE : 0), s))) return rc;

@@ -144,8 +144,14 @@ def linear_backward(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor) -> 
     dx, dw = torch.empty_like(x2), torch.empty_like(w)
     # dx[m][k] = sum_n dy[m][n] W[n][k]: "W(k, n)" read from W[n * K + k] -> TRANS_B
     _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(w), K, _lib.ptr(dx), K, None, None, 0, M, K, N, _lib.GEMM_TRANS_B, 0., _stream(x)))
-    # dw[n][k] = sum_m dy[m][n] x[m][k]: both operands indexed by the contraction first -> TRANS_A | TRANS_B
-    _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(x2), K, _lib.ptr(dw), K, None, None, 0, N, K, M, _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B, 0., _stream(x)))
+    # dw[n][k] = sum_m dy[m][n] x[m][k]: both operands indexed by the contraction first -> the weight-gradient kernel (d4_gemm_tn: operands
+    # straight into the MFMA layout, rows split into slices) or, for widths that are not multiples of 4, d4_gemm with TRANS_A | TRANS_B
+    if N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4:
+        part_floats = min(8 * N * K, 8 << 20) if M >= 512 else 0
+        part = torch.empty(part_floats, device=x.device) if part_floats else None
+        _lib.check(lib.d4_gemm_tn(_lib.ptr(dy2), N, _lib.ptr(x2), K, _lib.ptr(dw), K, N, K, M, _lib.ptr(part), part_floats, 0, 0, _stream(x)))
+    else:
+        _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(x2), K, _lib.ptr(dw), K, None, None, 0, N, K, M, _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B, 0., _stream(x)))
     return dx.view(x.shape), dw
 
 

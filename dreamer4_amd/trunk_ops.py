@@ -399,7 +399,7 @@ def world_model_prediction(W, noised_latents, signal_levels, step_sizes_log2, *,
     if has_actions:
         emb = None
         if discrete_actions is not None and discrete_actions.shape[1] > 0:
-            offs = torch.tensor([0, *torch.tensor(num_discrete_actions).cumsum(0)[:-1].tolist()], device=dev)
+            offs = _action_offsets(tuple(num_discrete_actions), dev)
             emb = W['action_embedder.discrete_action_embed.weight'][discrete_actions + offs].sum(dim=-2)
         if continuous_actions is not None and continuous_actions.shape[1] > 0:
             c = (W['action_embedder.continuous_action_embed.weight'] * continuous_actions[..., None]).sum(dim=-2)
@@ -419,6 +419,20 @@ def world_model_prediction(W, noised_latents, signal_levels, step_sizes_log2, *,
     if num_spatial_tokens != n:
         x = _lq_pool(W, 'to_latent_pred.1.', x)
     return torch.ops.d4hip.linear(x, W['to_latent_pred.2.weight'], None, None, 0, 0.), agent_embed
+
+
+_OFFSETS = {}
+
+
+def _action_offsets(sizes, dev):
+    """First embedding row of each discrete action type; kept per (sizes, device) so that a step uploads nothing (and can be captured)."""
+    key = (sizes, str(dev))
+    if key not in _OFFSETS:
+        acc, offs = 0, []
+        for n in sizes:
+            offs.append(acc); acc += n
+        _OFFSETS[key] = torch.tensor(offs, device=dev)
+    return _OFFSETS[key]
 
 
 def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shortcut_train, *, max_steps, return_agent_embed=False, lens=None, **model):

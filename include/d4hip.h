@@ -270,6 +270,12 @@ int d4_gemm(const float* A, int lda, const float* W, int ldw, float* C, int ldc,
  * d4_gemm calls; falls back to them when the grouped form does not apply. */
 int d4_gemm_pair(const float* A1, int lda1, const float* W1, float* C1, int ldc1, int M1, int N1, const float* A2, int lda2, const float* W2, float* C2,
                  int ldc2, int M2, int N2, int K, int flags, float rms_eps, void* stream);
+/* Gradient of a Linear's weight (backward of dreamer4.py:2079-2116, 1968-2075): C[M][N] = A^T B, A [K][lda] (the output gradient, M columns),
+ * B [K][ldb] (the layer input, N columns), both row-major with the contraction over their ROWS.  M, N, lda, ldb, ldc multiples of 4, 16-byte
+ * aligned operands.  `part` (part_floats floats, or NULL) holds the partial products when the rows are split into slices; tile_n / slices = 0
+ * take the shape rule (csrc/gemm_tn.hip), other values force the 64 x (64 tile_n) tile and the slice count (benchmarks).  Deterministic. */
+int d4_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* part, int64_t part_floats,
+               int tile_n, int slices, void* stream);
 /* strided-batch form (the AttentionPool's per-head value projection, D4:2143-2177): problem b reads A + b*strideA,
  * W + b*strideW and writes C (and R) + b*strideC   (strides in elements). */
 int d4_gemm_batched(const float* A, int lda, const float* W, int ldw, float* C, int ldc, const float* bias,

@@ -289,6 +289,38 @@ def test_gemm_pair_is_bit_identical_to_two_launches(lib, M1, M2, N1, N2, flags):
     assert torch.allclose(o2.double(), X @ W2.double().t(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('M,N,K,lda,ldb,ldc,slices', [(2736, 512, 3840, 2736, 512, 512, 0), (512, 1368, 3840, 512, 1368, 1368, 0), (260, 512, 1000, 264, 520, 512, 0),
+                                                      (4, 8, 5, 4, 8, 8, 0), (68, 132, 17, 68, 132, 140, 1), (512, 512, 4099, 512, 512, 512, 5),
+                                                      (64, 64, 16, 64, 64, 64, 0), (512, 32, 8192, 512, 32, 32, 0)])
+def test_weight_gradient_gemm_vs_float64_and_deterministic(lib, M, N, K, lda, ldb, ldc, slices):
+    """d4_gemm_tn: C = A^T B with the contraction over the operands' rows (the gradient of a Linear's weight), read straight into the MFMA
+    layout; ragged tiles, row counts that are not multiples of the 16-row step or the slice, padded leading dimensions, forced and ruled slice
+    counts.  Error against float64 <= 4e-7 of sum |a b| (fp32 accumulation), columns outside [M][N] untouched, two runs bit-identical."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    A = torch.randn(K, lda, device='cuda', generator=g); B = torch.randn(K, ldb, device='cuda', generator=g)
+    part = torch.empty(8 << 20, device='cuda')
+    outs = []
+    for _ in range(2):
+        C_ = torch.full((M, ldc), float('nan'), device='cuda')
+        _lib.check(lib.d4_gemm_tn(_lib.ptr(A), lda, _lib.ptr(B), ldb, _lib.ptr(C_), ldc, M, N, K, _lib.ptr(part), part.numel(), 0, slices, stream()))
+        outs.append(C_)
+    assert torch.equal(outs[0][:, :N], outs[1][:, :N])
+    assert ldc == N or torch.isnan(outs[0][:, N:]).all()
+    ref = A[:, :M].double().t() @ B[:, :N].double()
+    scale = A[:, :M].double().abs().t() @ B[:, :N].double().abs()
+    assert ((outs[0][:, :N].double() - ref).abs() / scale.clamp(min=1e-30)).max().item() <= 4e-7
+    # no scratch: one slice, same tolerance
+    C1 = torch.full((M, ldc), float('nan'), device='cuda')
+    _lib.check(lib.d4_gemm_tn(_lib.ptr(A), lda, _lib.ptr(B), ldb, _lib.ptr(C1), ldc, M, N, K, None, 0, 0, 0, stream()))
+    assert ((C1[:, :N].double() - ref).abs() / scale.clamp(min=1e-30)).max().item() <= 4e-7
+
+
+def test_weight_gradient_gemm_rejects_widths_that_are_not_multiples_of_4(lib):
+    A = torch.randn(16, 6, device='cuda'); C_ = torch.empty(6, 6, device='cuda')
+    with pytest.raises(_lib.D4Error, match='multiples of 4'):
+        _lib.check(lib.d4_gemm_tn(_lib.ptr(A), 6, _lib.ptr(A), 6, _lib.ptr(C_), 6, 6, 6, 16, None, 0, 0, 0, stream()))
+
+
 def test_gemm_rejects_misaligned_operands(lib):
     A = torch.randn(8, 34, device='cuda')
     with pytest.raises(_lib.D4Error, match='multiples of 4'):
