@@ -22,7 +22,9 @@ static constexpr float RMS_EPS = 1.1920928955078125e-07f;   // torch.finfo(float
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------ SiLU-GLU glue
-// hidden layout [rows][2 * Ip]: value half at column 0, gate half at column Ip (Ip = inner rounded up to 4; pad columns are zero)
+// hidden layout [rows][2 * Ip]: value half at column 0, gate half at column Ip (Ip = inner rounded up to 16, so that 2 Ip — the contraction
+// length of the input-gradient GEMM — is a multiple of 32; pad columns are zero)
+static inline int ff_ip(int inner) { return (inner + 15) / 16 * 16; }
 __global__ void swiglu_fwd_kernel(const float* h, float* u, int rows, int I, int Ip) {
     const int64_t tot = (int64_t)rows * Ip;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
@@ -75,12 +77,73 @@ static int gemm_dw(const float* A, int lda, const float* B, int ldb, float* C, i
     return splitk_reduce(part, full + (rem > 0), M, N, nullptr, 0, C, ldc, s);
 }
 
+// Input gradient dX[M][N] = dY[M][K] W[K][N] (W = the Linear's weight, row-major [out = K][in = N]): W's contraction index is its slow one.
+// The weight is transposed once per call into `wt` [N][K] (a few MB: microseconds) so that the product runs as the plain row-major form on the
+// LDS-DMA family (gemm2.hip) instead of the transposed-operand form of the first family (measured 95-105 vs 65-77 TF/s on these shapes).
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = t[tx][ty + 8 * i];
+    }
+}
+static int gemm_dx(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K, float* wt, hipStream_t s) {
+    static const bool on = !(getenv("D4_GEMM_DX_T") && atoi(getenv("D4_GEMM_DX_T")) == 0);
+    if (!on || !wt || K % 32 != 0 || ldy % 4 != 0 || M < 256) return gemm_b(dY, ldy, W, ldw, dX, ldx, nullptr, M, N, K, GEMM_TRANS_B, s);
+    hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, W, ldw, wt, K, K, N);
+    D4_LAUNCH_CHECK();
+    return gemm_b(dY, ldy, wt, K, dX, ldx, nullptr, M, N, K, 0, s);
+}
+
+// Several contiguous copies / zero fills in ONE launch (the concatenated weight images of a block and the pieces of their gradients: what
+// used to be a memset and four to six device-to-device copies per block and pass).  Segments must not overlap.
+struct MultiCopy {
+    static constexpr int MAX = 10;
+    float* dst[MAX]; const float* src[MAX]; int64_t n[MAX];       // src null: zero fill
+    int count = 0;
+    void add(float* d, const float* s, int64_t len) { if (len > 0) { dst[count] = d; src[count] = s; n[count] = len; ++count; } }
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopy mc) {
+    const int seg = blockIdx.y;
+    float* __restrict__ d = mc.dst[seg];
+    const float* __restrict__ s = mc.src[seg];
+    const int64_t n = mc.n[seg];
+    const bool vec = ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n4 = n / 4;
+        for (int64_t i = tid; i < n4; i += stride)
+            reinterpret_cast<float4*>(d)[i] = s ? reinterpret_cast<const float4*>(s)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t i = n4 * 4 + tid; i < n; i += stride) d[i] = s ? s[i] : 0.f;
+    } else {
+        for (int64_t i = tid; i < n; i += stride) d[i] = s ? s[i] : 0.f;
+    }
+}
+static int multi_copy(const MultiCopy& mc, hipStream_t s) {
+    if (mc.count == 0) return 0;
+    D4_REQUIRE(mc.count <= MultiCopy::MAX, "multi_copy: too many segments");
+    int64_t big = 0;
+    for (int i = 0; i < mc.count; ++i) big = mc.n[i] > big ? mc.n[i] : big;
+    const int bx = (int)((big / 4 + 255) / 256 < 1 ? 1 : ((big / 4 + 255) / 256 > 512 ? 512 : (big / 4 + 255) / 256));
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, mc.count), dim3(256), 0, s, mc);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 struct FfWs {            // workspace carve-up (floats); all leading dimensions are multiples of 4
-    float *xn, *w1p, *b1p, *w2p, *h, *u, *du, *dh, *dxn, *tg, *dw1p, *dw2p, *part;
+    float *xn, *w1p, *b1p, *w2p, *h, *u, *du, *dh, *dxn, *tg, *dw1p, *dw2p, *part, *wt;
     size_t total;
 };
 static FfWs ff_ws(float* base, int R, int D, int I) {
-    const size_t Ip = (size_t)(I + 3) / 4 * 4;
+    const size_t Ip = (size_t)ff_ip(I);
     FfWs w{};
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
@@ -88,6 +151,7 @@ static FfWs ff_ws(float* base, int R, int D, int I) {
     w.h = take((size_t)R * 2 * Ip); w.u = take((size_t)R * Ip); w.du = take((size_t)R * Ip); w.dh = take((size_t)R * 2 * Ip);
     w.dxn = take((size_t)R * D); w.tg = take((size_t)R * D); w.dw1p = take(2 * Ip * D); w.dw2p = take((size_t)D * Ip);
     w.part = take(DW_PART_FLOATS);
+    w.wt = take(2 * Ip * D);             // transposed weight image of the input-gradient GEMMs (gemm_dx)
     w.total = off;
     return w;
 }
@@ -95,14 +159,13 @@ static FfWs ff_ws(float* base, int R, int D, int I) {
 // padded copies of proj_in ([a rows | pad | g rows | pad]), its bias, and proj_out (columns padded), then the forward up to u
 static int ff_recompute(const FfWs& w, const float* x, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
                         int R, int D, int I, hipStream_t s) {
-    const int Ip = (I + 3) / 4 * 4;
+    const int Ip = ff_ip(I);
     int rc;
-    D4_HIP(hipMemsetAsync(w.w1p, 0, sizeof(float) * 2 * Ip * D, s));
-    D4_HIP(hipMemsetAsync(w.b1p, 0, sizeof(float) * 2 * Ip, s));
-    D4_HIP(hipMemcpyAsync(w.w1p, w_in, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.w1p + (size_t)Ip * D, w_in + (size_t)I * D, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.b1p, b_in, sizeof(float) * I, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.b1p + Ip, b_in + I, sizeof(float) * I, hipMemcpyDeviceToDevice, s));
+    MultiCopy mc;
+    mc.add(w.w1p, w_in, (int64_t)I * D); mc.add(w.w1p + (size_t)I * D, nullptr, (int64_t)(Ip - I) * D);
+    mc.add(w.w1p + (size_t)Ip * D, w_in + (size_t)I * D, (int64_t)I * D); mc.add(w.w1p + (size_t)(Ip + I) * D, nullptr, (int64_t)(Ip - I) * D);
+    mc.add(w.b1p, b_in, I); mc.add(w.b1p + I, nullptr, Ip - I); mc.add(w.b1p + Ip, b_in + I, I); mc.add(w.b1p + Ip + I, nullptr, Ip - I);
+    if ((rc = multi_copy(mc, s))) return rc;
     if ((rc = pad_cols(w_out, w.w2p, D, I, Ip, s))) return rc;
     if ((rc = rmsnorm_rows(x, D, norm_w, w.xn, D, R, D, RMS_EPS, s))) return rc;
     if ((rc = gemm_b(w.xn, D, w.w1p, D, w.h, 2 * Ip, w.b1p, R, 2 * Ip, D, 0, s))) return rc;
@@ -430,7 +493,7 @@ __global__ void zero_pad_cols_kernel(float* x, int rows, int ld, int c0, int c1)
 }
 
 struct AttnWs {
-    float *xn, *wcat, *bcat, *proj, *dproj, *d_o3, *o3, *dwcat, *tg, *dxn, *gpart, *part;
+    float *xn, *wcat, *bcat, *proj, *dproj, *d_o3, *o3, *dwcat, *tg, *dxn, *gpart, *part, *wt;
     size_t total;
     int P, hp4;
 };
@@ -438,13 +501,14 @@ static AttnWs attn_ws(float* base, int R, int F, int D, int heads, int dh) {
     AttnWs w{};
     const int hd = heads * dh;
     w.hp4 = (heads + 3) / 4 * 4;
-    w.P = 3 * hd + 2 * w.hp4;
+    w.P = (3 * hd + 2 * w.hp4 + 31) / 32 * 32;       // a multiple of 32: P is the contraction length of the input-gradient GEMM (gemm_dx)
     size_t off = 0;
     auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; };
     w.xn = take((size_t)R * D); w.wcat = take((size_t)w.P * D); w.bcat = take(w.P); w.proj = take((size_t)R * w.P); w.dproj = take((size_t)R * w.P);
     w.d_o3 = take((size_t)R * hd); w.o3 = take((size_t)R * hd); w.dwcat = take((size_t)w.P * D); w.tg = take((size_t)R * D); w.dxn = take((size_t)R * D);
     w.gpart = take((size_t)F * hd);
     w.part = take(DW_PART_FLOATS);
+    w.wt = take((size_t)w.P * D);
     w.total = off;
     return w;
 }
@@ -455,16 +519,16 @@ struct AttnParams { const float *norm_w, *wq, *wk, *wv, *wo, *wg, *wm, *bm, *gam
 static int attn_project(const AttnWs& w, const float* x, const AttnParams& prm, int R, int D, int heads, int dh, bool has_rv, hipStream_t s) {
     const int hd = heads * dh;
     int rc;
-    D4_HIP(hipMemsetAsync(w.wcat, 0, sizeof(float) * (size_t)w.P * D, s));
-    D4_HIP(hipMemsetAsync(w.bcat, 0, sizeof(float) * w.P, s));
-    const size_t blk = sizeof(float) * (size_t)hd * D;
-    D4_HIP(hipMemcpyAsync(w.wcat, prm.wq, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.wcat + (size_t)hd * D, prm.wk, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.wcat + (size_t)2 * hd * D, prm.wv, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.wcat + (size_t)3 * hd * D, prm.wg, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
-    if (has_rv) {
-        D4_HIP(hipMemcpyAsync(w.wcat + (size_t)(3 * hd + w.hp4) * D, prm.wm, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
-        D4_HIP(hipMemcpyAsync(w.bcat + 3 * hd + w.hp4, prm.bm, sizeof(float) * heads, hipMemcpyDeviceToDevice, s));
+    {   // rows of wcat: q | k | v | gates, pad to hp4 | mix (or zero), pad to P;  bcat: zero but for the mix bias
+        const int64_t blk = (int64_t)hd * D;
+        const int mix0 = 3 * hd + w.hp4;
+        MultiCopy mc;
+        mc.add(w.wcat, prm.wq, blk); mc.add(w.wcat + blk, prm.wk, blk); mc.add(w.wcat + 2 * blk, prm.wv, blk);
+        mc.add(w.wcat + 3 * blk, prm.wg, (int64_t)heads * D); mc.add(w.wcat + 3 * blk + (int64_t)heads * D, nullptr, (int64_t)(w.hp4 - heads) * D);
+        mc.add(w.wcat + (int64_t)mix0 * D, has_rv ? prm.wm : nullptr, (int64_t)heads * D);
+        mc.add(w.wcat + (int64_t)(mix0 + heads) * D, nullptr, (int64_t)(w.P - mix0 - heads) * D);
+        mc.add(w.bcat, nullptr, mix0); mc.add(w.bcat + mix0, has_rv ? prm.bm : nullptr, heads); mc.add(w.bcat + mix0 + heads, nullptr, w.P - mix0 - heads);
+        if ((rc = multi_copy(mc, s))) return rc;
     }
     if ((rc = rmsnorm_rows(x, D, prm.norm_w, w.xn, D, R, D, RMS_EPS, s))) return rc;
     return gemm_b(w.xn, D, w.wcat, D, w.proj, w.P, w.bcat, R, w.P, D, 0, s);
@@ -486,7 +550,7 @@ int d4_ff_forward(const float* x, const float* norm_w, const float* w_in, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (rows == 0) return 0;
     const FfWs w = ff_ws(workspace, rows, dim, inner);
-    const int Ip = (inner + 3) / 4 * 4;
+    const int Ip = ff_ip(inner);
     int rc;
     if ((rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, rows, dim, inner, s))) return rc;
     return gemm_b(w.u, Ip, w.w2p, Ip, y, dim, b_out, rows, dim, Ip, 0, s);
@@ -502,7 +566,7 @@ static int ff_backward_impl(const float* x, const float* dy, const float* norm_w
     D4_REQUIRE(workspace_bytes >= d4_ff_workspace_bytes(rows, dim, inner), "d4_ff_backward: workspace too small");
     D4_REQUIRE(rows >= 1, "d4_ff_backward: no rows");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int R = rows, D = dim, I = inner, Ip = (inner + 3) / 4 * 4;
+    const int R = rows, D = dim, I = inner, Ip = ff_ip(inner);
     const FfWs w = ff_ws(workspace, R, D, I);
     int rc;
     if (!reuse && (rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, R, D, I, s))) return rc;
@@ -510,16 +574,19 @@ static int ff_backward_impl(const float* x, const float* dy, const float* norm_w
     if ((rc = colsum(dy, D, R, D, d_b_out, s))) return rc;
     if ((rc = gemm_dw(dy, D, w.u, Ip, w.dw2p, Ip, D, Ip, R, w.part, s))) return rc;                                    // dW2 = dy^T u
     if ((rc = copy_rows(w.dw2p, Ip, d_w_out, I, D, I, s))) return rc;
-    if ((rc = gemm_b(dy, D, w.w2p, Ip, w.du, Ip, nullptr, R, Ip, D, GEMM_TRANS_B, s))) return rc;                       // du = dy W2
+    if ((rc = gemm_dx(dy, D, w.w2p, Ip, w.du, Ip, R, Ip, D, w.wt, s))) return rc;                                        // du = dy W2
     hipLaunchKernelGGL(swiglu_bwd_kernel, grid_for((int64_t)R * Ip), dim3(256), 0, s, w.h, w.du, w.dh, R, I, Ip);
     D4_LAUNCH_CHECK();
     // h = xn W1^T + b1
     if ((rc = colsum(w.dh, 2 * Ip, R, I, d_b_in, s))) return rc;
     if ((rc = colsum(w.dh + Ip, 2 * Ip, R, I, d_b_in + I, s))) return rc;
     if ((rc = gemm_dw(w.dh, 2 * Ip, w.xn, D, w.dw1p, D, 2 * Ip, D, R, w.part, s))) return rc;                          // dW1 = dh^T xn
-    D4_HIP(hipMemcpyAsync(d_w_in, w.dw1p, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(d_w_in + (size_t)I * D, w.dw1p + (size_t)Ip * D, sizeof(float) * (size_t)I * D, hipMemcpyDeviceToDevice, s));
-    if ((rc = gemm_b(w.dh, 2 * Ip, w.w1p, D, w.dxn, D, nullptr, R, D, 2 * Ip, GEMM_TRANS_B, s))) return rc;            // dxn = dh W1
+    {
+        MultiCopy mc;
+        mc.add(d_w_in, w.dw1p, (int64_t)I * D); mc.add(d_w_in + (size_t)I * D, w.dw1p + (size_t)Ip * D, (int64_t)I * D);
+        if ((rc = multi_copy(mc, s))) return rc;
+    }
+    if ((rc = gemm_dx(w.dh, 2 * Ip, w.w1p, D, w.dxn, D, R, D, 2 * Ip, w.wt, s))) return rc;                             // dxn = dh W1
     // xn = rmsnorm(x) * gamma
     if ((rc = rmsnorm_bwd(x, w.dxn, norm_w, w.tg, dx, R, D, RMS_EPS, s))) return rc;
     return colsum(w.tg, D, R, D, d_norm_w, s);
@@ -593,35 +660,37 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
     const AttnWs w = attn_ws(workspace, R, g.groups, D, heads, dim_head);
     if (!reuse && (rc = attn_project(w, x, prm, R, D, heads, dim_head, has_rv, s))) return rc;     // reuse: the forward's xn / wcat / proj are still there
     // out = o3 Wo^T
-    if ((rc = gemm_b(dy, D, prm.wo, hd, w.d_o3, hd, nullptr, R, hd, D, GEMM_TRANS_B, s))) return rc;                    // d_o3 = dy Wo
+    if ((rc = gemm_dx(dy, D, prm.wo, hd, w.d_o3, hd, R, hd, D, w.wt, s))) return rc;                                     // d_o3 = dy Wo
     AttnBwdArgs a{w.proj, w.P, residual_values, prm.gamma, w.d_o3, w.o3, w.dproj, o.d_rv, w.gpart, g.groups, g.items, heads, w.hp4, softclamp, g.num_special, belief};
     set_geom(a, g);
     if ((rc = attn_core(a, dim_head, s))) return rc;
-    if (w.hp4 > heads) {           // the pad columns of the gate / mix logits carry no gradient
-        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + heads, 3 * hd + w.hp4);
-        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
-        D4_LAUNCH_CHECK();
-    }
+    // the pad columns of the gate / mix logits and of the row carry no gradient
+    if (w.hp4 > heads) hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.hp4 - heads)), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + heads, 3 * hd + w.hp4);
+    if (w.P > 3 * hd + w.hp4 + heads)
+        hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.P - (3 * hd + w.hp4 + heads))), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
+    D4_LAUNCH_CHECK();
     if ((rc = gemm_dw(dy, D, w.o3, hd, o.d_wo, hd, D, hd, R, w.part, s))) return rc;                                     // dWo = dy^T o3
     if ((rc = colsum(w.gpart, hd, g.groups, hd, o.d_gamma, s))) return rc;
     // projections: dW = dproj^T xn, dxn = dproj Wcat
     if ((rc = gemm_dw(w.dproj, w.P, w.xn, D, w.dwcat, D, w.P, D, R, w.part, s))) return rc;
-    const size_t blk = sizeof(float) * (size_t)hd * D;
-    D4_HIP(hipMemcpyAsync(o.d_wq, w.dwcat, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(o.d_wk, w.dwcat + (size_t)hd * D, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(o.d_wv, w.dwcat + (size_t)2 * hd * D, blk, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(o.d_wg, w.dwcat + (size_t)3 * hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
+    {
+        const int64_t blk = (int64_t)hd * D;
+        MultiCopy mc;
+        mc.add(o.d_wq, w.dwcat, blk); mc.add(o.d_wk, w.dwcat + blk, blk); mc.add(o.d_wv, w.dwcat + 2 * blk, blk);
+        mc.add(o.d_wg, w.dwcat + 3 * blk, (int64_t)heads * D);
+        if (has_rv) mc.add(o.d_wm, w.dwcat + (size_t)(3 * hd + w.hp4) * D, (int64_t)heads * D);
+        if ((rc = multi_copy(mc, s))) return rc;
+    }
     if (has_rv) {
-        D4_HIP(hipMemcpyAsync(o.d_wm, w.dwcat + (size_t)(3 * hd + w.hp4) * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
         if ((rc = colsum(w.dproj + 3 * hd + w.hp4, w.P, R, heads, o.d_bm, s))) return rc;
     }
-    if ((rc = gemm_b(w.dproj, w.P, w.wcat, D, w.dxn, D, nullptr, R, D, w.P, GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dx(w.dproj, w.P, w.wcat, D, w.dxn, D, R, D, w.P, w.wt, s))) return rc;
     if ((rc = rmsnorm_bwd(x, w.dxn, prm.norm_w, w.tg, o.dx, R, D, RMS_EPS, s))) return rc;
     return colsum(w.tg, D, R, D, o.d_norm_w, s);
 }
 
 struct XWs {
-    float *qn, *cn, *wqg, *wkv, *projq, *projk, *dprojq, *dprojk, *d_o3, *o3, *dwqg, *dwkv, *tg, *dqn, *tgc, *dcn, *gpart, *part;
+    float *qn, *cn, *wqg, *wkv, *projq, *projk, *dprojq, *dprojk, *d_o3, *o3, *dwqg, *dwkv, *tg, *dqn, *tgc, *dcn, *gpart, *part, *wt;
     size_t total; int Pq, Pk, hp4;
 };
 XWs x_ws(float* base, int Rq, int Rk, int G, int D, int Dc, int heads, int dh) {
@@ -635,6 +704,7 @@ XWs x_ws(float* base, int Rq, int Rk, int G, int D, int Dc, int heads, int dh) {
     w.d_o3 = take((size_t)Rq * hd); w.o3 = take((size_t)Rq * hd); w.dwqg = take((size_t)w.Pq * D); w.dwkv = take((size_t)w.Pk * Dc);
     w.tg = take((size_t)Rq * D); w.dqn = take((size_t)Rq * D); w.tgc = take((size_t)Rk * Dc); w.dcn = take((size_t)Rk * Dc); w.gpart = take((size_t)G * hd);
     w.part = take(DW_PART_FLOATS);
+    w.wt = take((size_t)(w.Pk > w.Pq ? w.Pk : w.Pq) * (D > Dc ? D : Dc));
     w.total = off;
     return w;
 }
@@ -644,11 +714,13 @@ struct XParams { const float *norm_w, *norm_ctx_w, *wq, *wk, *wv, *wo, *wg, *gam
 int x_project(const XWs& w, const float* q_tokens, const float* ctx, const XParams& prm, int Rq, int Rk, int D, int Dc, int heads, int dh, hipStream_t s) {
     const int hd = heads * dh;
     int rc;
-    D4_HIP(hipMemsetAsync(w.wqg, 0, sizeof(float) * (size_t)w.Pq * D, s));
-    D4_HIP(hipMemcpyAsync(w.wqg, prm.wq, sizeof(float) * (size_t)hd * D, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.wqg + (size_t)hd * D, prm.wg, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.wkv, prm.wk, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(w.wkv + (size_t)hd * Dc, prm.wv, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
+    {
+        MultiCopy mc;
+        mc.add(w.wqg, prm.wq, (int64_t)hd * D); mc.add(w.wqg + (size_t)hd * D, prm.wg, (int64_t)heads * D);
+        mc.add(w.wqg + (size_t)(hd + heads) * D, nullptr, (int64_t)(w.Pq - hd - heads) * D);
+        mc.add(w.wkv, prm.wk, (int64_t)hd * Dc); mc.add(w.wkv + (size_t)hd * Dc, prm.wv, (int64_t)hd * Dc);
+        if ((rc = multi_copy(mc, s))) return rc;
+    }
     if ((rc = rmsnorm_rows(q_tokens, D, prm.norm_w, w.qn, D, Rq, D, RMS_EPS, s))) return rc;
     if (prm.norm_ctx_w) { if ((rc = rmsnorm_rows(ctx, Dc, prm.norm_ctx_w, w.cn, Dc, Rk, Dc, RMS_EPS, s))) return rc; }
     else if ((rc = copy_rows(ctx, Dc, w.cn, Dc, Rk, Dc, s))) return rc;
@@ -705,7 +777,7 @@ static int cross_attn_backward_impl(const float* q_tokens, const float* ctx, con
     const XWs w = x_ws(workspace, Rq, Rk, groups, D, Dc, heads, dim_head);
     const XParams prm{norm_w, norm_ctx_w, wq, wk, wv, wo, w_gates, k_gamma};
     if (!reuse && (rc = x_project(w, q_tokens, ctx, prm, Rq, Rk, D, Dc, heads, dim_head, s))) return rc;
-    if ((rc = gemm_b(dy, D, wo, hd, w.d_o3, hd, nullptr, Rq, hd, D, GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dx(dy, D, wo, hd, w.d_o3, hd, Rq, hd, D, w.wt, s))) return rc;
     XAttnArgs a{w.projq, w.Pq, w.projk, w.Pk, k_gamma, w.d_o3, w.o3, w.dprojq, w.dprojk, w.gpart, groups, nq, nk, heads, ctx_item_major, softclamp};
     if ((rc = xattn_core(a, dim_head, s))) return rc;
     if (w.hp4 > heads) {
@@ -716,21 +788,23 @@ static int cross_attn_backward_impl(const float* q_tokens, const float* ctx, con
     if ((rc = colsum(w.gpart, hd, groups, hd, d_k_gamma, s))) return rc;
     // query side
     if ((rc = gemm_dw(w.dprojq, w.Pq, w.qn, D, w.dwqg, D, w.Pq, D, Rq, w.part, s))) return rc;
-    D4_HIP(hipMemcpyAsync(d_wq, w.dwqg, sizeof(float) * (size_t)hd * D, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(d_w_gates, w.dwqg + (size_t)hd * D, sizeof(float) * (size_t)heads * D, hipMemcpyDeviceToDevice, s));
-    if ((rc = gemm_b(w.dprojq, w.Pq, w.wqg, D, w.dqn, D, nullptr, Rq, D, w.Pq, GEMM_TRANS_B, s))) return rc;
+    if ((rc = gemm_dx(w.dprojq, w.Pq, w.wqg, D, w.dqn, D, Rq, D, w.Pq, w.wt, s))) return rc;
     if ((rc = rmsnorm_bwd(q_tokens, w.dqn, norm_w, w.tg, d_q_tokens, Rq, D, RMS_EPS, s))) return rc;
     if ((rc = colsum(w.tg, D, Rq, D, d_norm_w, s))) return rc;
     // context side
     if ((rc = gemm_dw(w.dprojk, w.Pk, w.cn, Dc, w.dwkv, Dc, w.Pk, Dc, Rk, w.part, s))) return rc;
-    D4_HIP(hipMemcpyAsync(d_wk, w.dwkv, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
-    D4_HIP(hipMemcpyAsync(d_wv, w.dwkv + (size_t)hd * Dc, sizeof(float) * (size_t)hd * Dc, hipMemcpyDeviceToDevice, s));
+    {   // the pieces of both concatenated weight gradients in one launch
+        MultiCopy mc;
+        mc.add(d_wq, w.dwqg, (int64_t)hd * D); mc.add(d_w_gates, w.dwqg + (size_t)hd * D, (int64_t)heads * D);
+        mc.add(d_wk, w.dwkv, (int64_t)hd * Dc); mc.add(d_wv, w.dwkv + (size_t)hd * Dc, (int64_t)hd * Dc);
+        if ((rc = multi_copy(mc, s))) return rc;
+    }
     if (norm_ctx_w) {
-        if ((rc = gemm_b(w.dprojk, w.Pk, w.wkv, Dc, w.dcn, Dc, nullptr, Rk, Dc, w.Pk, GEMM_TRANS_B, s))) return rc;
+        if ((rc = gemm_dx(w.dprojk, w.Pk, w.wkv, Dc, w.dcn, Dc, Rk, Dc, w.Pk, w.wt, s))) return rc;
         if ((rc = rmsnorm_bwd(ctx, w.dcn, norm_ctx_w, w.tgc, d_ctx, Rk, Dc, RMS_EPS, s))) return rc;
         return colsum(w.tgc, Dc, Rk, Dc, d_norm_ctx_w, s);
     }
-    return gemm_b(w.dprojk, w.Pk, w.wkv, Dc, d_ctx, Dc, nullptr, Rk, Dc, w.Pk, GEMM_TRANS_B, s);
+    return gemm_dx(w.dprojk, w.Pk, w.wkv, Dc, d_ctx, Dc, Rk, Dc, w.Pk, w.wt, s);
 }
 
 #define D4_XBWD_PARAMS const float* q_tokens, const float* ctx, const float* dy, const float* norm_w, const float* norm_ctx_w, const float* wq,          \
