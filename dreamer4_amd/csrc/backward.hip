@@ -196,11 +196,13 @@ struct AttnBwdArgs {
 };
 
 constexpr int AB_S = 32, AB_LD = 65;
-template <int DH>
+// CAP: token capacity of the LDS arrays (16 or 32): at <= 16 tokens per group the block needs 27 KB instead of 60 KB of LDS, so five blocks
+// instead of two share a CU — the kernel is a chain of LDS reads and wave reductions, and the extra waves are what hides them
+template <int DH, int CAP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
-    __shared__ float qs[AB_S * AB_LD], kn[AB_S * AB_LD], kh[AB_S * AB_LD], vm[AB_S * AB_LD], dO[AB_S * AB_LD], dvm[AB_S * AB_LD];     // 6 x 8.3 KB
-    __shared__ float P[AB_S * (AB_S + 1)], dsm[AB_S * (AB_S + 1)];
-    __shared__ float kinv[AB_S], vinv[AB_S], mxs[AB_S], gts[AB_S];
+    __shared__ float qs[CAP * AB_LD], kn[CAP * AB_LD], kh[CAP * AB_LD], vm[CAP * AB_LD], dO[CAP * AB_LD], dvm[CAP * AB_LD];     // 6 x 8.3 KB
+    __shared__ float P[CAP * (CAP + 1)], dsm[CAP * (CAP + 1)];
+    __shared__ float kinv[CAP], vinv[CAP], mxs[CAP], gts[CAP];
     __shared__ float gpart[4][64];
     const int S = p.S, hd = p.heads * DH;
     const int f = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
         float dsim = pij * (dp - rowdot);
         if (p.softclamp > 0.f) dsim *= 1.f - th * th;
         dsim *= scale;
-        if (lane < S) { P[i * (AB_S + 1) + lane] = pij; dsm[i * (AB_S + 1) + lane] = dsim; }
+        if (lane < S) { P[i * (CAP + 1) + lane] = pij; dsm[i * (CAP + 1) + lane] = dsim; }
         // dq_i = sum_j dsim_ij kn_j
         float dq = 0.f;
         for (int j = 0; j < S; ++j) dq += __shfl(dsim, j) * kn[j * AB_LD + lane];
@@ -315,8 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
     for (int j = w; j < S; j += 4) {
         float dkn = 0.f, dv = dvm[j * AB_LD + lane];
         for (int i = 0; i < S; ++i) {
-            dkn += dsm[i * (AB_S + 1) + j] * qs[i * AB_LD + lane];
-            dv += P[i * (AB_S + 1) + j] * dO[i * AB_LD + lane];
+            dkn += dsm[i * (CAP + 1) + j] * qs[i * AB_LD + lane];
+            dv += P[i * (CAP + 1) + j] * dO[i * AB_LD + lane];
         }
         dkn = rot_t(dkn, j);
         const float khj = kh[j * AB_LD + lane];
@@ -345,9 +347,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
 
 static int attn_core(const AttnBwdArgs& a, int dh, hipStream_t s) {
     if (a.F * a.heads == 0) return 0;
-    if (dh == 64) hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(a.F * a.heads), dim3(256), 0, s, a);
-    else if (dh == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(a.F * a.heads), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(attn_bwd_kernel<16>, dim3(a.F * a.heads), dim3(256), 0, s, a);
+    const bool small = a.S <= 16;
+    if (dh == 64 && small) hipLaunchKernelGGL((attn_bwd_kernel<64, 16>), dim3(a.F * a.heads), dim3(256), 0, s, a);
+    else if (dh == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, 32>), dim3(a.F * a.heads), dim3(256), 0, s, a);
+    else if (dh == 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 32>), dim3(a.F * a.heads), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_bwd_kernel<16, 32>), dim3(a.F * a.heads), dim3(256), 0, s, a);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -802,7 +806,7 @@ static int cross_attn_backward_impl(const float* q_tokens, const float* ctx, con
     if (norm_ctx_w) {
         if ((rc = gemm_dx(w.dprojk, w.Pk, w.wkv, Dc, w.dcn, Dc, Rk, Dc, w.Pk, w.wt, s))) return rc;
         if ((rc = rmsnorm_bwd(ctx, w.dcn, norm_ctx_w, w.tgc, d_ctx, Rk, Dc, RMS_EPS, s))) return rc;
-        return colsum(w.tgc, Dc, Rk, Dc, d_norm_ctx_w, s);
+        return colsum(w.tgc, Dc, Rk, Dc, d_norm_ctx_w, s, w.part, DW_PART_FLOATS);
     }
     return gemm_dx(w.dprojk, w.Pk, w.wkv, Dc, d_ctx, Dc, Rk, Dc, w.Pk, w.wt, s);
 }

@@ -175,7 +175,7 @@ int swiglu_pack_rows(const float* W, const float* bias, const float* gamma, floa
                      int inner, int inner_pad, int K, hipStream_t s);
 int pad_cols(const float* W, float* out, int rows, int cols, int cols_pad, hipStream_t s);
 // learn.hip: out[c] = sum_r x[r][c] (fixed order); RMSNorm backward (tg = dxhat * x * rstd, column-summed by the caller -> dgamma)
-int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s);
+int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0);
 int rmsnorm_bwd(const float* x, const float* dxhat, const float* gamma, float* tg, float* dx, int rows, int d, float eps, hipStream_t s);
 int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int D, float eps, hipStream_t s);
 int layernorm_rows(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int D, float eps, int silu, hipStream_t s);
