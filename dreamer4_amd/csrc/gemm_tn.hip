@@ -174,4 +174,32 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
     return 0;
 }
 
+// Input gradient dX[M][N] = dY[M][K] W[K][N] (W = the Linear's weight, row-major [out = K][in = N]): W's contraction index is its slow one.
+// The weight is transposed once per call into `wt` [N][K] (a few MB: microseconds) so that the product runs as the plain row-major form on the
+// LDS-DMA family (gemm2.hip) instead of the transposed-operand form of the first family (measured 95-105 vs 65-77 TF/s on these shapes).
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = t[tx][ty + 8 * i];
+    }
+}
+int gemm_dx(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K, float* wt, hipStream_t s) {
+    static const bool on = !(getenv("D4_GEMM_DX_T") && atoi(getenv("D4_GEMM_DX_T")) == 0);
+    if (!on || !wt || K % 32 != 0 || ldy % 4 != 0 || M < 256) { GemmArgs g{dY, ldy, W, ldw, dX, ldx, nullptr, nullptr, 0, M, N, K, GEMM_TRANS_B, 0.f}; return gemm(g, s); }
+    hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, W, ldw, wt, K, K, N);
+    D4_LAUNCH_CHECK();
+    GemmArgs g{dY, ldy, wt, K, dX, ldx, nullptr, nullptr, 0, M, N, K, 0, 0.f};
+    return gemm(g, s);
+}
+
+
 }  // namespace d4

@@ -214,6 +214,9 @@ int silu_rows(const float* z, float* y, int64_t n, hipStream_t s);
 int splitk_reduce(const float* part, int S, int M, int N, const float* bias, int silu, float* y, int ldy, hipStream_t s);
 // weight-gradient GEMM C[M][N] = A^T B with A [K][lda], B [K][ldb] row-major (contraction over rows), operands read straight into the MFMA
 // layout (gemm_tn.hip); `part` = scratch for the k-slices' partial products (part_floats floats) or null; forced_* = 0: the shape rule
+// input gradient dX[M][N] = dY[M][K] W[K][N] (W: a Linear's weight [out = K][in = N]) through a transposed weight image `wt` (N * K floats scratch)
+// on the LDS-DMA family; falls back to the transposed-operand form of gemm() when wt is null, K % 32 != 0 or M < 256
+int gemm_dx(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K, float* wt, hipStream_t s);
 bool gemm_tn_applicable(const float* A, int lda, const float* B, int ldb, const float* C, int ldc, int M, int N, int K);
 int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, float* part, size_t part_floats, hipStream_t s,
             int forced_tn = 0, int forced_slices = 0);

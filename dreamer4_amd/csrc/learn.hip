@@ -475,18 +475,21 @@ static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, co
         }
         if ((rc = colsum(dzp, ldd, R, dout_i, m.db[i], s))) return rc;
         const float* lin_in = pre ? sxh[i] : sx[i];
+        // input gradients go through a transposed image of the weight (gemm_dx; scratch shared with the weight gradient's partial products,
+        // used one after the other on the stream)
+        float* wt = (e->l_dwpart && (size_t)dout_i * din <= L_DWPART_FLOATS) ? e->l_dwpart : nullptr;
         // dW[n][k] = sum_r dz[r][n] * lin_in[r][k]
         if ((rc = gemm_dw_l(e, dzp, ldd, lin_in, din, m.dw[i], din, dout_i, din, R, s))) return rc;
         if (!pre) {
             // dx[r][k] = sum_n dz[r][n] * W[n][k] is the previous layer's activation gradient directly
-            if (i > 0 && (rc = gemm_l(dzp, ldd, m.w[i], din, dy, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
-            if (i == 0 && dx0 && (rc = gemm_l(dzp, ldd, m.w[i], din, dx0, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
+            if (i > 0 && (rc = gemm_dx(dzp, ldd, m.w[i], din, dy, din, R, din, dout_i, wt, s))) return rc;
+            if (i == 0 && dx0 && (rc = gemm_dx(dzp, ldd, m.w[i], din, dx0, din, R, din, dout_i, wt, s))) return rc;
             cur = dy;
             continue;
         }
         D4_REQUIRE(m.dg[i], "learner: head parameters were bound without gradient buffers");
         // dxhat[r][k] = sum_n dz[r][n] * W[n][k]
-        if ((rc = gemm_l(dzp, ldd, m.w[i], din, dxh, din, R, din, dout_i, GEMM_TRANS_B, s))) return rc;
+        if ((rc = gemm_dx(dzp, ldd, m.w[i], din, dxh, din, R, din, dout_i, wt, s))) return rc;
         // through the RMSNorm; dy of the previous layer overwrites e->l_tmp[0]; tg reuses dz (dz is dead after the GEMMs)
         float* tg = dz;
         hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, sx[i], dxh, m.g[i], tg, i > 0 ? dy : dx0, R, din, RMS_EPS_L);
