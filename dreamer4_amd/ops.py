@@ -141,6 +141,10 @@ def linear_backward(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor) -> 
     K, N = x.shape[-1], weight.shape[0]
     x2, dy2, w = x.float().contiguous().view(-1, K), dy.float().contiguous().view(-1, N), weight.float().contiguous()
     M = x2.shape[0]
+    n_out = N
+    if N % 4:            # a head's last Linear (1 or a few outputs): zero-pad the output width to the kernels' 4-float granularity
+        pad = 4 - N % 4
+        dy2, w, N = torch.nn.functional.pad(dy2, (0, pad)), torch.nn.functional.pad(w, (0, 0, 0, pad)), N + pad
     dx, dw = torch.empty_like(x2), torch.empty_like(w)
     # dx[m][k] = sum_n dy[m][n] W[n][k]: "W(k, n)" read from W[n * K + k] -> TRANS_B
     _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(w), K, _lib.ptr(dx), K, None, None, 0, M, K, N, _lib.GEMM_TRANS_B, 0., _stream(x)))
@@ -152,7 +156,7 @@ def linear_backward(x: torch.Tensor, dy: torch.Tensor, weight: torch.Tensor) -> 
         _lib.check(lib.d4_gemm_tn(_lib.ptr(dy2), N, _lib.ptr(x2), K, _lib.ptr(dw), K, N, K, M, _lib.ptr(part), part_floats, 0, 0, _stream(x)))
     else:
         _lib.check(lib.d4_gemm(_lib.ptr(dy2), N, _lib.ptr(x2), K, _lib.ptr(dw), K, None, None, 0, N, K, M, _lib.GEMM_TRANS_A | _lib.GEMM_TRANS_B, 0., _stream(x)))
-    return dx.view(x.shape), dw
+    return dx.view(x.shape), (dw[:n_out].clone() if n_out != N else dw)
 
 
 @linear_backward.register_fake

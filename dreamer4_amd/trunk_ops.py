@@ -471,19 +471,21 @@ def dynamics_flow_losses(W, latents, noise, signal_levels, step_sizes_log2, shor
 
 # ------------------------------------------------------------------------------------------------ agent-token losses of the training forward
 def _head_mlp(W, pre, x, n_layers, recipe):
-    """The heads' normed MLP (x_mlps_pytorch.create_mlp stand-in): 'pre_rms' or 'post_layer'."""
+    """The heads' normed MLP (x_mlps_pytorch.create_mlp stand-in): 'pre_rms' or 'post_layer'.  Linear and RMSNorm are the
+    differentiable HIP operators (torch.ops.d4hip.linear / rmsnorm: d4_gemm, d4_gemm_tn, d4_rmsnorm_backward) — no vendor BLAS on the path."""
     from torch.nn import functional as F
     eps = torch.finfo(torch.float32).eps
+    lin = lambda t, w, b: torch.ops.d4hip.linear(t, w, b, None, 0, 0.)
     for i in range(n_layers):
         last = i == n_layers - 1
         if recipe == 'pre_rms':
-            x = F.linear(F.rms_norm(x, x.shape[-1:], W[f'{pre}layers.{i}.0.weight'], eps), W[f'{pre}layers.{i}.1.weight'], W[f'{pre}layers.{i}.1.bias'])
+            x = lin(torch.ops.d4hip.rmsnorm(x, W[f'{pre}layers.{i}.0.weight'], eps), W[f'{pre}layers.{i}.1.weight'], W[f'{pre}layers.{i}.1.bias'])
             if not last:
                 x = F.silu(x)
         elif last:
-            x = F.linear(x, W[f'{pre}layers.{i}.weight'], W[f'{pre}layers.{i}.bias'])
+            x = lin(x, W[f'{pre}layers.{i}.weight'], W[f'{pre}layers.{i}.bias'])
         else:
-            x = F.linear(x, W[f'{pre}layers.{i}.0.weight'], W[f'{pre}layers.{i}.0.bias'])
+            x = lin(x, W[f'{pre}layers.{i}.0.weight'], W[f'{pre}layers.{i}.0.bias'])
             x = F.silu(F.layer_norm(x, x.shape[-1:], W[f'{pre}layers.{i}.1.weight'], W[f'{pre}layers.{i}.1.bias'], 1e-5))
     return x
 

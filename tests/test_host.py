@@ -293,29 +293,3 @@ def test_loss_normalizer_state_and_beta_zero_property():
     assert torch.allclose(second, torch.ones(2))
     frozen = m._normalize_loss('flow_loss_normalizer', torch.tensor(2.), False)
     assert frozen.item() == 2. and m.flow_loss_normalizer.exp_avg_sq.item() == 1.
-
-
-@pytest.mark.parametrize('link', ['softplus_p1', 'exp_p1'])
-def test_beta_link_descriptor_in_the_training_forward_continuous_loss(link):
-    """The mirror's continuous behaviour-cloning term (dreamer4.py:7566-7597) honours `continuous_beta_param` like the kernels and the
-    oracle do; an unknown link is refused at construction."""
-    import dataclasses
-    from dreamer4_amd import trunk_ops
-    from oracle import restate
-    cfg, W = golden_oracle('weights_beta_exp.npz')
-    cfg = dataclasses.replace(cfg, continuous_beta_param=link)
-    g = torch.Generator().manual_seed(7)
-    b, t_ = 2, 5
-    agent = torch.randn(b, t_, cfg.dim, generator=g)
-    lat = torch.randn(b, t_, cfg.num_latent_tokens, cfg.dim_latent, generator=g)
-    ca = torch.rand(b, t_, cfg.num_continuous_actions, generator=g)
-    ref = restate.dynamics_agent_losses(cfg, W, agent, lat, cont_actions=ca)
-    out = trunk_ops.dynamics_agent_losses(
-        W, agent, lat, multi_token_pred_len=cfg.multi_token_pred_len, num_discrete_actions=tuple(cfg.num_discrete_actions), reward_range=cfg.reward_range,
-        reward_num_bins=cfg.reward_num_bins, policy_head_mlp_depth=cfg.policy_head_mlp_depth, terminal_mlp_depth=cfg.terminal_mlp_depth,
-        head_mlp_recipe=cfg.head_mlp_recipe, continuous_beta_param=link, continuous_actions=ca)
-    assert torch.allclose(out['continuous_actions'], ref['continuous_actions'], atol=1e-6, rtol=1e-5)
-    other = restate.dynamics_agent_losses(dataclasses.replace(cfg, continuous_beta_param='exp_p1' if link == 'softplus_p1' else 'softplus_p1'), W, agent, lat, cont_actions=ca)
-    assert (other['continuous_actions'] - ref['continuous_actions']).abs().max() > 1e-3
-    with pytest.raises(ValueError, match='continuous_beta_param'):
-        small_model(num_continuous_actions=2, continuous_beta_param='sigmoid')
