@@ -169,14 +169,16 @@ struct AttnBwdArgs {
     const float* inv_freq = nullptr;   // [DH / 2] rotary frequencies applied to q and k at position j (time attention), or null
 };
 
-constexpr int AB_S = 32, AB_LD = 65;
+constexpr int AB_S = 64, AB_LD = 65;           // items (tokens of a frame / frames of a trajectory) per group: <= 64 (a score row = one wavefront)
 // CAP: token capacity of the LDS arrays (16 or 32): at <= 16 tokens per group the block needs 27 KB instead of 60 KB of LDS, so five blocks
 // instead of two share a CU — the kernel is a chain of LDS reads and wave reductions, and the extra waves are what hides them
 template <int DH, int CAP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
-    __shared__ float qs[CAP * AB_LD], kn[CAP * AB_LD], kh[CAP * AB_LD], vm[CAP * AB_LD], dO[CAP * AB_LD], dvm[CAP * AB_LD];     // 6 x 8.3 KB
-    __shared__ float P[CAP * (CAP + 1)], dsm[CAP * (CAP + 1)];
-    __shared__ float kinv[CAP], vinv[CAP], mxs[CAP], gts[CAP];
+    extern __shared__ float ab_s[];             // dynamic: 27 KB (CAP 16), 60 KB (32), 134 KB (64: one block per CU)
+    float* qs = ab_s; float* kn = qs + CAP * AB_LD; float* kh = kn + CAP * AB_LD; float* vm = kh + CAP * AB_LD; float* dO = vm + CAP * AB_LD;
+    float* dvm = dO + CAP * AB_LD;
+    float* P = dvm + CAP * AB_LD; float* dsm = P + CAP * (CAP + 1);
+    float* kinv = dsm + CAP * (CAP + 1); float* vinv = kinv + CAP; float* mxs = vinv + CAP; float* gts = mxs + CAP;
     __shared__ float gpart[4][64];
     const int S = p.S, hd = p.heads * DH;
     const int f = blockIdx.x / p.heads, h = blockIdx.x % p.heads;
@@ -321,11 +323,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs p) {
 
 static int attn_core(const AttnBwdArgs& a, int dh, hipStream_t s) {
     if (a.F * a.heads == 0) return 0;
-    const bool small = a.S <= 16;
-    if (dh == 64 && small) hipLaunchKernelGGL((attn_bwd_kernel<64, 16>), dim3(a.F * a.heads), dim3(256), 0, s, a);
-    else if (dh == 64) hipLaunchKernelGGL((attn_bwd_kernel<64, 32>), dim3(a.F * a.heads), dim3(256), 0, s, a);
-    else if (dh == 32) hipLaunchKernelGGL((attn_bwd_kernel<32, 32>), dim3(a.F * a.heads), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_bwd_kernel<16, 32>), dim3(a.F * a.heads), dim3(256), 0, s, a);
+    auto lds_of = [](int cap) { return (size_t)(6 * cap * AB_LD + 2 * cap * (cap + 1) + 4 * cap) * sizeof(float); };
+    static bool attr = false;
+    if (!attr) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64)));
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64)));
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(64)));
+        attr = true;
+    }
+    const dim3 grid(a.F * a.heads), block(256);
+    const int cap = a.S <= 16 ? 16 : (a.S <= 32 ? 32 : 64);
+#define D4_AB_LAUNCH(DH_, CAP_) hipLaunchKernelGGL((attn_bwd_kernel<DH_, CAP_>), grid, block, lds_of(CAP_), s, a)
+    if (dh == 64) { if (cap == 16) D4_AB_LAUNCH(64, 16); else if (cap == 32) D4_AB_LAUNCH(64, 32); else D4_AB_LAUNCH(64, 64); }
+    else if (dh == 32) { if (cap <= 32) D4_AB_LAUNCH(32, 32); else D4_AB_LAUNCH(32, 64); }
+    else { if (cap <= 32) D4_AB_LAUNCH(16, 32); else D4_AB_LAUNCH(16, 64); }
+#undef D4_AB_LAUNCH
     D4_LAUNCH_CHECK();
     return 0;
 }

@@ -260,7 +260,7 @@ def space_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma,
 def time_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma, inv_freq, *, residual_values=None, mix_weight=None,
                    mix_bias=None, softclamp_value=50., belief=True):
     """The trunk's time layers (dreamer4.py:3176-3215): causal attention along time for every token column, rotary positions
-    (`inv_freq` = time_rotary.inv_freq), no KV cache (the training form).  x (batch, frames, tokens, dim), frames <= 32;
+    (`inv_freq` = time_rotary.inv_freq), no KV cache (the training form).  x (batch, frames, tokens, dim), frames <= 64;
     `residual_values` (batch, frames, tokens, heads, dim_head).  = torch.ops.d4hip.attn_block_time."""
     _dev(x)
     assert x.ndim == 4, 'x must be (batch, frames, tokens, dim)'

@@ -317,7 +317,7 @@ int d4_ff_backward_saved(const float* x, const float* dy, const float* norm_w, c
 /* Space attention block (Attention.forward, dreamer4.py:1968-2075, self attention within a frame): x / y [frames*tokens][dim],
  * residual_values [frames*tokens][heads*dim_head] or null (then w_mix / b_mix and their gradients are unused), wq / wk / wv
  * [heads*dim_head][dim], wo [dim][heads*dim_head], w_gates / w_mix [heads][dim], b_mix [heads], k_gamma [heads][dim_head];
- * tokens <= 32 per frame, dim_head 16 / 32 / 64; num_special trailing tokens are hidden from the ordinary queries (dreamer4.py:1769-1783). */
+ * tokens <= 64 per frame, dim_head 16 / 32 / 64; num_special trailing tokens are hidden from the ordinary queries (dreamer4.py:1769-1783). */
 size_t d4_attn_workspace_bytes(int frames, int tokens, int dim, int heads, int dim_head);
 int d4_space_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,
                           const float* wo, const float* w_gates, const float* w_mix, const float* b_mix, const float* k_gamma,
@@ -336,7 +336,7 @@ int d4_space_attn_backward_saved(const float* x, const float* residual_values, c
                            float* d_w_gates, float* d_w_mix, float* d_b_mix, float* d_k_gamma,
                            float* workspace, size_t workspace_bytes, void* stream);
 /* Time attention block (the same Attention with rotary positions and a causal mask along time, one problem per token column,
- * dreamer4.py:3176-3215 / 1626-1659): x / y [batch][frames][tokens][dim] row-major, frames <= 32 (no KV cache: the training form);
+ * dreamer4.py:3176-3215 / 1626-1659): x / y [batch][frames][tokens][dim] row-major, frames <= 64 (no KV cache: the training form);
  * inv_freq [dim_head / 2] = time_rotary.inv_freq. */
 size_t d4_time_attn_workspace_bytes(int batch, int frames, int tokens, int dim, int heads, int dim_head);
 int d4_time_attn_forward(const float* x, const float* residual_values, const float* norm_w, const float* wq, const float* wk, const float* wv,

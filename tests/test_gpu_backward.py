@@ -58,6 +58,8 @@ def _attn_params(D, heads, dh, g):
     (3, 30, 128, 3, 32, False, 6, 50., True),         # first layer (no residual), tokenizer-encoder-like special block, heads not a multiple of 4
     (4, 12, 64, 5, 16, True, 0, 2., False),           # tight soft clamp, no belief projection, no special tokens
     (130, 15, 512, 8, 64, True, 1, 50., True),        # BASELINE cfg 2 geometry (15 tokens per frame, 8 x 64 heads)
+    (3, 64, 64, 2, 64, True, 2, 50., True),           # the operator's limit: 64 tokens per frame (LDS arrays at capacity 64)
+    (2, 41, 64, 2, 32, True, 1, 50., True),
 ])
 def test_space_attention_forward_and_backward_vs_oracle_autograd(F_, S, D, heads, dh, has_rv, ns, clamp, belief):
     g = torch.Generator().manual_seed(7)
@@ -90,7 +92,7 @@ def test_space_attention_forward_and_backward_vs_oracle_autograd(F_, S, D, heads
         close(Wg[k].grad, Wd[k].grad, 'd ' + k)
 
 
-@pytest.mark.parametrize('B,T,S,D,heads,dh,has_rv,clamp', [(2, 7, 5, 64, 2, 64, True, 50.), (1, 32, 3, 64, 3, 32, False, 50.), (3, 16, 15, 128, 2, 16, True, 3.)])
+@pytest.mark.parametrize('B,T,S,D,heads,dh,has_rv,clamp', [(2, 7, 5, 64, 2, 64, True, 50.), (1, 32, 3, 64, 3, 32, False, 50.), (3, 16, 15, 128, 2, 16, True, 3.), (1, 64, 2, 64, 2, 64, True, 50.), (2, 48, 3, 64, 1, 32, False, 50.)])
 def test_time_attention_forward_and_backward_vs_oracle_autograd(B, T, S, D, heads, dh, has_rv, clamp):
     from einops import rearrange
     g = torch.Generator().manual_seed(9)
@@ -374,7 +376,7 @@ def test_argument_errors_are_loud():
     W = _attn_params(64, 2, 64, torch.Generator().manual_seed(0))
     Wg = {k: v.cuda() for k, v in W.items()}
     with pytest.raises(D4Error, match='items per group'):
-        trunk_ops.space_attention(torch.zeros(1, 40, 64, device='cuda'), Wg['norm.weight'], Wg['to_q.weight'], Wg['to_k.weight'], Wg['to_v.weight'],
+        trunk_ops.space_attention(torch.zeros(1, 70, 64, device='cuda'), Wg['norm.weight'], Wg['to_q.weight'], Wg['to_k.weight'], Wg['to_v.weight'],
                                   Wg['to_out.weight'], Wg['to_gates.0.weight'], Wg['k_heads_rmsnorm.gamma'])
     with pytest.raises(D4Error, match='no CPU fallback'):
         trunk_ops.feedforward(torch.zeros(2, 64), *[v for v in _ff_params(64, 170, torch.Generator().manual_seed(0)).values()])
