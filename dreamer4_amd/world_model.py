@@ -707,6 +707,18 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         self._live_cache = tc
         return pred, (agent, tc)
 
+    def _shortcut_coin(self, generator, prob):
+        """The shortcut / plain-flow coin of a training step (dreamer4.py:345-346, 6965: `rand(1).item() < prob`, a HOST draw in the reference).
+        Drawn on the host here too — a device draw would make every training step wait for the device — from the global CPU generator, or,
+        when the caller passes a (device) generator, from a CPU companion seeded with its initial seed (deterministic per seed)."""
+        if generator is None:
+            return bool(torch.rand(1).item() < prob)
+        pair = getattr(self, '_coin_generator', None)
+        if pair is None or pair[0] is not generator or pair[2] != generator.initial_seed():
+            pair = (generator, torch.Generator().manual_seed(generator.initial_seed()), generator.initial_seed())
+            object.__setattr__(self, '_coin_generator', pair)
+        return bool(torch.rand(1, generator=pair[1]).item() < prob)
+
     def _training_forward(self, latents, discrete_actions, continuous_actions, tasks, *, return_all_losses=False, seed=None, generator=None,
                           add_autoregressive_action_loss=True, prob_shortcut_train=None, draws=None, rewards=None, terminals=None,
                           update_loss_ema=None, lens=None, **kwargs):
@@ -733,7 +745,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
             if g is None and seed is not None:
                 g = torch.Generator(device=dev).manual_seed(seed)
             prob = (1. - n_log2 ** -1.) if prob_shortcut_train is None else prob_shortcut_train           # dreamer4.py:4898
-            shortcut = bool(torch.rand(1, device=dev, generator=g).item() < prob)
+            shortcut = self._shortcut_coin(g, prob)
             if shortcut:                                                                                    # dreamer4.py:6967-6974, eq. (4)
                 step_log2 = torch.randint(1, n_log2, (B,), device=dev, generator=g)
                 nss = (2 ** step_log2)[:, None]

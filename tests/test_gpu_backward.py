@@ -258,16 +258,22 @@ def test_world_model_training_forward_matches_the_fixture_and_trains():
     opt = torch.optim.AdamW(trunk, lr=3e-3, weight_decay=0.)
     gen = torch.Generator(device='cuda').manual_seed(3)
     lat = t(g['latents']).cuda()
-    first = last = None
+    # judged on FIXED draws before and after (the loss of a training step depends on its own signal levels, noise and shortcut coin)
+    B_, T_ = lat.shape[:2]
+    fixed = dict(shortcut_train=False, step_sizes_log2=torch.zeros(B_, dtype=torch.long), signal_levels=torch.randint(0, m.max_steps, (B_, T_), generator=torch.Generator().manual_seed(5)),
+                 noise=torch.randn(lat.shape, generator=torch.Generator().manual_seed(6)))
+    probe = lambda: m(latents=lat, discrete_actions=t(g['actions']), draws=fixed, add_autoregressive_action_loss=False).item()
+    with torch.no_grad():
+        first = probe()
     for step in range(40):
         opt.zero_grad(set_to_none=True)
         loss = m(latents=lat, discrete_actions=t(g['actions']), generator=gen, add_autoregressive_action_loss=False)
         loss.backward()
         opt.step()
         m.invalidate_prepared()
-        last = loss.item()
-        first = first if first is not None else last
-    assert last < 0.7 * first, (first, last)
+    with torch.no_grad():
+        last = probe()
+    assert last < 0.85 * first, (first, last)
 
 
 def test_world_model_training_forward_with_rewards_terminals_and_actions_vs_reference_fixture():
