@@ -29,8 +29,9 @@ struct TnArgs {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int TM, int TN, int DEPTH>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
-    __shared__ f4 red[3 * 16 * 64];                // [3 waves][16 accumulators][64 lanes] per reduction pass
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tn_kernel(TnArgs p) {
+    constexpr int RC = 8;                          // accumulators per reduction pass: 3 x 8 x 64 float4 = 24 KB of LDS (four workgroups per CU)
+    __shared__ f4 red[3 * RC * 64];                // [3 waves][RC accumulators][64 lanes]
     constexpr int NACC = 16 * TM * TN;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int l16 = lane & 15, lk = lane >> 4;
@@ -94,21 +95,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
         }
     }
 
-    // fixed-order sum of the four waves' partial tiles: waves 1..3 park theirs in LDS (16 accumulators = 48 KB per pass), wave 0 adds them
+    // fixed-order sum of the four waves' partial tiles: waves 1..3 park theirs in LDS (8 accumulators = 24 KB per pass), wave 0 adds them
     // in wave order; then wave 0 stores
 #pragma unroll
-    for (int pass = 0; pass < NACC / 16; ++pass) {
+    for (int pass = 0; pass < NACC / RC; ++pass) {
         if (pass > 0) __syncthreads();
         if (w > 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) red[((w - 1) * 16 + i) * 64 + lane] = acc[pass * 16 + i];
+            for (int i = 0; i < RC; ++i) red[((w - 1) * RC + i) * 64 + lane] = acc[pass * RC + i];
         }
         __syncthreads();
         if (w == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < RC; ++i)
 #pragma unroll
-                for (int o = 0; o < 3; ++o) acc[pass * 16 + i] += red[(o * 16 + i) * 64 + lane];
+                for (int o = 0; o < 3; ++o) acc[pass * RC + i] += red[(o * RC + i) * 64 + lane];
         }
     }
     if (w > 0) return;
@@ -143,7 +144,8 @@ bool gemm_tn_applicable(const float* A, int lda, const float* B, int ldb, const 
 // slice >= 256 contraction rows, partials within `part`.  64 x 64 tile per workgroup throughout (the 64 x 128 form needs twice the registers,
 // runs one wave per SIMD and measured slower on every shape).
 void gemm_tn_plan(int M, int N, int K, size_t part_floats, int* tile_n, int* slices, int forced_tn, int forced_slices) {
-    const int tn = forced_tn == 2 ? 2 : 1;
+    const int tn = 1;
+    (void)forced_tn;
     const int64_t tiles = (int64_t)cdiv(M, 64) * cdiv(N, 64 * tn);
     int S = (int)((768 + tiles / 2) / tiles);
     if (S > 8) S = 8;
@@ -164,11 +166,9 @@ int gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
     S = cdiv(K, ks);
     TnArgs p{A, lda, B, ldb, S > 1 ? part : C, S > 1 ? N : ldc, S > 1 ? (int64_t)M * N : 0, M, N, K, ks};
     const dim3 grid(cdiv(M, 64) * cdiv(N, 64 * tn), S), block(256);
-    if (tn == 2) hipLaunchKernelGGL((gemm_tn_kernel<1, 2, 3>), grid, block, 0, s, p);
-    else if (forced_tn == 3) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 3>), grid, block, 0, s, p);
+    if (forced_tn == 3) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 3>), grid, block, 0, s, p);
     else if (forced_tn == 4) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 2>), grid, block, 0, s, p);
-    else if (forced_tn == 5) hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 6>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_tn_kernel<1, 1, 4>), grid, block, 0, s, p);       // 116 registers: four waves per SIMD, four workgroups per CU
     D4_LAUNCH_CHECK();
     if (S > 1) return splitk_reduce(part, S, M, N, nullptr, 0, C, ldc, s);
     return 0;
