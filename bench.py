@@ -307,7 +307,7 @@ def main():
 
     if timing:
         # the dominant configuration only: keeps the event overhead in the timed region small (--warmup 0: all of them)
-        lib.d4_profile_enable(((1 << dom) if dom is not None else (1 << ncls) - 1) | (EVENT_STRIDE << 24))
+        lib.d4_profile_enable(((1 << dom) if dom is not None else (1 << ncls) - 1) | (EVENT_STRIDE << 26))
     gen_ms, learn_ms = [], []
     frames_total = 0
     parallel.barrier()

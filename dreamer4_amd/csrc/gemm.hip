@@ -354,8 +354,8 @@ bool gemm_profile_active() { return g_prof_mask != 0 || gemm_bf16_profile_active
 static std::recursive_mutex& gemm_mutex();
 int gemm_profile_enable(int mask) {
     std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
-    g_prof_stride = (mask >> 24) > 0 ? (mask >> 24) : 1;          // bits 24..30: stride; bits 0..23: configurations
-    mask &= 0xFFFFFF;
+    g_prof_stride = (mask >> 26) > 0 ? (mask >> 26) : 1;          // bits 26..30: stride; bits 0..25: configurations
+    mask &= 0x3FFFFFF;
     g_prof_tick = 0;
     g_prof_mask = mask;
     return 0;
@@ -441,8 +441,9 @@ static const char* const kTileKernel[N_TILE_CFG] = {
     "gemm_kernel<128, 128, 2, 4, 32, 1", "gemm_kernel<128, 128, 4, 2, 32, 1", "gemm_kernel<128, 96, 4, 1, 32, 1", "gemm_kernel<64, 128, 2, 2, 32, 1",
     "gemm_kernel<64, 64, 2, 2, 32, 1", "gemm_kernel<256, 128, 4, 4, 32, 1", "gemm_kernel<64, 128, 2, 2, 16, 1", "gemm_kernel<64, 64, 2, 2, 16, 1"};
 // profile classes: the N_TILE_CFG configurations of this family, then the configurations of the second family (gemm2.hip)
-int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs(); }
+int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 1; }     // + the persistent split-operand form (gemm_x3sk.hip)
 const char* gemm_profile_class_name(int c) {
+    if (c == N_TILE_CFG + gemm2_configs() + gemm_x3_configs()) return gemm_x3sk_name();
     if (c >= N_TILE_CFG + gemm2_configs()) return gemm_x3_config_name(c - N_TILE_CFG - gemm2_configs());
     if (c >= N_TILE_CFG) return gemm2_config_name(c - N_TILE_CFG);
     return c >= 0 ? kTileKernel[c] : "";
@@ -711,6 +712,20 @@ static int launch_v3(int c, const GemmArgs& p, hipStream_t stream) {
     return 0;
 }
 
+static int launch_v3sk(const GemmArgs& p, hipStream_t stream) {
+    const int cls = N_TILE_CFG + gemm2_configs() + gemm_x3_configs();
+    const bool timed = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
+    if (!timed) return gemm_x3sk_launch(p, stream);
+    ProfRec rec{};
+    rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.flags = p.flags; rec.batch = p.batch;
+    rec.bm = 128; rec.bn = 128;
+    rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K;
+    if (int rc = gemm_x3sk_launch(p, stream, rec.a, rec.b)) return rc;
+    g_prof.push_back(rec);
+    return 0;
+}
+
 static int autotune_v3(const GemmArgs& p, hipStream_t stream, int* best_out) {
     hipEvent_t e0 = prof_event(), e1 = prof_event();
     const int saved_mask = g_prof_mask;
@@ -821,6 +836,15 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         // input projections (N = 2 x 1376 ... 5504: 1.2-1.35x the f32-input MFMA kernels) and other N >= 2048 projections (level to 1.3x) —
         // and loses on the N <= 1552 shapes (0.8-0.95x).  D4_GEMM_X3 = 0: never, 2: every applicable call (experiments).
         static const int mode = getenv("D4_GEMM_X3") ? atoi(getenv("D4_GEMM_X3")) : 1;
+        // Round 3, late: the persistent form (gemm_x3sk.hip) cuts the tiles of a launch's last partial round along k.  Measured
+        // (profiles/r03i_gemm_x3sk.txt): the cross-workgroup exchange costs what the cut saves at K = 512, so it is OPT-IN
+        // (D4_GEMM_X3SK=1: the calls gemm_x3sk_rule names) and no call takes it by default.
+        static const bool sk_on = getenv("D4_GEMM_X3SK") && atoi(getenv("D4_GEMM_X3SK")) != 0;
+        if (sk_on && mode >= 1 && g_forced_cfg < 0 && !gemm_skinny_applicable(p) && gemm_x3sk_rule(p)) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(stream, &cap);
+            if (cap == hipStreamCaptureStatusNone) return launch_v3sk(p, stream);
+        }
         const bool preferred = mode >= 2 || (mode == 1 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && p.M >= 256);
         if (preferred && gemm_x3_applicable(p) && !gemm_skinny_applicable(p)) return gemm_v3(p, stream);
         GemmArgs q = p;

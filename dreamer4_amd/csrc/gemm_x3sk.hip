@@ -1,0 +1,430 @@
+// Persistent form of the split-operand fp32 GEMM (gemm_x3.hip, 128 x 128 tiles on 8 waves): ONE workgroup per CU walks a static list of
+// work items, and the tiles that do not fill a whole round of the machine are cut along k into S slices that S workgroups multiply
+// concurrently ("stream-K" with an integer split) and a third kind of work item sums in k order.
+//
+// Why: this tile needs 120 KB of LDS, so exactly one workgroup fits a CU and a launch proceeds in rounds of 256 tiles
+// (profiles/r03g_x3_quantisation_sweep.txt is a staircase in steps of 256 tiles; a k-tile step takes ~1.8 us).  The cfg-2 shapes sit badly on
+// that staircase: the SiLU-GLU input projection is 616 tiles = 2.4 rounds and pays 3.  Here the F = floor(T / P) whole rounds run as
+// before and the R = T - F P remaining tiles are cut into S = floor(P / R) k-slices: 2.4 -> 2.5 rounds.
+//
+// Order of a workgroup's items: (1) its k-slice of a remaining tile FIRST — the slice's sums (hi + lo per element, the folded RMSNorm's
+// partial row sums) go to a workspace slot and the tile's counter is bumped; (2) its F whole tiles, with the epilogue as in
+// gemm_x3_kernel; (3) fix-ups: a remaining tile's slices are read back in k order, summed, and put through the epilogue.  The fix-ups are
+// dealt to the highest workgroup indices — the P - R S workgroups that had no slice and are ahead by a slice's time — so the
+// store -> flag -> load chain of the exchange (several memory round trips, ~10 us) is off every workgroup's critical path: by the time a
+// fix-up starts, its slices were written a whole tile-time ago.  (A first version let the slice-0 workgroup wait for the others right
+// after its own k-loop: the chain then sat at the end of the launch and ate the gain — 88.9 vs 90.1 us on the SiLU-GLU input projection.)
+//
+// Exchange between workgroups: L2 is per XCD and not coherent across XCDs inside a kernel, so the partial tiles and the counters go
+// through agent-scope relaxed atomics (write-through / re-fetch: the idiom tools/micro/grid_barrier_bench.hip validated) — no fence,
+// no cache flush.  THIS EXCHANGE IS WHAT THE FORM COSTS: a 64 KB slice takes ~10-20 us to cross between workgroups by agent-scope dword
+// accesses, and an uncached allocation (hipDeviceMallocUncached, plain 16-byte accesses) is slower still (profiles/r03i_gemm_x3sk.txt).  A slice never waits; a fix-up waits only for slices, which are every workgroup's FIRST item, and workgroups are
+// dispatched in index order: no residency assumption, no deadlock.  The wait is bounded all the same (a lost counter poisons the tile
+// with NaN instead of hanging the queue).  The fix-up clears the counter it consumed: a launch leaves the counters zero.
+//
+// STATUS (measured, profiles/r03i_gemm_x3sk.txt): correct on every shape and epilogue, but at K = 512 the exchange gives back what the cut
+// saves — SiLU-GLU input projection 87.3 us vs 89.0 us for the plain kernel, the output projection (K = 1376) 58.6 us vs 49-52 us on the
+// f32-input kernels.  It pays where the cut removes most of a long round: 1792 x 5504 x 1024 127 us vs 144 us plain / 188 us f32-input.
+// OPT-IN (D4_GEMM_X3SK=1; d4_gemm_split config 6): no call of the engine takes it by default.
+//
+// Bits: whole tiles are bit-identical to gemm_x3_kernel (same k order, same instruction).  A cut tile is
+// (hi + lo)[slice 0] + (hi + lo)[slice 1] + ... — fp32 re-association at S - 1 points of the k sum, and its folded-RMSNorm row sums are
+// added per slice; which tiles are cut is a function of the shape and the CU count alone (never of timing), so results are
+// deterministic.  Error against float64: as gemm_x3_kernel (tests/test_gpu_kernels.py::test_gemm_split_stream_k).
+#include "common.h"
+#include <hip/hip_ext.h>
+#include "kernels.h"
+#include <map>
+#include <type_traits>
+
+namespace d4 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int SK_BM = 128, SK_BN = 128, SK_WGM = 4, SK_WGN = 2, SK_D = 3;
+constexpr int SK_BK = 32, SK_LD = SK_BK + 8, SK_NT = SK_WGM * SK_WGN * 64;
+constexpr int SK_TN = SK_BN / SK_WGN / 32;                     // wave tile 32 x 64: TM = 1, TN = 2
+constexpr int SK_G = SK_BK / 8;
+constexpr int SK_APL = SK_BM * SK_LD, SK_BPL = SK_BN * SK_LD;   // one plane of one buffer (elements)
+constexpr int SK_SLOT = SK_BM * SK_BN + SK_BM;                  // floats of one partial tile: accumulators in register order, then row sums
+constexpr size_t SK_LDS = (size_t)(2 * 3 * (SK_BM + SK_BN) * SK_LD) * 2 + SK_BM * sizeof(float) + 16;
+static_assert(SK_BM * SK_G == SK_NT && SK_BN * SK_G == SK_NT, "one 8-element group of each operand per thread and k-tile");
+
+struct SkArgs {
+    GemmArgs p;
+    int P, F, R, S;           // grid; whole rounds; remaining tiles; k slices per remaining tile
+    int nfb;                  // the last nfb workgroups take the fix-ups (S > 1)
+    float* ws;                // [R * S][SK_SLOT] the slices' sums
+    unsigned* flags;          // [R] slices done per remaining tile, zero between launches
+};
+
+__device__ __forceinline__ void split3(float a, __bf16& h1, __bf16& h2, __bf16& h3) {
+    h1 = (__bf16)a;
+    const float r = a - (float)h1;
+    h2 = (__bf16)r;
+    h3 = (__bf16)(r - (float)h2);
+}
+
+enum { ROLE_WHOLE = 0, ROLE_SLICE = 1, ROLE_FIXUP = 2 };
+
+__global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
+    const GemmArgs& p = s.p;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [2][3][BM][LD]
+    __bf16* Bs = As + 2 * 3 * SK_APL;                                 // [2][3][BN][LD]
+    float* rowscale_s = reinterpret_cast<float*>(Bs + 2 * 3 * SK_BPL);   // [BM]
+    int* fail_s = reinterpret_cast<int*>(rowscale_s + SK_BM);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / SK_WGN, wn = wave % SK_WGN;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.x;
+    const int nbn = (p.N + SK_BN - 1) / SK_BN, nbm = (p.M + SK_BM - 1) / SK_BM;
+    const int nk_all = p.K / SK_BK;
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wb);
+    const int nsl = b < s.R * s.S ? 1 : 0;
+    int nfix = 0;
+    if (s.S > 1 && b >= s.P - s.nfb) {
+        const int j0 = s.P - 1 - b;
+        nfix = j0 < s.R ? (s.R - 1 - j0) / s.nfb + 1 : 0;
+    }
+    const int nitems = nsl + s.F + nfix;
+
+    for (int it = 0; it < nitems; ++it) {
+        int tile, kt0 = 0, kt1 = nk_all, role = ROLE_WHOLE, slot = 0, jrem = 0;
+        if (it < nsl) {
+            jrem = b % s.R;
+            const int z = b / s.R;
+            tile = s.F * s.P + jrem;
+            kt0 = (int)((int64_t)z * nk_all / s.S); kt1 = (int)((int64_t)(z + 1) * nk_all / s.S);
+            if (s.S > 1) { role = ROLE_SLICE; slot = jrem * s.S + z; }
+        } else if (it < nsl + s.F) tile = b + (it - nsl) * s.P;
+        else {
+            jrem = s.P - 1 - b + (it - nsl - s.F) * s.nfb;
+            tile = s.F * s.P + jrem; role = ROLE_FIXUP; slot = jrem * s.S;
+        }
+        // tile index -> (tm, tn): the XCD-aware banded walk of gemm_x3_kernel (workgroup b sits on XCD b % 8 and b + seg * P keeps it)
+        int tm, tn;
+        {
+            int bid = tile;
+            const int nblk = nbm * nbn, nx = 8;
+            const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+            constexpr int RB = 4;
+            const int band = bid / (RB * nbn), j = bid % (RB * nbn);
+            const int rows = min(RB, nbm - band * RB);
+            tm = band * RB + j % rows; tn = j / rows;
+        }
+        const int bm0 = tm * SK_BM, bn0 = tn * SK_BN;
+        const int rowsA = min(SK_BM, p.M - bm0), rowsB = min(SK_BN, p.N - bn0);
+        auto uniform_rsrc = [](const void* base, int64_t bytes) {
+            const uint64_t bb = reinterpret_cast<uint64_t>(base);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bb);
+            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(bb >> 32));
+            const int nb = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(p.A + (int64_t)bm0 * p.lda, ((int64_t)(rowsA - 1) * p.lda + p.K) * 4);
+        const int64_t wbytes = ((int64_t)(rowsB - 1) * p.ldw + p.K) * 2;
+        const __amdgpu_buffer_rsrc_t rsB0 = uniform_rsrc(Wb + (int64_t)bn0 * p.ldw, wbytes);
+        const __amdgpu_buffer_rsrc_t rsB1 = uniform_rsrc(Wb + p.wplane + (int64_t)bn0 * p.ldw, wbytes);
+        const __amdgpu_buffer_rsrc_t rsB2 = uniform_rsrc(Wb + 2 * p.wplane + (int64_t)bn0 * p.ldw, wbytes);
+
+        // register staging as gemm_x3_kernel<128, 128, 4, 2, D = 3, two LDS buffers>; k runs over this slice's k-tiles only
+        f32x4 ra[SK_D][2];
+        f32x4 rb[SK_D][3];
+        float ssq0 = 0.f, ssq1 = 0.f;
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        const int srow = tid / SK_G, scol = (tid % SK_G) * 8;
+        const uint32_t offA = (uint32_t)((srow * p.lda + scol) * 4), offB = (uint32_t)((srow * p.ldw + scol) * 2);
+        auto load_tile = [&](auto set_tag, int k0) {
+            constexpr int S = decltype(set_tag)::value;
+            ra[S][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA + (uint32_t)k0 * 4, 0, 0));
+            ra[S][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA + (uint32_t)k0 * 4 + 16, 0, 0));
+            rb[S][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB0, offB + (uint32_t)k0 * 2, 0, 0));
+            rb[S][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB1, offB + (uint32_t)k0 * 2, 0, 0));
+            rb[S][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB2, offB + (uint32_t)k0 * 2, 0, 0));
+        };
+        auto store_tile = [&](auto set_tag, int buf) {
+            constexpr int S = decltype(set_tag)::value;
+            __bf16* as = As + buf * 3 * SK_APL + srow * SK_LD + scol;
+            __bf16* bs = Bs + buf * 3 * SK_BPL + srow * SK_LD + scol;
+            *reinterpret_cast<f32x4*>(bs) = rb[S][0];
+            *reinterpret_cast<f32x4*>(bs + SK_BPL) = rb[S][1];
+            *reinterpret_cast<f32x4*>(bs + 2 * SK_BPL) = rb[S][2];
+            const f32x4 v0 = ra[S][0], v1 = ra[S][1];
+            bf16x8 o1, o2, o3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h1, h2, h3;
+                split3(v0[e], h1, h2, h3); o1[e] = h1; o2[e] = h2; o3[e] = h3;
+                split3(v1[e], h1, h2, h3); o1[e + 4] = h1; o2[e + 4] = h2; o3[e + 4] = h3;
+            }
+            *reinterpret_cast<bf16x8*>(as) = o1;
+            *reinterpret_cast<bf16x8*>(as + SK_APL) = o2;
+            *reinterpret_cast<bf16x8*>(as + 2 * SK_APL) = o3;
+            ssq0 = ssq0 + __builtin_fmaf(v0[3], v0[3], __builtin_fmaf(v0[2], v0[2], __builtin_fmaf(v0[1], v0[1], v0[0] * v0[0])));
+            ssq1 = ssq1 + __builtin_fmaf(v1[3], v1[3], __builtin_fmaf(v1[2], v1[2], __builtin_fmaf(v1[1], v1[1], v1[0] * v1[0])));
+        };
+
+        f32x16 hi[SK_TN], lo[SK_TN];
+#pragma unroll
+        for (int j = 0; j < SK_TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { hi[j][e] = 0.f; lo[j][e] = 0.f; }
+
+        auto mma = [&](int buf, int ks) {
+            const __bf16* as = As + buf * 3 * SK_APL + (wm * 32 + lrow) * SK_LD + lhalf * 8 + ks * 16;
+            const __bf16* bs = Bs + buf * 3 * SK_BPL + (wn * SK_TN * 32 + lrow) * SK_LD + lhalf * 8 + ks * 16;
+            bf16x8 af[3], bf[3][SK_TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[pl] = *reinterpret_cast<const bf16x8*>(as + pl * SK_APL);
+#pragma unroll
+                for (int j = 0; j < SK_TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(bs + pl * SK_BPL + j * 32 * SK_LD);
+            }
+#define D4_SK_TERM(PA, PB, ACC) \
+    _Pragma("unroll") for (int j = 0; j < SK_TN; ++j) ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA], bf[PB][j], ACC[j], 0, 0, 0);
+            D4_SK_TERM(2, 0, lo)
+            D4_SK_TERM(0, 0, hi)
+            D4_SK_TERM(1, 1, lo)
+            D4_SK_TERM(0, 2, lo)
+            D4_SK_TERM(1, 0, lo)
+            D4_SK_TERM(0, 1, lo)
+#undef D4_SK_TERM
+        };
+
+        const int nk = kt1 - kt0, kbeg = kt0 * SK_BK;
+        const int klast = kbeg + (nk - 1) * SK_BK;
+        if (role != ROLE_FIXUP) {
+        load_tile(S0{}, kbeg);
+        load_tile(S1{}, min(kbeg + SK_BK, klast));
+        load_tile(S2{}, min(kbeg + 2 * SK_BK, klast));
+        store_tile(S0{}, 0);
+        __syncthreads();
+        auto k_tile = [&](int kt, auto set_tag, auto store_tag) {
+            constexpr int S = decltype(set_tag)::value;
+            const int buf = kt & 1;
+            load_tile(set_tag, min(kbeg + (kt + SK_D) * SK_BK, klast));
+            const bool store = decltype(store_tag)::value || kt + 1 < nk;
+            mma(buf, 0);
+            if (store) store_tile(std::integral_constant<int, (S + 1) % SK_D>{}, buf ^ 1);
+            mma(buf, 1);
+            if constexpr (decltype(store_tag)::value) {
+                constexpr int NMFMA = 2 * 6 * SK_TN;
+#pragma unroll
+                for (int i = 0; i < NMFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // 4 VALU
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);     // 1 DS
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read
+                }
+            }
+            __syncthreads();
+        };
+        using Always = std::true_type;
+        using Check = std::false_type;
+        const int nfull = (nk - 1) / SK_D;
+        int kt = 0;
+        for (int t = 0; t < nfull; ++t, kt += SK_D) {
+            k_tile(kt, S0{}, Always{});
+            k_tile(kt + 1, S1{}, Always{});
+            k_tile(kt + 2, S2{}, Always{});
+        }
+        k_tile(kt, S0{}, Check{});
+        if (kt + 1 < nk) k_tile(kt + 1, S1{}, Check{});
+        if (kt + 2 < nk) k_tile(kt + 2, S2{}, Check{});
+        }
+
+        // ---- this slice's sums: hi + lo per element, the row's sum of squares on the first lane of each 4-lane row group
+#pragma unroll
+        for (int j = 0; j < SK_TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hi[j][e] += lo[j][e];
+        const bool rms = (p.flags & GEMM_RMS_ROWSCALE) != 0;
+        float rsum = 0.f;
+        if (rms) {
+            rsum = ssq0 + ssq1;                        // chunks (2g) + (2g + 1)
+            rsum += dpp_f<0xB1>(rsum);                 // ((0+1)+(2+3)), ((4+5)+(6+7))
+            rsum += dpp_f<0x4E>(rsum);                 // the four lanes of a row
+        }
+        const bool row_lane = (tid % SK_G) == 0;
+
+        if (role == ROLE_SLICE) {
+            float* w = s.ws + (int64_t)slot * SK_SLOT;
+#pragma unroll
+            for (int j = 0; j < SK_TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) __hip_atomic_store(w + (j * 16 + e) * SK_NT + tid, hi[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rms && row_lane) __hip_atomic_store(w + SK_BM * SK_BN + srow, rsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_waitcnt(0);             // every store of this thread has been acknowledged ...
+            __syncthreads();                           // ... and of the workgroup
+            if (tid == 0) __hip_atomic_fetch_add(s.flags + jrem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (role == ROLE_FIXUP) {
+            if (tid == 0) {
+                int failed = 0;
+                unsigned spins = 0;
+                while (__hip_atomic_load(s.flags + jrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s.S) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) { failed = 1; break; }
+                }
+                __hip_atomic_store(s.flags + jrem, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *fail_s = failed;
+            }
+            __syncthreads();
+            const float poison = *fail_s ? __builtin_nanf("") : 0.f;
+            for (int c = 0; c < s.S; ++c) {            // slices in k order
+                const float* w = s.ws + (int64_t)(slot + c) * SK_SLOT;
+#pragma unroll
+                for (int j = 0; j < SK_TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float v = __hip_atomic_load(w + (j * 16 + e) * SK_NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + poison;
+                        hi[j][e] = c == 0 ? v : hi[j][e] + v;
+                    }
+                if (rms && row_lane) {
+                    const float v = __hip_atomic_load(w + SK_BM * SK_BN + srow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rsum = c == 0 ? v : rsum + v;
+                }
+            }
+        }
+        if (rms) {
+            if (row_lane) rowscale_s[srow] = rsqrtf(rsum / (float)p.K + p.rms_eps);
+            __syncthreads();
+        }
+
+        // ---- epilogue (as gemm_x3_kernel): C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int lr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+            const int gm = bm0 + lr;
+            if (gm >= p.M) continue;
+            const float rs = rms ? rowscale_s[lr] : 1.f;
+            if (swiglu) {
+#pragma unroll
+                for (int j = 0; j < SK_TN; j += 2) {
+                    const int gn = bn0 + wn * SK_TN * 32 + j * 32 + lrow;       // packed column of the value
+                    if (gn >= p.N) continue;
+                    float val = hi[j][e] * rs, gate = hi[j + 1][e] * rs;
+                    if (p.bias) { val += p.bias[gn]; gate += p.bias[gn + 32]; }
+                    const int on = (gn / 64) * 32 + (gn % 64);
+                    p.C[(int64_t)gm * p.ldc + on] = val * siluf(gate);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SK_TN; ++j) {
+                    const int gn = bn0 + wn * SK_TN * 32 + j * 32 + lrow;
+                    if (gn >= p.N) continue;
+                    float v = hi[j][e] * rs;
+                    if (p.bias) v += p.bias[gn];
+                    if (p.flags & GEMM_SILU) v = siluf(v);
+                    if (p.R) v += p.R[(int64_t)gm * p.ldr + gn];
+                    if (p.flags & GEMM_ACCUMULATE) v += p.C[(int64_t)gm * p.ldc + gn];
+                    p.C[(int64_t)gm * p.ldc + gn] = v;
+                    if (p.C2) {
+                        const int ts = gm % p.c2_S;
+                        const int keep = p.c2_hi - p.c2_lo;
+                        const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : ((p.c2_last && ts == p.c2_S - 1) ? keep : -1);
+                        if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + p.c2_last) + rank) * p.ldc2 + gn] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();                               // rowscale_s / fail_s are rewritten by the next item
+    }
+}
+
+// one workspace (partial tiles + flags) per stream, allocated at first use outside graph capture
+struct SkWs { float* ws = nullptr; unsigned* flags = nullptr; };
+std::map<hipStream_t, SkWs> g_sk_ws;
+int g_sk_cus = 0;
+
+int sk_cus() {
+    if (g_sk_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_sk_cus = n;
+    }
+    return g_sk_cus;
+}
+
+}  // namespace
+
+const char* gemm_x3sk_name() { return "gemm_x3sk_kernel"; }
+
+bool gemm_x3sk_applicable(const GemmArgs& p) {
+    return gemm_x3_applicable(p) && p.batch <= 1 && p.M > 0 && (!(p.flags & GEMM_SWIGLU) || (p.N % 64) == 0);
+}
+
+// F whole rounds, R remaining tiles cut into S k-slices; returns the k-tile steps the longest workgroup walks (the launch's length)
+int gemm_x3sk_plan(const GemmArgs& p, int* F, int* R, int* S, int* P_out) {
+    const int P = sk_cus();
+    const int T = cdiv(p.M, SK_BM) * cdiv(p.N, SK_BN), nk = p.K / SK_BK;
+    int f = T / P, r = T - f * P, sl = 1;
+    if (r > 0) {
+        sl = P / r;
+        if (sl > 4) sl = 4;                            // a slice shorter than ~6 k-tiles is mostly prologue
+        while (sl > 1 && nk / sl < 6) --sl;
+    }
+    *F = f; *R = r; *S = sl;
+    if (P_out) *P_out = P;
+    return f * nk + (r > 0 ? cdiv(nk, sl) + (sl > 1 ? 2 : 0) : 0);
+}
+
+// The shape rule (never a timing): the persistent form runs a call when cutting the last round shortens the launch by >= 10 % against
+// whole 128 x 128 tiles, the call is big enough to fill the machine, and N >= 512 (tall N = 256 products stream their A operand from
+// HBM and sit on the f32-input kernels).
+bool gemm_x3sk_rule(const GemmArgs& p) {
+    if (!gemm_x3sk_applicable(p) || p.M < 1024 || p.N < 512) return false;
+    int F, R, S, P;
+    const int len = gemm_x3sk_plan(p, &F, &R, &S, &P);
+    const int T = cdiv(p.M, SK_BM) * cdiv(p.N, SK_BN), nk = p.K / SK_BK;
+    if ((int64_t)T * nk < (int64_t)P * 12) return false;
+    return S > 1 && 10 * len <= 9 * cdiv(T, P) * nk;
+}
+
+int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    D4_REQUIRE(gemm_x3sk_applicable(p), "gemm_x3sk: call not supported (M=%d N=%d K=%d flags=%d batch=%d)", p.M, p.N, p.K, p.flags, p.batch);
+    SkArgs a;
+    a.p = p;
+    gemm_x3sk_plan(p, &a.F, &a.R, &a.S, &a.P);
+    const int T = a.F * a.P + a.R;
+    if (T < a.P && a.S == 1) a.P = T;                  // a small call: one tile per workgroup, nothing persistent
+    a.ws = nullptr; a.flags = nullptr;
+    a.nfb = 0;
+    if (a.S > 1) {
+        const int nfree = a.P - a.R * a.S, third = cdiv(a.R, 3);
+        a.nfb = nfree > third ? nfree : third;         // the workgroups without a slice take the fix-ups, up to three each; else more share them
+        SkWs& w = g_sk_ws[stream];
+        if (!w.ws) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(stream, &cap);
+            D4_REQUIRE(cap == hipStreamCaptureStatusNone, "gemm_x3sk: the partial-tile workspace of a stream cannot be created during graph capture (run the call once before capturing)");
+            const int P = sk_cus();
+            D4_HIP(hipMalloc(reinterpret_cast<void**>(&w.ws), (size_t)P * SK_SLOT * sizeof(float)));
+            D4_HIP(hipMalloc(reinterpret_cast<void**>(&w.flags), (size_t)P * sizeof(unsigned)));
+            D4_HIP(hipMemset(w.flags, 0, (size_t)P * sizeof(unsigned)));
+        }
+        a.ws = w.ws; a.flags = w.flags;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS));
+        attr_set = true;
+    }
+    const dim3 grid(a.P), block(SK_NT);
+    if (ea) hipExtLaunchKernelGGL(gemm_x3sk_kernel, grid, block, (uint32_t)SK_LDS, stream, ea, eb, 0, a);
+    else hipLaunchKernelGGL(gemm_x3sk_kernel, grid, block, SK_LDS, stream, a);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace d4

@@ -68,6 +68,12 @@ void gemm_x3_config_tile(int c, int* bm, int* bn);
 int gemm_x3_heuristic(const GemmArgs& p);
 int gemm_x3_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 int split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane, hipStream_t s);
+// persistent form of the 128 x 128 split-operand kernel (gemm_x3sk.hip): one workgroup per CU, the tiles of the last partial round cut along k
+bool gemm_x3sk_applicable(const GemmArgs& p);
+bool gemm_x3sk_rule(const GemmArgs& p);                    // the calls that take it (a rule on the shape and the CU count)
+int gemm_x3sk_plan(const GemmArgs& p, int* F, int* R, int* S, int* P);
+const char* gemm_x3sk_name();
+int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 // second fp32 family (gemm2.hip): 16x16x4 MFMA fed by an LDS-DMA ring; non-transposed operands, K % 32 == 0
 bool gemm2_applicable(const GemmArgs& p);
 bool gemm2_config_valid(int c, const GemmArgs& p);

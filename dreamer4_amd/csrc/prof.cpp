@@ -36,8 +36,8 @@ bool glue_profile_active() { return g_mask != 0; }
 
 int glue_profile_enable(int m) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_stride = (m >> 24) > 0 ? (m >> 24) : 1;
-    g_mask = m & 0xFFFFFF;
+    g_stride = (m >> 26) > 0 ? (m >> 26) : 1;
+    g_mask = m & 0x3FFFFFF;
     for (int i = 0; i < GL_N; ++i) g_tick[i] = 0;
     return 0;
 }

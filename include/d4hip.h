@@ -230,8 +230,8 @@ int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                   float grad_scale, float* scratch, void* stream);
 
-/* Measurement hook (bench.py roofline leg): `mask` bit c (c < 24) enables tile configuration c of the GEMM kernels; every
- * (mask >> 24)-th launch (0 -> every launch) of an enabled configuration carries a HIP event pair on its dispatch (launch stream); d4_profile_read sums elapsed ms / algorithmic flops /
+/* Measurement hook (bench.py roofline leg): `mask` bit c (c < 26) enables tile configuration c of the GEMM kernels; every
+ * (mask >> 26)-th launch (0 -> every launch) of an enabled configuration carries a HIP event pair on its dispatch (launch stream); d4_profile_read sums elapsed ms / algorithmic flops /
  * launches per configuration and clears the log.  d4_profile_classes() configurations exist; d4_profile_class_name(c) is the
  * prefix of the kernel name rocprofv3 reports for configuration c ("gemm_kernel<BM, BN, WGM, WGN, BK, 1"). */
 /* bf16 path: every `stride`-th bf16 GEMM launch carries an event pair (0 = off); read sums ms / flops / launches and clears. */
@@ -294,7 +294,8 @@ int d4_cvt_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
  * bf16 numbers and a product is accumulated from its six leading bf16 x bf16 terms in fp32 — fp32 accuracy (error against float64 no
  * larger than the f32-input MFMA kernels'), 6/16 of their matrix-pipe time.  d4_split_bf16x3 writes the three planes of W
  * (dst[p * plane_stride + i], p = 0..2; plane_stride % 8 == 0); d4_gemm_split takes A in fp32 and splits it on the fly.  `config` = -1: the
- * dispatcher's choice, else one tile configuration of the family (all give the same bits). */
+ * dispatcher's choice, 0..5 one tile configuration of the family (all give the same bits), 6 the persistent form (csrc/gemm_x3sk.hip:
+ * one workgroup per CU, the tiles of the last partial round cut along k and summed in k order — whole tiles keep the family's bits). */
 int d4_split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane_stride, void* stream);
 int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_stride, int ldw, float* C, int ldc, const float* bias,
                   const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, void* stream);

@@ -222,6 +222,53 @@ def test_gemm_split_operands_is_fp32_accurate(lib, M, N, K, flags):
     assert (outs[0].double() - ref).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize('M,N,K,flags', [(3584, 2752, 512, 5), (3584, 512, 1376, 0), (3584, 1552, 512, 1), (3840, 2752, 512, 5), (1000, 300, 96, 1),
+                                         (130, 129, 2048, 0), (257, 64, 64, 2), (3584, 512, 1376, 32)])
+def test_gemm_split_stream_k(lib, M, N, K, flags):
+    """gemm_x3sk.hip (d4_gemm_split config 6): the persistent form of the 128 x 128 split-operand kernel — one workgroup per CU, the tiles of the
+    last partial round cut along k into slices that are summed in k order through agent-scope atomics.  Whole tiles keep the family's
+    bits; a cut tile differs from the plain kernel by fp32 re-association at the cuts only.  Checked: error against float64 no larger
+    than the plain kernel's (+ 5 %), elementwise distance to the plain kernel within a few output roundings, repeated launches
+    bit-identical (the ready flags are left cleared), every epilogue, ragged edges, and a 4-slice cut (130 x 129 x 2048)."""
+    g = torch.Generator(device='cuda').manual_seed(11)
+    A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
+    b = torch.randn(N, device='cuda', generator=g)
+    swiglu = bool(flags & _lib.GEMM_SWIGLU)
+    accumulate = bool(flags & 32)
+    R = None if swiglu else torch.randn(M, N, device='cuda', generator=g)
+    W3, plane = split_planes(lib, W)
+    Nout = N // 2 if swiglu else N
+    eps = 1.1920929e-07
+    Ad, Wd = A.double(), W.double()
+    X = Ad * torch.rsqrt(Ad.pow(2).mean(-1, keepdim=True) + eps) if flags & _lib.GEMM_RMS_ROWSCALE else Ad
+    ref = X @ Wd.t() + b.double()
+    if flags & _lib.GEMM_SILU:
+        ref = torch.nn.functional.silu(ref)
+    if swiglu:
+        r = ref.reshape(M, N // 64, 2, 32)
+        ref = (r[:, :, 0] * torch.nn.functional.silu(r[:, :, 1])).reshape(M, N // 2)
+    if R is not None:
+        ref = ref + R.double()
+    C0 = torch.randn(M, Nout, device='cuda', generator=g) if accumulate else None
+    if accumulate:
+        ref = ref + C0.double()
+    outs = []
+    for cfg in (4, 6, 6, 6):
+        o = C0.clone() if accumulate else torch.full((M, Nout), float('nan'), device='cuda')
+        _lib.check(lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, cfg, stream()))
+        outs.append(o)
+    torch.cuda.synchronize()
+    plain, sk = outs[0], outs[1]
+    assert torch.isfinite(sk).all()
+    assert torch.equal(outs[2], sk) and torch.equal(outs[3], sk)
+    rms = lambda x: (x.double() - ref).pow(2).mean().sqrt().item()
+    scale = ref.pow(2).mean().sqrt().item()
+    assert rms(sk) <= 1.05 * rms(plain) + 6e-8 * scale
+    assert (sk - plain).abs().max().item() <= 2e-6 * max(1., ref.abs().max().item())
+    tol = 3e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
+    assert (sk.double() - ref).abs().max().item() <= tol
+
+
 def test_gemm_split_operands_wide_exponent_spread(lib):
     """gemm_x3.hip with operands whose magnitudes span 2^120 inside one row (|a|, |w| from 2^-60 to 2^60): every output must stay within
     fp32 rounding of float64 RELATIVE TO sum_k |a_k w_k| (the dropped a2.w3 + a3.w2 + a3.w3 terms are <= 2^-24 of each product, and no
