@@ -271,8 +271,9 @@ def main():
     timing = not args.no_kernel_timing
     ncls = lib.d4_profile_classes()
     raw_names = [lib.d4_profile_class_name(i).decode() for i in range(ncls)]
-    is_split = [n.startswith('gemm_x3_kernel') for n in raw_names]     # fp32 GEMM on the bf16 matrix cores: split operands, 6 bf16 MFMA products per fp32 product
-    names = [n + (', *> fp32 by split operands on the bf16 MFMA' if sp else ', *> fp32 MFMA') for n, sp in zip(raw_names, is_split)]
+    is_split = [n.startswith(('gemm_x3_kernel', 'gemm_x3sk_kernel')) for n in raw_names]     # fp32 GEMM on the bf16 matrix cores: split operands, 6 bf16 MFMA products per fp32 product
+    names = [n + ((' (persistent 128 x 128 / 128 x 64 form)' if n.startswith('gemm_x3sk') else ', *>') + ' fp32 by split operands on the bf16 MFMA' if sp else ', *> fp32 MFMA')
+             for n, sp in zip(raw_names, is_split)]
     # warm-up: first-use tile autotuning of every GEMM shape happens here; the last warm-up step is also used to find the
     # dominant tile configuration (all configurations event-timed), so that the timed region only carries events for it
     dom, warm_classes, warm_exec, glue_measured, fused_flops = None, None, (0., 0.), None, 0.

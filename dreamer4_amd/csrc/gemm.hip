@@ -836,15 +836,12 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         // input projections (N = 2 x 1376 ... 5504: 1.2-1.35x the f32-input MFMA kernels) and other N >= 2048 projections (level to 1.3x) —
         // and loses on the N <= 1552 shapes (0.8-0.95x).  D4_GEMM_X3 = 0: never, 2: every applicable call (experiments).
         static const int mode = getenv("D4_GEMM_X3") ? atoi(getenv("D4_GEMM_X3")) : 1;
-        // Round 3, late: the persistent form (gemm_x3sk.hip) cuts the tiles of a launch's last partial round along k.  Measured
-        // (profiles/r03i_gemm_x3sk.txt): the cross-workgroup exchange costs what the cut saves at K = 512, so it is OPT-IN
-        // (D4_GEMM_X3SK=1: the calls gemm_x3sk_rule names) and no call takes it by default.
-        static const bool sk_on = getenv("D4_GEMM_X3SK") && atoi(getenv("D4_GEMM_X3SK")) != 0;
-        if (sk_on && mode >= 1 && g_forced_cfg < 0 && !gemm_skinny_applicable(p) && gemm_x3sk_rule(p)) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(stream, &cap);
-            if (cap == hipStreamCaptureStatusNone) return launch_v3sk(p, stream);
-        }
+        // Round 3, late: the persistent form (gemm_x3sk.hip) runs the whole rounds of a launch as before and a last round that is at most
+        // half full as 128 x 64 half tiles (bit-identical; nothing crosses between workgroups).  gemm_x3sk_rule names the calls: at cfg 2
+        // the SiLU-GLU input projection of the denoising evaluations (616 tiles = 2 rounds + 104).  D4_GEMM_X3SK=0: never.
+        static const bool sk_on = !(getenv("D4_GEMM_X3SK") && atoi(getenv("D4_GEMM_X3SK")) == 0);
+        if (sk_on && mode >= 1 && g_forced_cfg < 0 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p) && gemm_x3sk_rule(p))
+            return launch_v3sk(p, stream);
         const bool preferred = mode >= 2 || (mode == 1 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && p.M >= 256);
         if (preferred && gemm_x3_applicable(p) && !gemm_skinny_applicable(p)) return gemm_v3(p, stream);
         GemmArgs q = p;

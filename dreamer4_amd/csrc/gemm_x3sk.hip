@@ -22,10 +22,17 @@
 // dispatched in index order: no residency assumption, no deadlock.  The wait is bounded all the same (a lost counter poisons the tile
 // with NaN instead of hanging the queue).  The fix-up clears the counter it consumed: a launch leaves the counters zero.
 //
-// STATUS (measured, profiles/r03i_gemm_x3sk.txt): correct on every shape and epilogue, but at K = 512 the exchange gives back what the cut
+// HALF TILES (the form the engine uses): when the remaining tiles number at most half the workgroups, they are not cut along k but along N — 2 R
+// work items of 128 x 64 (the 8 waves as 4 x 2 with 32 x 32 wave tiles; a SiLU-GLU column group is one such item: its value wave and its
+// gate wave meet through LDS in the epilogue), one per workgroup, after the whole rounds.  Nothing is exchanged between workgroups and
+// every element keeps its k order: bit-identical to gemm_x3_kernel, 2.4 rounds -> 2 rounds + one shorter one (a half tile takes ~0.88 of a
+// whole tile's time — the k-tile step is bound by the per-wave split / LDS / barrier chain, not by the MFMAs: 83.3 vs 86.5 us on the
+// SiLU-GLU input projection, the one cfg-2 call gemm_x3sk_rule sends here).
+//
+// STATUS of the k-cut (measured, profiles/r03i_gemm_x3sk.txt): correct on every shape and epilogue, but at K = 512 the exchange gives back what the cut
 // saves — SiLU-GLU input projection 87.3 us vs 89.0 us for the plain kernel, the output projection (K = 1376) 58.6 us vs 49-52 us on the
 // f32-input kernels.  It pays where the cut removes most of a long round: 1792 x 5504 x 1024 127 us vs 144 us plain / 188 us f32-input.
-// OPT-IN (D4_GEMM_X3SK=1; d4_gemm_split config 6): no call of the engine takes it by default.
+// The k-cut is reachable through d4_gemm_split config 6 only: no call of the engine takes it.
 //
 // Bits: whole tiles are bit-identical to gemm_x3_kernel (same k order, same instruction).  A cut tile is
 // (hi + lo)[slice 0] + (hi + lo)[slice 1] + ... — fp32 re-association at S - 1 points of the k sum, and its folded-RMSNorm row sums are
@@ -45,9 +52,8 @@ namespace {
 
 constexpr int SK_BM = 128, SK_BN = 128, SK_WGM = 4, SK_WGN = 2, SK_D = 3;
 constexpr int SK_BK = 32, SK_LD = SK_BK + 8, SK_NT = SK_WGM * SK_WGN * 64;
-constexpr int SK_TN = SK_BN / SK_WGN / 32;                     // wave tile 32 x 64: TM = 1, TN = 2
 constexpr int SK_G = SK_BK / 8;
-constexpr int SK_APL = SK_BM * SK_LD, SK_BPL = SK_BN * SK_LD;   // one plane of one buffer (elements)
+constexpr int SK_APL = SK_BM * SK_LD, SK_BPL = SK_BN * SK_LD;   // one plane of one buffer (elements); half tiles use the first 64 rows of a B plane
 constexpr int SK_SLOT = SK_BM * SK_BN + SK_BM;                  // floats of one partial tile: accumulators in register order, then row sums
 constexpr size_t SK_LDS = (size_t)(2 * 3 * (SK_BM + SK_BN) * SK_LD) * 2 + SK_BM * sizeof(float) + 16;
 static_assert(SK_BM * SK_G == SK_NT && SK_BN * SK_G == SK_NT, "one 8-element group of each operand per thread and k-tile");
@@ -55,6 +61,7 @@ static_assert(SK_BM * SK_G == SK_NT && SK_BN * SK_G == SK_NT, "one 8-element gro
 struct SkArgs {
     GemmArgs p;
     int P, F, R, S;           // grid; whole rounds; remaining tiles; k slices per remaining tile
+    int half;                 // 1: the remaining tiles run as 2 R half tiles of 128 x 64 (S = 1)
     int nfb;                  // the last nfb workgroups take the fix-ups (S > 1)
     float* ws;                // [R * S][SK_SLOT] the slices' sums
     unsigned* flags;          // [R] slices done per remaining tile, zero between launches
@@ -69,139 +76,108 @@ __device__ __forceinline__ void split3(float a, __bf16& h1, __bf16& h2, __bf16& 
 
 enum { ROLE_WHOLE = 0, ROLE_SLICE = 1, ROLE_FIXUP = 2 };
 
-__global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
+// One work item on the calling workgroup: rows bm0 .. bm0 + 127, columns bn0 .. bn0 + 64 TNV - 1, k-tiles kt0 .. kt1 - 1.
+// TNV = 2: a 128 x 128 tile (wave tile 32 x 64); TNV = 1: a half tile of 128 x 64 (wave tile 32 x 32), role WHOLE only.
+template <int TNV>
+__device__ __forceinline__ void sk_item(const SkArgs& s, const int bm0, const int bn0, const int kt0, const int kt1, const int role, const int slot,
+                                        const int jrem, __bf16* As, __bf16* Bs, float* rowscale_s, int* fail_s) {
     const GemmArgs& p = s.p;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [2][3][BM][LD]
-    __bf16* Bs = As + 2 * 3 * SK_APL;                                 // [2][3][BN][LD]
-    float* rowscale_s = reinterpret_cast<float*>(Bs + 2 * 3 * SK_BPL);   // [BM]
-    int* fail_s = reinterpret_cast<int*>(rowscale_s + SK_BM);
-
+    constexpr int BNV = 64 * TNV;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / SK_WGN, wn = wave % SK_WGN;
     const int lrow = lane & 31, lhalf = lane >> 5;
-    const int b = blockIdx.x;
-    const int nbn = (p.N + SK_BN - 1) / SK_BN, nbm = (p.M + SK_BM - 1) / SK_BM;
-    const int nk_all = p.K / SK_BK;
     const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wb);
-    const int nsl = b < s.R * s.S ? 1 : 0;
-    int nfix = 0;
-    if (s.S > 1 && b >= s.P - s.nfb) {
-        const int j0 = s.P - 1 - b;
-        nfix = j0 < s.R ? (s.R - 1 - j0) / s.nfb + 1 : 0;
-    }
-    const int nitems = nsl + s.F + nfix;
+    const int rowsA = min(SK_BM, p.M - bm0), rowsB = min(BNV, p.N - bn0);
+    auto uniform_rsrc = [](const void* base, int64_t bytes) {
+        const uint64_t bb = reinterpret_cast<uint64_t>(base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bb);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(bb >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+    };
+    // rows past the matrix edge fall outside num_records and read as zeros
+    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(p.A + (int64_t)bm0 * p.lda, ((int64_t)(rowsA - 1) * p.lda + p.K) * 4);
+    const int64_t wbytes = ((int64_t)(rowsB - 1) * p.ldw + p.K) * 2;
+    const __amdgpu_buffer_rsrc_t rsB0 = uniform_rsrc(Wb + (int64_t)bn0 * p.ldw, wbytes);
+    const __amdgpu_buffer_rsrc_t rsB1 = uniform_rsrc(Wb + p.wplane + (int64_t)bn0 * p.ldw, wbytes);
+    const __amdgpu_buffer_rsrc_t rsB2 = uniform_rsrc(Wb + 2 * p.wplane + (int64_t)bn0 * p.ldw, wbytes);
 
-    for (int it = 0; it < nitems; ++it) {
-        int tile, kt0 = 0, kt1 = nk_all, role = ROLE_WHOLE, slot = 0, jrem = 0;
-        if (it < nsl) {
-            jrem = b % s.R;
-            const int z = b / s.R;
-            tile = s.F * s.P + jrem;
-            kt0 = (int)((int64_t)z * nk_all / s.S); kt1 = (int)((int64_t)(z + 1) * nk_all / s.S);
-            if (s.S > 1) { role = ROLE_SLICE; slot = jrem * s.S + z; }
-        } else if (it < nsl + s.F) tile = b + (it - nsl) * s.P;
-        else {
-            jrem = s.P - 1 - b + (it - nsl - s.F) * s.nfb;
-            tile = s.F * s.P + jrem; role = ROLE_FIXUP; slot = jrem * s.S;
-        }
-        // tile index -> (tm, tn): the XCD-aware banded walk of gemm_x3_kernel (workgroup b sits on XCD b % 8 and b + seg * P keeps it)
-        int tm, tn;
-        {
-            int bid = tile;
-            const int nblk = nbm * nbn, nx = 8;
-            const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
-            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
-            constexpr int RB = 4;
-            const int band = bid / (RB * nbn), j = bid % (RB * nbn);
-            const int rows = min(RB, nbm - band * RB);
-            tm = band * RB + j % rows; tn = j / rows;
-        }
-        const int bm0 = tm * SK_BM, bn0 = tn * SK_BN;
-        const int rowsA = min(SK_BM, p.M - bm0), rowsB = min(SK_BN, p.N - bn0);
-        auto uniform_rsrc = [](const void* base, int64_t bytes) {
-            const uint64_t bb = reinterpret_cast<uint64_t>(base);
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bb);
-            const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(bb >> 32));
-            const int nb = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF));
-            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
-        };
-        const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(p.A + (int64_t)bm0 * p.lda, ((int64_t)(rowsA - 1) * p.lda + p.K) * 4);
-        const int64_t wbytes = ((int64_t)(rowsB - 1) * p.ldw + p.K) * 2;
-        const __amdgpu_buffer_rsrc_t rsB0 = uniform_rsrc(Wb + (int64_t)bn0 * p.ldw, wbytes);
-        const __amdgpu_buffer_rsrc_t rsB1 = uniform_rsrc(Wb + p.wplane + (int64_t)bn0 * p.ldw, wbytes);
-        const __amdgpu_buffer_rsrc_t rsB2 = uniform_rsrc(Wb + 2 * p.wplane + (int64_t)bn0 * p.ldw, wbytes);
-
-        // register staging as gemm_x3_kernel<128, 128, 4, 2, D = 3, two LDS buffers>; k runs over this slice's k-tiles only
-        f32x4 ra[SK_D][2];
-        f32x4 rb[SK_D][3];
-        float ssq0 = 0.f, ssq1 = 0.f;
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        using S2 = std::integral_constant<int, 2>;
-        const int srow = tid / SK_G, scol = (tid % SK_G) * 8;
-        const uint32_t offA = (uint32_t)((srow * p.lda + scol) * 4), offB = (uint32_t)((srow * p.ldw + scol) * 2);
-        auto load_tile = [&](auto set_tag, int k0) {
-            constexpr int S = decltype(set_tag)::value;
-            ra[S][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA + (uint32_t)k0 * 4, 0, 0));
-            ra[S][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA + (uint32_t)k0 * 4 + 16, 0, 0));
-            rb[S][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB0, offB + (uint32_t)k0 * 2, 0, 0));
-            rb[S][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB1, offB + (uint32_t)k0 * 2, 0, 0));
-            rb[S][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB2, offB + (uint32_t)k0 * 2, 0, 0));
-        };
-        auto store_tile = [&](auto set_tag, int buf) {
-            constexpr int S = decltype(set_tag)::value;
-            __bf16* as = As + buf * 3 * SK_APL + srow * SK_LD + scol;
-            __bf16* bs = Bs + buf * 3 * SK_BPL + srow * SK_LD + scol;
+    // register staging as gemm_x3_kernel<128, 128, 4, 2, D = 3, two LDS buffers>; k runs over this item's k-tiles only.  Half tiles have 64
+    // W rows for 128 staging rows: the upper half of the workgroup loads the same rows again (unconditional loads keep the counted waits
+    // exact) and does not store them.
+    f32x4 ra[SK_D][2];
+    f32x4 rb[SK_D][3];
+    float ssq0 = 0.f, ssq1 = 0.f;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    const int srow = tid / SK_G, scol = (tid % SK_G) * 8;
+    const int browB = TNV == 2 ? srow : (srow & 63);
+    const bool b_store = TNV == 2 || srow < 64;
+    const uint32_t offA = (uint32_t)((srow * p.lda + scol) * 4), offB = (uint32_t)((browB * p.ldw + scol) * 2);
+    auto load_tile = [&](auto set_tag, int k0) {
+        constexpr int S = decltype(set_tag)::value;
+        ra[S][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA + (uint32_t)k0 * 4, 0, 0));
+        ra[S][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, offA + (uint32_t)k0 * 4 + 16, 0, 0));
+        rb[S][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB0, offB + (uint32_t)k0 * 2, 0, 0));
+        rb[S][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB1, offB + (uint32_t)k0 * 2, 0, 0));
+        rb[S][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB2, offB + (uint32_t)k0 * 2, 0, 0));
+    };
+    auto store_tile = [&](auto set_tag, int buf) {
+        constexpr int S = decltype(set_tag)::value;
+        __bf16* as = As + buf * 3 * SK_APL + srow * SK_LD + scol;
+        __bf16* bs = Bs + buf * 3 * SK_BPL + browB * SK_LD + scol;
+        if (b_store) {
             *reinterpret_cast<f32x4*>(bs) = rb[S][0];
             *reinterpret_cast<f32x4*>(bs + SK_BPL) = rb[S][1];
             *reinterpret_cast<f32x4*>(bs + 2 * SK_BPL) = rb[S][2];
-            const f32x4 v0 = ra[S][0], v1 = ra[S][1];
-            bf16x8 o1, o2, o3;
+        }
+        const f32x4 v0 = ra[S][0], v1 = ra[S][1];
+        bf16x8 o1, o2, o3;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 h1, h2, h3;
-                split3(v0[e], h1, h2, h3); o1[e] = h1; o2[e] = h2; o3[e] = h3;
-                split3(v1[e], h1, h2, h3); o1[e + 4] = h1; o2[e + 4] = h2; o3[e + 4] = h3;
-            }
-            *reinterpret_cast<bf16x8*>(as) = o1;
-            *reinterpret_cast<bf16x8*>(as + SK_APL) = o2;
-            *reinterpret_cast<bf16x8*>(as + 2 * SK_APL) = o3;
-            ssq0 = ssq0 + __builtin_fmaf(v0[3], v0[3], __builtin_fmaf(v0[2], v0[2], __builtin_fmaf(v0[1], v0[1], v0[0] * v0[0])));
-            ssq1 = ssq1 + __builtin_fmaf(v1[3], v1[3], __builtin_fmaf(v1[2], v1[2], __builtin_fmaf(v1[1], v1[1], v1[0] * v1[0])));
-        };
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h1, h2, h3;
+            split3(v0[e], h1, h2, h3); o1[e] = h1; o2[e] = h2; o3[e] = h3;
+            split3(v1[e], h1, h2, h3); o1[e + 4] = h1; o2[e + 4] = h2; o3[e + 4] = h3;
+        }
+        *reinterpret_cast<bf16x8*>(as) = o1;
+        *reinterpret_cast<bf16x8*>(as + SK_APL) = o2;
+        *reinterpret_cast<bf16x8*>(as + 2 * SK_APL) = o3;
+        ssq0 = ssq0 + __builtin_fmaf(v0[3], v0[3], __builtin_fmaf(v0[2], v0[2], __builtin_fmaf(v0[1], v0[1], v0[0] * v0[0])));
+        ssq1 = ssq1 + __builtin_fmaf(v1[3], v1[3], __builtin_fmaf(v1[2], v1[2], __builtin_fmaf(v1[1], v1[1], v1[0] * v1[0])));
+    };
 
-        f32x16 hi[SK_TN], lo[SK_TN];
+    f32x16 hi[TNV], lo[TNV];
 #pragma unroll
-        for (int j = 0; j < SK_TN; ++j)
+    for (int j = 0; j < TNV; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { hi[j][e] = 0.f; lo[j][e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { hi[j][e] = 0.f; lo[j][e] = 0.f; }
 
-        auto mma = [&](int buf, int ks) {
-            const __bf16* as = As + buf * 3 * SK_APL + (wm * 32 + lrow) * SK_LD + lhalf * 8 + ks * 16;
-            const __bf16* bs = Bs + buf * 3 * SK_BPL + (wn * SK_TN * 32 + lrow) * SK_LD + lhalf * 8 + ks * 16;
-            bf16x8 af[3], bf[3][SK_TN];
+    auto mma = [&](int buf, int ks) {
+        const __bf16* as = As + buf * 3 * SK_APL + (wm * 32 + lrow) * SK_LD + lhalf * 8 + ks * 16;
+        const __bf16* bs = Bs + buf * 3 * SK_BPL + (wn * TNV * 32 + lrow) * SK_LD + lhalf * 8 + ks * 16;
+        bf16x8 af[3], bf[3][TNV];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                af[pl] = *reinterpret_cast<const bf16x8*>(as + pl * SK_APL);
+        for (int pl = 0; pl < 3; ++pl) {
+            af[pl] = *reinterpret_cast<const bf16x8*>(as + pl * SK_APL);
 #pragma unroll
-                for (int j = 0; j < SK_TN; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(bs + pl * SK_BPL + j * 32 * SK_LD);
-            }
+            for (int j = 0; j < TNV; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8*>(bs + pl * SK_BPL + j * 32 * SK_LD);
+        }
 #define D4_SK_TERM(PA, PB, ACC) \
-    _Pragma("unroll") for (int j = 0; j < SK_TN; ++j) ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA], bf[PB][j], ACC[j], 0, 0, 0);
-            D4_SK_TERM(2, 0, lo)
-            D4_SK_TERM(0, 0, hi)
-            D4_SK_TERM(1, 1, lo)
-            D4_SK_TERM(0, 2, lo)
-            D4_SK_TERM(1, 0, lo)
-            D4_SK_TERM(0, 1, lo)
+    _Pragma("unroll") for (int j = 0; j < TNV; ++j) ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA], bf[PB][j], ACC[j], 0, 0, 0);
+        D4_SK_TERM(2, 0, lo)
+        D4_SK_TERM(0, 0, hi)
+        D4_SK_TERM(1, 1, lo)
+        D4_SK_TERM(0, 2, lo)
+        D4_SK_TERM(1, 0, lo)
+        D4_SK_TERM(0, 1, lo)
 #undef D4_SK_TERM
-        };
+    };
 
-        const int nk = kt1 - kt0, kbeg = kt0 * SK_BK;
-        const int klast = kbeg + (nk - 1) * SK_BK;
-        if (role != ROLE_FIXUP) {
+    const int nk = kt1 - kt0, kbeg = kt0 * SK_BK;
+    const int klast = kbeg + (nk - 1) * SK_BK;
+    if (role != ROLE_FIXUP) {
         load_tile(S0{}, kbeg);
         load_tile(S1{}, min(kbeg + SK_BK, klast));
         load_tile(S2{}, min(kbeg + 2 * SK_BK, klast));
@@ -216,13 +192,13 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
             if (store) store_tile(std::integral_constant<int, (S + 1) % SK_D>{}, buf ^ 1);
             mma(buf, 1);
             if constexpr (decltype(store_tag)::value) {
-                constexpr int NMFMA = 2 * 6 * SK_TN;
+                constexpr int NMFMA = 2 * 6 * TNV;
 #pragma unroll
                 for (int i = 0; i < NMFMA; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // 4 VALU
-                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);     // 1 DS
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // 1 VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4 * (3 - TNV), 0); // 4 (8: half tiles have half the MFMAs for the same split) VALU
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);             // 1 DS
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);             // 1 VMEM read
                 }
             }
             __syncthreads();
@@ -239,33 +215,34 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
         k_tile(kt, S0{}, Check{});
         if (kt + 1 < nk) k_tile(kt + 1, S1{}, Check{});
         if (kt + 2 < nk) k_tile(kt + 2, S2{}, Check{});
-        }
+    }
 
-        // ---- this slice's sums: hi + lo per element, the row's sum of squares on the first lane of each 4-lane row group
+    // ---- this item's sums: hi + lo per element, the row's sum of squares on the first lane of each 4-lane row group
 #pragma unroll
-        for (int j = 0; j < SK_TN; ++j)
+    for (int j = 0; j < TNV; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hi[j][e] += lo[j][e];
-        const bool rms = (p.flags & GEMM_RMS_ROWSCALE) != 0;
-        float rsum = 0.f;
-        if (rms) {
-            rsum = ssq0 + ssq1;                        // chunks (2g) + (2g + 1)
-            rsum += dpp_f<0xB1>(rsum);                 // ((0+1)+(2+3)), ((4+5)+(6+7))
-            rsum += dpp_f<0x4E>(rsum);                 // the four lanes of a row
-        }
-        const bool row_lane = (tid % SK_G) == 0;
+        for (int e = 0; e < 16; ++e) hi[j][e] += lo[j][e];
+    const bool rms = (p.flags & GEMM_RMS_ROWSCALE) != 0;
+    float rsum = 0.f;
+    if (rms) {
+        rsum = ssq0 + ssq1;                        // chunks (2g) + (2g + 1)
+        rsum += dpp_f<0xB1>(rsum);                 // ((0+1)+(2+3)), ((4+5)+(6+7))
+        rsum += dpp_f<0x4E>(rsum);                 // the four lanes of a row
+    }
+    const bool row_lane = (tid % SK_G) == 0;
 
+    if constexpr (TNV == 2) {
         if (role == ROLE_SLICE) {
             float* w = s.ws + (int64_t)slot * SK_SLOT;
 #pragma unroll
-            for (int j = 0; j < SK_TN; ++j)
+            for (int j = 0; j < TNV; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) __hip_atomic_store(w + (j * 16 + e) * SK_NT + tid, hi[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (rms && row_lane) __hip_atomic_store(w + SK_BM * SK_BN + srow, rsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_waitcnt(0);             // every store of this thread has been acknowledged ...
             __syncthreads();                           // ... and of the workgroup
             if (tid == 0) __hip_atomic_fetch_add(s.flags + jrem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
+            return;
         }
         if (role == ROLE_FIXUP) {
             if (tid == 0) {
@@ -283,7 +260,7 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
             for (int c = 0; c < s.S; ++c) {            // slices in k order
                 const float* w = s.ws + (int64_t)(slot + c) * SK_SLOT;
 #pragma unroll
-                for (int j = 0; j < SK_TN; ++j)
+                for (int j = 0; j < TNV; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const float v = __hip_atomic_load(w + (j * 16 + e) * SK_NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + poison;
@@ -295,50 +272,140 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
                 }
             }
         }
-        if (rms) {
-            if (row_lane) rowscale_s[srow] = rsqrtf(rsum / (float)p.K + p.rms_eps);
-            __syncthreads();
-        }
+    }
+    if (rms) {
+        if (row_lane) rowscale_s[srow] = rsqrtf(rsum / (float)p.K + p.rms_eps);
+        __syncthreads();
+    }
 
-        // ---- epilogue (as gemm_x3_kernel): C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+    // ---- epilogue (as gemm_x3_kernel): C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
+    if (TNV == 1 && swiglu) {
+        // half tile = one packed column group: wave column 0 holds its 32 values, wave column 1 their 32 gates; silu(gate) crosses through LDS
+        // (the A buffers are free: the k-loop ended on a barrier)
+        float* xs = reinterpret_cast<float*>(As);                  // [128][33]
+        const int gn = bn0 + lrow;                                 // packed column of the value
+        if (wn == 1) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int lr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
-            const int gm = bm0 + lr;
-            if (gm >= p.M) continue;
-            const float rs = rms ? rowscale_s[lr] : 1.f;
-            if (swiglu) {
+            for (int e = 0; e < 16; ++e) {
+                const int lr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                float gate = hi[0][e] * (rms ? rowscale_s[lr] : 1.f);
+                if (p.bias) gate += p.bias[gn + 32];
+                xs[lr * 33 + lrow] = siluf(gate);
+            }
+        }
+        __syncthreads();
+        if (wn == 0 && gn < p.N) {
 #pragma unroll
-                for (int j = 0; j < SK_TN; j += 2) {
-                    const int gn = bn0 + wn * SK_TN * 32 + j * 32 + lrow;       // packed column of the value
-                    if (gn >= p.N) continue;
-                    float val = hi[j][e] * rs, gate = hi[j + 1][e] * rs;
-                    if (p.bias) { val += p.bias[gn]; gate += p.bias[gn + 32]; }
-                    const int on = (gn / 64) * 32 + (gn % 64);
-                    p.C[(int64_t)gm * p.ldc + on] = val * siluf(gate);
-                }
-            } else {
+            for (int e = 0; e < 16; ++e) {
+                const int lr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+                const int gm = bm0 + lr;
+                if (gm >= p.M) continue;
+                float val = hi[0][e] * (rms ? rowscale_s[lr] : 1.f);
+                if (p.bias) val += p.bias[gn];
+                const int on = (gn / 64) * 32 + (gn % 64);
+                p.C[(int64_t)gm * p.ldc + on] = val * xs[lr * 33 + lrow];
+            }
+        }
+        __syncthreads();
+        return;
+    }
 #pragma unroll
-                for (int j = 0; j < SK_TN; ++j) {
-                    const int gn = bn0 + wn * SK_TN * 32 + j * 32 + lrow;
-                    if (gn >= p.N) continue;
-                    float v = hi[j][e] * rs;
-                    if (p.bias) v += p.bias[gn];
-                    if (p.flags & GEMM_SILU) v = siluf(v);
-                    if (p.R) v += p.R[(int64_t)gm * p.ldr + gn];
-                    if (p.flags & GEMM_ACCUMULATE) v += p.C[(int64_t)gm * p.ldc + gn];
-                    p.C[(int64_t)gm * p.ldc + gn] = v;
-                    if (p.C2) {
-                        const int ts = gm % p.c2_S;
-                        const int keep = p.c2_hi - p.c2_lo;
-                        const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : ((p.c2_last && ts == p.c2_S - 1) ? keep : -1);
-                        if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + p.c2_last) + rank) * p.ldc2 + gn] = v;
-                    }
+    for (int e = 0; e < 16; ++e) {
+        const int lr = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lhalf;
+        const int gm = bm0 + lr;
+        if (gm >= p.M) continue;
+        const float rs = rms ? rowscale_s[lr] : 1.f;
+        if (swiglu) {
+            if constexpr (TNV == 2) {
+                const int gn = bn0 + wn * 64 + lrow;               // packed column of the value
+                if (gn >= p.N) continue;
+                float val = hi[0][e] * rs, gate = hi[1][e] * rs;
+                if (p.bias) { val += p.bias[gn]; gate += p.bias[gn + 32]; }
+                const int on = (gn / 64) * 32 + (gn % 64);
+                p.C[(int64_t)gm * p.ldc + on] = val * siluf(gate);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TNV; ++j) {
+                const int gn = bn0 + wn * TNV * 32 + j * 32 + lrow;
+                if (gn >= p.N) continue;
+                float v = hi[j][e] * rs;
+                if (p.bias) v += p.bias[gn];
+                if (p.flags & GEMM_SILU) v = siluf(v);
+                if (p.R) v += p.R[(int64_t)gm * p.ldr + gn];
+                if (p.flags & GEMM_ACCUMULATE) v += p.C[(int64_t)gm * p.ldc + gn];
+                p.C[(int64_t)gm * p.ldc + gn] = v;
+                if (p.C2) {
+                    const int ts = gm % p.c2_S;
+                    const int keep = p.c2_hi - p.c2_lo;
+                    const int rank = (ts >= p.c2_lo && ts < p.c2_hi) ? ts - p.c2_lo : ((p.c2_last && ts == p.c2_S - 1) ? keep : -1);
+                    if (rank >= 0) p.C2[((int64_t)(gm / p.c2_S) * (keep + p.c2_last) + rank) * p.ldc2 + gn] = v;
                 }
             }
         }
-        __syncthreads();                               // rowscale_s / fail_s are rewritten by the next item
+    }
+    __syncthreads();                                   // rowscale_s / fail_s / the LDS tiles are rewritten by the next item
+}
+
+__global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
+    const GemmArgs& p = s.p;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [2][3][BM][LD]
+    __bf16* Bs = As + 2 * 3 * SK_APL;                                 // [2][3][BN][LD]
+    float* rowscale_s = reinterpret_cast<float*>(Bs + 2 * 3 * SK_BPL);   // [BM]
+    int* fail_s = reinterpret_cast<int*>(rowscale_s + SK_BM);
+
+    const int b = blockIdx.x;
+    const int nbn = (p.N + SK_BN - 1) / SK_BN, nbm = (p.M + SK_BM - 1) / SK_BM;
+    const int nk_all = p.K / SK_BK;
+    // tile index -> (tm, tn): the XCD-aware banded walk of gemm_x3_kernel (workgroup b sits on XCD b % 8 and b + i * P keeps it)
+    auto tile_of = [&](int tile, int& tm, int& tn) {
+        int bid = tile;
+        const int nblk = nbm * nbn, nx = 8;
+        const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+        constexpr int RB = 4;
+        const int band = bid / (RB * nbn), j = bid % (RB * nbn);
+        const int rows = min(RB, nbm - band * RB);
+        tm = band * RB + j % rows; tn = j / rows;
+    };
+    int tm, tn;
+    if (s.half) {
+        // whole rounds, then the remaining tiles as 2 R half tiles: item h = (remaining tile h / 2, column half h & 1) on workgroup h % P
+        for (int i = 0; i < s.F; ++i) {
+            tile_of(b + i * s.P, tm, tn);
+            sk_item<2>(s, tm * SK_BM, tn * SK_BN, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
+        }
+        for (int h = b; h < 2 * s.R; h += s.P) {
+            tile_of(s.F * s.P + h / 2, tm, tn);
+            const int bn0 = tn * SK_BN + (h & 1) * 64;
+            if (bn0 < p.N) sk_item<1>(s, tm * SK_BM, bn0, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
+        }
+        return;
+    }
+    const int nsl = b < s.R * s.S ? 1 : 0;
+    int nfix = 0;
+    if (s.S > 1 && b >= s.P - s.nfb) {
+        const int j0 = s.P - 1 - b;
+        nfix = j0 < s.R ? (s.R - 1 - j0) / s.nfb + 1 : 0;
+    }
+    const int nitems = nsl + s.F + nfix;
+    for (int it = 0; it < nitems; ++it) {
+        int tile, kt0 = 0, kt1 = nk_all, role = ROLE_WHOLE, slot = 0, jrem = 0;
+        if (it < nsl) {
+            jrem = b % s.R;
+            const int z = b / s.R;
+            tile = s.F * s.P + jrem;
+            kt0 = (int)((int64_t)z * nk_all / s.S); kt1 = (int)((int64_t)(z + 1) * nk_all / s.S);
+            if (s.S > 1) { role = ROLE_SLICE; slot = jrem * s.S + z; }
+        } else if (it < nsl + s.F) tile = b + (it - nsl) * s.P;
+        else {
+            jrem = s.P - 1 - b + (it - nsl - s.F) * s.nfb;
+            tile = s.F * s.P + jrem; role = ROLE_FIXUP; slot = jrem * s.S;
+        }
+        tile_of(tile, tm, tn);
+        sk_item<2>(s, tm * SK_BM, tn * SK_BN, kt0, kt1, role, slot, jrem, As, Bs, rowscale_s, fail_s);
     }
 }
 
@@ -379,27 +446,40 @@ int gemm_x3sk_plan(const GemmArgs& p, int* F, int* R, int* S, int* P_out) {
     return f * nk + (r > 0 ? cdiv(nk, sl) + (sl > 1 ? 2 : 0) : 0);
 }
 
-// The shape rule (never a timing): the persistent form runs a call when cutting the last round shortens the launch by >= 10 % against
-// whole 128 x 128 tiles, the call is big enough to fill the machine, and N >= 512 (tall N = 256 products stream their A operand from
-// HBM and sit on the f32-input kernels).
-bool gemm_x3sk_rule(const GemmArgs& p) {
-    if (!gemm_x3sk_applicable(p) || p.M < 1024 || p.N < 512) return false;
-    int F, R, S, P;
-    const int len = gemm_x3sk_plan(p, &F, &R, &S, &P);
-    const int T = cdiv(p.M, SK_BM) * cdiv(p.N, SK_BN), nk = p.K / SK_BK;
-    if ((int64_t)T * nk < (int64_t)P * 12) return false;
-    return S > 1 && 10 * len <= 9 * cdiv(T, P) * nk;
+// Half tiles: the remaining tiles (at most half the workgroups) run as 2 R items of 128 x 64 after the F whole rounds
+bool gemm_x3sk_half_plan(const GemmArgs& p, int* F, int* R, int* P_out) {
+    const int P = sk_cus();
+    const int T = cdiv(p.M, SK_BM) * cdiv(p.N, SK_BN);
+    const int f = T / P, r = T - f * P;
+    *F = f; *R = r;
+    if (P_out) *P_out = P;
+    return r > 0 && 2 * r <= P;
 }
 
-int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+// The shape rule (never a timing): the persistent form with half tiles runs a call that has at least one whole round and whose last
+// round is at most half full — the 128 x 64 items then take ~0.7 of a round (measured, profiles/r03i_gemm_x3sk.txt) instead of a whole one.
+// Tall N = 256 products stream their A operand from HBM and sit on the f32-input kernels (N >= 512 here).
+bool gemm_x3sk_rule(const GemmArgs& p) {
+    if (!gemm_x3sk_applicable(p) || p.M < 1024 || p.N < 512) return false;
+    int F, R, P;
+    return gemm_x3sk_half_plan(p, &F, &R, &P) && F >= 1 && F <= 3;
+}
+
+// mode 0: half tiles where the plan allows them, else whole tiles only (the engine's form: nothing crosses between workgroups);
+// mode 1: the k-cut of the remaining tiles (slices + fix-ups through the workspace)
+int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb, int mode) {
     D4_REQUIRE(gemm_x3sk_applicable(p), "gemm_x3sk: call not supported (M=%d N=%d K=%d flags=%d batch=%d)", p.M, p.N, p.K, p.flags, p.batch);
     SkArgs a;
     a.p = p;
-    gemm_x3sk_plan(p, &a.F, &a.R, &a.S, &a.P);
-    const int T = a.F * a.P + a.R;
-    if (T < a.P && a.S == 1) a.P = T;                  // a small call: one tile per workgroup, nothing persistent
     a.ws = nullptr; a.flags = nullptr;
-    a.nfb = 0;
+    a.nfb = 0; a.half = 0;
+    if (mode == 0) {
+        a.S = 1;
+        a.half = gemm_x3sk_half_plan(p, &a.F, &a.R, &a.P) ? 1 : 0;
+    } else
+        gemm_x3sk_plan(p, &a.F, &a.R, &a.S, &a.P);
+    const int T = a.F * a.P + a.R;
+    if (T < a.P && a.S == 1 && !a.half) a.P = T;       // a small call: one tile per workgroup, nothing persistent
     if (a.S > 1) {
         const int nfree = a.P - a.R * a.S, third = cdiv(a.R, 3);
         a.nfb = nfree > third ? nfree : third;         // the workgroups without a slice take the fix-ups, up to three each; else more share them

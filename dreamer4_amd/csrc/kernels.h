@@ -73,7 +73,7 @@ bool gemm_x3sk_applicable(const GemmArgs& p);
 bool gemm_x3sk_rule(const GemmArgs& p);                    // the calls that take it (a rule on the shape and the CU count)
 int gemm_x3sk_plan(const GemmArgs& p, int* F, int* R, int* S, int* P);
 const char* gemm_x3sk_name();
-int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr, int mode = 0);   // mode 0: half tiles, 1: k-cut
 // second fp32 family (gemm2.hip): 16x16x4 MFMA fed by an LDS-DMA ring; non-transposed operands, K % 32 == 0
 bool gemm2_applicable(const GemmArgs& p);
 bool gemm2_config_valid(int c, const GemmArgs& p);

@@ -229,7 +229,9 @@ def test_gemm_split_stream_k(lib, M, N, K, flags):
     last partial round cut along k into slices that are summed in k order through agent-scope atomics.  Whole tiles keep the family's
     bits; a cut tile differs from the plain kernel by fp32 re-association at the cuts only.  Checked: error against float64 no larger
     than the plain kernel's (+ 5 %), elementwise distance to the plain kernel within a few output roundings, repeated launches
-    bit-identical (the ready flags are left cleared), every epilogue, ragged edges, and a 4-slice cut (130 x 129 x 2048)."""
+    bit-identical (the ready flags are left cleared), every epilogue, ragged edges, and a 4-slice cut (130 x 129 x 2048).
+    The half-tile mode (config 7: the last round as 128 x 64 items, SiLU-GLU value / gate waves meeting through LDS) is BIT-IDENTICAL to the
+    plain kernel."""
     g = torch.Generator(device='cuda').manual_seed(11)
     A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
     b = torch.randn(N, device='cuda', generator=g)
@@ -253,12 +255,14 @@ def test_gemm_split_stream_k(lib, M, N, K, flags):
     if accumulate:
         ref = ref + C0.double()
     outs = []
-    for cfg in (4, 6, 6, 6):
+    for cfg in (4, 6, 6, 6, 7):
         o = C0.clone() if accumulate else torch.full((M, Nout), float('nan'), device='cuda')
         _lib.check(lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, cfg, stream()))
         outs.append(o)
     torch.cuda.synchronize()
     plain, sk = outs[0], outs[1]
+    # config 7, the form the engine uses: whole rounds + a last round of 128 x 64 half tiles — every element keeps its k order
+    assert torch.equal(outs[4], plain)
     assert torch.isfinite(sk).all()
     assert torch.equal(outs[2], sk) and torch.equal(outs[3], sk)
     rms = lambda x: (x.double() - ref).pow(2).mean().sqrt().item()

@@ -31,7 +31,7 @@ for M, N, K, flags, name in shapes:
     g = torch.Generator(device='cuda').manual_seed(1)
     A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
     Nout = N // 2 if flags & SWIGLU else N
-    outs = [torch.full((M, Nout), float('nan'), device='cuda') for _ in range(3)]
+    outs = [torch.full((M, Nout), float('nan'), device='cuda') for _ in range(4)]
     b = torch.randn(N, device='cuda', generator=g)
     R = torch.randn(M, N, device='cuda', generator=g) if not (flags & SWIGLU) else None
     plane = (N * K + 7) // 8 * 8
@@ -39,7 +39,7 @@ for M, N, K, flags, name in shapes:
     _lib.check(lib.d4_split_bf16x3(_lib.ptr(W), _lib.ptr(W3), N * K, plane, s))
     native = lambda: lib.d4_gemm(_lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(outs[0]), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, EPS, s)
     split = lambda c, o: lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, EPS, c, s)
-    _lib.check(native()); _lib.check(split(4, outs[1])); _lib.check(split(6, outs[2]))
+    _lib.check(native()); _lib.check(split(4, outs[1])); _lib.check(split(6, outs[2])); _lib.check(split(7, outs[3]))
     torch.cuda.synchronize()
     again = torch.full((M, Nout), float('nan'), device='cuda')
     _lib.check(split(6, again)); torch.cuda.synchronize()
@@ -55,8 +55,9 @@ for M, N, K, flags, name in shapes:
     err = [((o.double() - ref).pow(2).mean().sqrt().item() / sc) for o in outs]
     dmax = (outs[2] - outs[1]).abs().max().item() / sc
     same_frac = (outs[2] == outs[1]).float().mean().item()
-    tn, t4, t6 = timeit(native), timeit(lambda: split(4, outs[1])), timeit(lambda: split(6, outs[2]))
+    half_same = torch.equal(outs[3], outs[1])
+    tn, t4, t6, t7 = timeit(native), timeit(lambda: split(4, outs[1])), timeit(lambda: split(6, outs[2])), timeit(lambda: split(7, outs[3]))
     fl = 2.0 * M * N * K
-    print(f'{name:9s} M{M:6d} N{N:5d} K{K:5d} f{flags}: native {tn:6.1f} us {fl / tn / 1e6:6.1f} TF | 128x128/8 {t4:6.1f} us {fl / t4 / 1e6:6.1f} TF | persistent {t6:6.1f} us '
+    print(f'{name:9s} M{M:6d} N{N:5d} K{K:5d} f{flags}: native {tn:6.1f} us {fl / tn / 1e6:6.1f} TF | 128x128/8 {t4:6.1f} us {fl / t4 / 1e6:6.1f} TF | half tiles {t7:6.1f} us {fl / t7 / 1e6:6.1f} TF (x{t4 / t7:.2f} plain, bits equal {half_same}) | k-cut {t6:6.1f} us '
           f'{fl / t6 / 1e6:6.1f} TF (x{tn / t6:.2f} native, x{t4 / t6:.2f} plain) | rms err native {err[0]:.2e} plain {err[1]:.2e} persistent {err[2]:.2e} | '
           f'max |persistent - plain| {dmax:.1e}, equal {100 * same_frac:.1f} % | repeat identical {torch.equal(again, outs[2])} finite {bool(torch.isfinite(outs[2]).all())}', flush=True)
