@@ -561,15 +561,12 @@ static int ff_backward_impl(const float* x, const float* dy, const float* norm_w
     int rc;
     if (!reuse && (rc = ff_recompute(w, x, norm_w, w_in, b_in, w_out, R, D, I, s))) return rc;
     // y = u W2^T + b2
-    if ((rc = colsum(dy, D, R, D, d_b_out, s))) return rc;
     if ((rc = gemm_dw(dy, D, w.u, Ip, w.dw2p, Ip, D, Ip, R, w.part, s))) return rc;                                    // dW2 = dy^T u
     if ((rc = copy_rows(w.dw2p, Ip, d_w_out, I, D, I, s))) return rc;
     if ((rc = gemm_dx(dy, D, w.w2p, Ip, w.du, Ip, R, Ip, D, w.wt, s))) return rc;                                        // du = dy W2
     hipLaunchKernelGGL(swiglu_bwd_kernel, grid_for((int64_t)R * Ip), dim3(256), 0, s, w.h, w.du, w.dh, R, I, Ip);
     D4_LAUNCH_CHECK();
     // h = xn W1^T + b1
-    if ((rc = colsum(w.dh, 2 * Ip, R, I, d_b_in, s))) return rc;
-    if ((rc = colsum(w.dh + Ip, 2 * Ip, R, I, d_b_in + I, s))) return rc;
     if ((rc = gemm_dw(w.dh, 2 * Ip, w.xn, D, w.dw1p, D, 2 * Ip, D, R, w.part, s))) return rc;                          // dW1 = dh^T xn
     {
         MultiCopy mc;
@@ -579,7 +576,10 @@ static int ff_backward_impl(const float* x, const float* dy, const float* norm_w
     if ((rc = gemm_dx(w.dh, 2 * Ip, w.w1p, D, w.dxn, D, R, D, 2 * Ip, w.wt, s))) return rc;                             // dxn = dh W1
     // xn = rmsnorm(x) * gamma
     if ((rc = rmsnorm_bwd(x, w.dxn, norm_w, w.tg, dx, R, D, RMS_EPS, s))) return rc;
-    return colsum(w.tg, D, R, D, d_norm_w, s);
+    // the four column sums of the block (both bias gradients, the norm gain's) in one launch: their operands are all still in place
+    ColsumBatch cb;
+    cb.add(dy, D, R, D, d_b_out); cb.add(w.dh, 2 * Ip, R, I, d_b_in); cb.add(w.dh + Ip, 2 * Ip, R, I, d_b_in + I); cb.add(w.tg, D, R, D, d_norm_w);
+    return colsum_batch(cb, s);
 }
 
 int d4_ff_backward(const float* x, const float* dy, const float* norm_w, const float* w_in, const float* b_in, const float* w_out,
@@ -660,7 +660,6 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
         hipLaunchKernelGGL(zero_pad_cols_kernel, grid_for((int64_t)R * (w.P - (3 * hd + w.hp4 + heads))), dim3(256), 0, s, w.dproj, R, w.P, 3 * hd + w.hp4 + heads, w.P);
     D4_LAUNCH_CHECK();
     if ((rc = gemm_dw(dy, D, w.o3, hd, o.d_wo, hd, D, hd, R, w.part, s))) return rc;                                     // dWo = dy^T o3
-    if ((rc = colsum(w.gpart, hd, g.groups, hd, o.d_gamma, s))) return rc;
     // projections: dW = dproj^T xn, dxn = dproj Wcat
     if ((rc = gemm_dw(w.dproj, w.P, w.xn, D, w.dwcat, D, w.P, D, R, w.part, s))) return rc;
     {
@@ -671,12 +670,13 @@ int attn_block_backward(const float* x, const float* residual_values, const floa
         if (has_rv) mc.add(o.d_wm, w.dwcat + (size_t)(3 * hd + w.hp4) * D, (int64_t)heads * D);
         if ((rc = multi_copy(mc, s))) return rc;
     }
-    if (has_rv) {
-        if ((rc = colsum(w.dproj + 3 * hd + w.hp4, w.P, R, heads, o.d_bm, s))) return rc;
-    }
     if ((rc = gemm_dx(w.dproj, w.P, w.wcat, D, w.dxn, D, R, D, w.P, w.wt, s))) return rc;
     if ((rc = rmsnorm_bwd(x, w.dxn, prm.norm_w, w.tg, o.dx, R, D, RMS_EPS, s))) return rc;
-    return colsum(w.tg, D, R, D, o.d_norm_w, s);
+    ColsumBatch cb;                                    // key gain, mix bias, norm gain: one launch
+    cb.add(w.gpart, hd, g.groups, hd, o.d_gamma);
+    if (has_rv) cb.add(w.dproj + 3 * hd + w.hp4, w.P, R, heads, o.d_bm);
+    cb.add(w.tg, D, R, D, o.d_norm_w);
+    return colsum_batch(cb, s);
 }
 
 struct XWs {
@@ -775,12 +775,15 @@ static int cross_attn_backward_impl(const float* q_tokens, const float* ctx, con
         D4_LAUNCH_CHECK();
     }
     if ((rc = gemm_dw(dy, D, w.o3, hd, d_wo, hd, D, hd, Rq, w.part, s))) return rc;
-    if ((rc = colsum(w.gpart, hd, groups, hd, d_k_gamma, s))) return rc;
     // query side
     if ((rc = gemm_dw(w.dprojq, w.Pq, w.qn, D, w.dwqg, D, w.Pq, D, Rq, w.part, s))) return rc;
     if ((rc = gemm_dx(w.dprojq, w.Pq, w.wqg, D, w.dqn, D, Rq, D, w.Pq, w.wt, s))) return rc;
     if ((rc = rmsnorm_bwd(q_tokens, w.dqn, norm_w, w.tg, d_q_tokens, Rq, D, RMS_EPS, s))) return rc;
-    if ((rc = colsum(w.tg, D, Rq, D, d_norm_w, s))) return rc;
+    {
+        ColsumBatch cb;                                // key gain and the query norm's gain: one launch
+        cb.add(w.gpart, hd, groups, hd, d_k_gamma); cb.add(w.tg, D, Rq, D, d_norm_w);
+        if ((rc = colsum_batch(cb, s))) return rc;
+    }
     // context side
     if ((rc = gemm_dw(w.dprojk, w.Pk, w.cn, Dc, w.dwkv, Dc, w.Pk, Dc, Rk, w.part, s))) return rc;
     {   // the pieces of both concatenated weight gradients in one launch

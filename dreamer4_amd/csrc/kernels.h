@@ -182,6 +182,12 @@ int swiglu_pack_rows(const float* W, const float* bias, const float* gamma, floa
 int pad_cols(const float* W, float* out, int rows, int cols, int cols_pad, hipStream_t s);
 // learn.hip: out[c] = sum_r x[r][c] (fixed order); RMSNorm backward (tg = dxhat * x * rstd, column-summed by the caller -> dgamma)
 int colsum(const float* x, int ld, int rows, int cols, float* out, hipStream_t s, float* scratch = nullptr, size_t scratch_floats = 0);
+struct ColsumBatch {                   // up to four independent column sums as one launch (learn.hip: colsum_batch)
+    enum { MAX = 4 };
+    const float* x[MAX]; int ld[MAX], rows[MAX], cols[MAX]; float* out[MAX]; int first[MAX]; int n = 0;
+    void add(const float* x_, int ld_, int rows_, int cols_, float* out_) { x[n] = x_; ld[n] = ld_; rows[n] = rows_; cols[n] = cols_; out[n] = out_; ++n; }
+};
+int colsum_batch(ColsumBatch& b, hipStream_t s);
 int rmsnorm_bwd(const float* x, const float* dxhat, const float* gamma, float* tg, float* dx, int rows, int d, float eps, hipStream_t s);
 int rmsnorm_rows(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int D, float eps, hipStream_t s);
 int layernorm_rows(const float* x, int ldx, const float* g, const float* b, float* y, int ldy, int rows, int D, float eps, int silu, hipStream_t s);

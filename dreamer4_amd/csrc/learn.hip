@@ -79,14 +79,10 @@ __global__ __launch_bounds__(1024) void reduce1_kernel(const float* a, const flo
 // column sums: out[c] = sum_r x[r][c]; block = 16 columns x 64 row lanes (4x more blocks than a 64-column block: the
 // [4096][2048] bias-gradient reductions are latency bound, not bandwidth bound), 16 loads in flight per thread (a 3840-row reduction is
 // four round trips to memory instead of eight: 14.7 -> ~8 us), fixed order
-__global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int ld, int rows_all, int cols, float* out_all, int chunk) {
-    // blockIdx.y: row chunk [y * chunk, (y + 1) * chunk) summed into row y of out (one chunk = the whole matrix in the plain form)
-    const int r_lo = blockIdx.y * chunk, rows = min(rows_all, r_lo + chunk) - r_lo;
-    x += (int64_t)r_lo * ld;
-    float* out = out_all + (int64_t)blockIdx.y * cols;
+__device__ __forceinline__ void colsum_block(const float* x, int ld, int rows, int cols, float* out, int bx) {
     __shared__ float sh[64][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = bx * 16 + cl;
     float s = 0.f;
     if (c < cols) {
         for (int r = rl; r < rows; r += 16 * 64) {
@@ -107,6 +103,26 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int ld, in
         for (int i = 0; i < 64; ++i) t += sh[i][cl];
         out[c] = t;
     }
+}
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* x, int ld, int rows_all, int cols, float* out_all, int chunk) {
+    // blockIdx.y: row chunk [y * chunk, (y + 1) * chunk) summed into row y of out (one chunk = the whole matrix in the plain form)
+    const int r_lo = blockIdx.y * chunk, rows = min(rows_all, r_lo + chunk) - r_lo;
+    colsum_block(x + (int64_t)r_lo * ld, ld, rows, cols, out_all + (int64_t)blockIdx.y * cols, blockIdx.x);
+}
+// several independent column sums in ONE launch (a block backward has three or four: bias, norm-gain and key-gain gradients — each alone is a
+// 32-block, latency-bound launch of ~14 us); same per-column arithmetic and order as colsum_kernel
+__global__ __launch_bounds__(1024) void colsum_batch_kernel(ColsumBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
+    colsum_block(b.x[i], b.ld[i], b.rows[i], b.cols[i], b.out[i], blockIdx.x - b.first[i]);
+}
+int colsum_batch(ColsumBatch& b, hipStream_t s) {
+    if (b.n == 0) return 0;
+    int nb = 0;
+    for (int i = 0; i < b.n; ++i) { b.first[i] = nb; nb += cdiv(b.cols[i], 16); }
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(nb), dim3(1024), 0, s, b);
+    D4_LAUNCH_CHECK();
+    return 0;
 }
 // scratch (optional, >= 16 * cols floats): tall matrices (the attention pools' context gradients: up to 13 x the token rows) are summed in 16
 // row chunks over 16 x the blocks, then the 16 partial rows in a second, tiny launch — fixed order either way
