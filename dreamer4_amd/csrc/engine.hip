@@ -1447,6 +1447,16 @@ int d4_rmsnorm_backward(const float* x, const float* dy, const float* gamma, flo
     return d4::colsum(scratch, dim, rows, dim, d_gamma, s);
 }
 
+// MultiCategorical.sample + log_prob of the sample (D4:485-497, 1374-1376, 1422-1423), stateless: Gumbel-max per action type from injected
+// uniforms (same shape as the logits), log-softmax gather.  action_sizes: device [na].
+int d4_categorical_sample_logp(const float* logits, int ld, const float* uniform, int ld_u, const int32_t* action_sizes, int rows, int na,
+                               float temperature, int64_t* actions, float* log_probs, void* stream) {
+    D4_REQUIRE(logits && uniform && action_sizes && actions && log_probs && rows >= 0 && na >= 1, "d4_categorical_sample_logp: bad arguments");
+    d4::SampleArgs sa{};
+    sa.logits = logits; sa.ld = ld; sa.gumbel_u = uniform; sa.ld_u = ld_u; sa.actions = actions; sa.act_stride = na; sa.log_probs = log_probs;
+    sa.lp_stride = na; sa.action_sizes = action_sizes; sa.B = rows; sa.na = na; sa.temperature = temperature;
+    return d4::sample_actions_terminals(sa, static_cast<hipStream_t>(stream));
+}
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows, int bins, void* stream) {
     return d4::hl_gauss_scalar(logits, ld, centers, out, 1, rows, bins, static_cast<hipStream_t>(stream));
 }

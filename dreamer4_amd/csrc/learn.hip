@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256) void value_loss_kernel(const float* vbins, int
     if (lane == 0) row_loss[r] = loss * mk;
 }
 
+__global__ void masked_mean_final_kernel(const float* scal, float* out) { out[0] = scal[7] / fmaxf(scal[1], 1.f); }
+
 __global__ void finalize_losses_kernel(const float* scal, float* losses, int objective, float ent_w, float kl_w) {
     // scal: [1] count, [4] sum pl, [5] sum ent, [6] sum aux(kl), [7] sum value loss
     const float count = fmaxf(scal[1], 1.f);
@@ -687,6 +689,31 @@ int d4_gae(const float* rewards, const float* values, const int64_t* lens, const
     D4_REQUIRE(rewards && values && returns, "null argument");
     hipLaunchKernelGGL(d4::gae_kernel, dim3(d4::cdiv(batch, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), rewards, values, lens,
                        is_truncated, terminals, gamma, lam, batch, time, returns, (float*)nullptr, (float*)nullptr);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// Stateless form of the value branch's loss (D4:6254-6295: HL-Gauss / two-hot targets of the returns, cross entropy against the value bins,
+// mean over the learnable steps), forward + backward in one call:  loss[0] = sum_r mask[r] * CE_r / max(sum mask, 1),  dlogits = d loss / d logits.
+// support: [bins + 1] bin edges (HL-Gauss) or [bins] bin values (two-hot), device.  mask: [rows] or null (all rows).  scratch >= 2 * rows + 64 floats.
+int d4_hl_gauss_ce(const float* logits, int ld, const float* targets, const float* mask, const float* support, int rows, int bins, float vmin,
+                   float vmax, float sigma, float eps, int two_hot, float* loss, float* dlogits, float* scratch, void* stream) {
+    D4_REQUIRE(logits && targets && support && loss && dlogits && scratch && rows >= 1 && bins >= 1 && ld >= bins, "d4_hl_gauss_ce: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* scal = scratch;                     // [64]: [1] count, [7] summed row losses
+    float* ones = scratch + 64;                // [rows]
+    float* row_loss = ones + rows;             // [rows]
+    D4_HIP(hipMemsetAsync(scal, 0, 64 * sizeof(float), s));
+    if (!mask) { if (int rc = d4::fill_f32(ones, 1.f, rows, s)) return rc; mask = ones; }
+    hipLaunchKernelGGL(d4::reduce1_kernel<d4::RED_SUM>, dim3(1), dim3(1024), 0, s, mask, (const float*)nullptr, scal, (int64_t)rows, scal + 1);
+    if (two_hot)
+        hipLaunchKernelGGL(d4::value_loss_kernel<true>, dim3(d4::cdiv(rows, 4)), dim3(256), 0, s, logits, ld, targets, mask, scal, support, rows, bins,
+                           sqrtf(2.f) * sigma, eps, vmin, vmax, dlogits, row_loss);
+    else
+        hipLaunchKernelGGL(d4::value_loss_kernel<false>, dim3(d4::cdiv(rows, 4)), dim3(256), 0, s, logits, ld, targets, mask, scal, support, rows, bins,
+                           sqrtf(2.f) * sigma, eps, vmin, vmax, dlogits, row_loss);
+    hipLaunchKernelGGL(d4::reduce1_kernel<d4::RED_SUM>, dim3(1), dim3(1024), 0, s, row_loss, (const float*)nullptr, scal, (int64_t)rows, scal + 7);
+    hipLaunchKernelGGL(d4::masked_mean_final_kernel, dim3(1), dim3(1), 0, s, scal, loss);
     D4_LAUNCH_CHECK();
     return 0;
 }

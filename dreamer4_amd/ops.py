@@ -503,3 +503,66 @@ def flow_euler_step(x: torch.Tensor, pred: torch.Tensor, one_minus_t: float, dt:
 @flow_euler_step.register_fake
 def _(x, pred, one_minus_t, dt):
     return torch.empty_like(x, dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ sampling / value loss (stateless)
+@custom_op('d4hip::categorical_sample_logp', mutates_args=())
+def categorical_sample_logp(logits: torch.Tensor, uniform: torch.Tensor, action_sizes: list[int], temperature: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """MultiCategorical.sample + log_prob of the sample (D4:485-497, 1374-1376, 1422-1423): Gumbel-max per action type from injected uniforms of the
+    logits' shape; returns (actions int64 [..., na], log_probs [..., na])."""
+    _need_gpu(logits, uniform)
+    lib = _lib.load()
+    l2 = logits.float().contiguous().view(-1, logits.shape[-1])
+    u2 = uniform.float().contiguous().view(-1, uniform.shape[-1])
+    na = len(action_sizes)
+    assert sum(action_sizes) == l2.shape[1] == u2.shape[1] and na >= 1
+    sizes = torch.tensor(action_sizes, dtype=torch.int32, device=logits.device)
+    acts = torch.empty(l2.shape[0], na, dtype=torch.long, device=logits.device)
+    lps = torch.empty(l2.shape[0], na, device=logits.device)
+    _lib.check(lib.d4_categorical_sample_logp(_lib.ptr(l2), l2.shape[1], _lib.ptr(u2), u2.shape[1], _lib.ptr(sizes), l2.shape[0], na, temperature,
+                                              _lib.ptr(acts), _lib.ptr(lps), _stream(logits)))
+    return acts.view(*logits.shape[:-1], na), lps.view(*logits.shape[:-1], na)
+
+
+@categorical_sample_logp.register_fake
+def _(logits, uniform, action_sizes, temperature):
+    na = len(action_sizes)
+    return logits.new_empty(*logits.shape[:-1], na, dtype=torch.long), logits.new_empty(*logits.shape[:-1], na, dtype=torch.float32)
+
+
+@custom_op('d4hip::hl_gauss_ce', mutates_args=())
+def hl_gauss_ce(logits: torch.Tensor, targets: torch.Tensor, mask: torch.Tensor | None, support: torch.Tensor, vmin: float, vmax: float, sigma: float,
+                eps: float, two_hot: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    """The value branch's loss (D4:6254-6295): cross entropy of `logits` against the HL-Gauss (support = bin edges) or two-hot (support = bin values)
+    encoding of `targets`, mean over the masked rows.  Returns (loss, d loss / d logits); differentiable in `logits` through the second output."""
+    _need_gpu(logits, targets, support)
+    lib = _lib.load()
+    l2 = logits.float().contiguous().view(-1, logits.shape[-1])
+    t1 = targets.float().contiguous().view(-1)
+    m1 = mask.float().contiguous().view(-1) if mask is not None else None
+    sup = support.float().contiguous()
+    rows, bins = l2.shape
+    assert t1.numel() == rows and sup.numel() == (bins if two_hot else bins + 1)
+    loss = torch.empty(1, device=logits.device)
+    dl = torch.empty_like(l2)
+    scratch = torch.empty(2 * rows + 64, device=logits.device)
+    _lib.check(lib.d4_hl_gauss_ce(_lib.ptr(l2), bins, _lib.ptr(t1), _lib.ptr(m1), _lib.ptr(sup), rows, bins, vmin, vmax, sigma, eps, int(two_hot),
+                                  _lib.ptr(loss), _lib.ptr(dl), _lib.ptr(scratch), _stream(logits)))
+    return loss.view(()), dl.view(logits.shape)
+
+
+@hl_gauss_ce.register_fake
+def _(logits, targets, mask, support, vmin, vmax, sigma, eps, two_hot):
+    return logits.new_empty((), dtype=torch.float32), torch.empty_like(logits, dtype=torch.float32)
+
+
+def _hl_ce_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+
+
+def _hl_ce_bwd(ctx, d_loss, _d_dl):
+    (dl,) = ctx.saved_tensors
+    return dl * d_loss, None, None, None, None, None, None, None, None
+
+
+hl_gauss_ce.register_autograd(_hl_ce_bwd, setup_context=_hl_ce_setup)

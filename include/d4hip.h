@@ -381,6 +381,17 @@ int d4_rmsnorm_backward(const float* x, const float* dy, const float* gamma, flo
                         void* stream);
 int d4_hl_gauss_scalar(const float* logits, int ld, const float* centers, float* out, int rows,
                        int bins, void* stream);
+/* MultiCategorical.sample + log_prob of the sample (dreamer4.py:485-497, 1374-1376, 1422-1423), stateless: Gumbel-max per action type from
+ * injected uniforms [rows][ld_u] (the layout of the logits), log-softmax gather.  action_sizes: device int32 [na].  Indices are bit-exact
+ * against the reference whenever the top-2 (logit / T + Gumbel) margin exceeds fp32 rounding. */
+int d4_categorical_sample_logp(const float* logits, int ld, const float* uniform, int ld_u, const int32_t* action_sizes, int rows, int na,
+                               float temperature, int64_t* actions, float* log_probs, void* stream);
+/* The value branch's loss, stateless (dreamer4.py:6254-6295; HLGaussLoss / SymExpTwoHot targets): HL-Gauss (two_hot = 0: support = [bins + 1] bin
+ * edges, sigma in value units) or two-hot (two_hot = 1: support = [bins] bin values) targets of `targets`, cross entropy against `logits`, mean
+ * over the rows with mask != 0 (mask null: all rows).  loss[0] and dlogits [rows][ld] = d loss / d logits in one call.
+ * scratch >= 2 * rows + 64 floats. */
+int d4_hl_gauss_ce(const float* logits, int ld, const float* targets, const float* mask, const float* support, int rows, int bins, float vmin,
+                   float vmax, float sigma, float eps, int two_hot, float* loss, float* dlogits, float* scratch, void* stream);
 int d4_gae(const float* rewards, const float* values, const int64_t* lens, const uint8_t* is_truncated,
            const uint8_t* terminals, float gamma, float lam, int batch, int time, float* returns,
            void* stream);

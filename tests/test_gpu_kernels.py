@@ -453,3 +453,61 @@ def test_torch_library_ops_run_the_hip_kernels_and_trace_without_graph_breaks(li
     tr8, te8 = tr.to(torch.uint8), (~tr).to(torch.uint8)               # (kept alive: a temporary would be freed before the launch)
     _lib.check(lib.d4_gae(_lib.ptr(r), _lib.ptr(v), _lib.ptr(lens), _lib.ptr(tr8), _lib.ptr(te8), 0.997, 0.95, 4, 7, _lib.ptr(ref2), stream()))
     assert torch.equal(out, ref2)
+
+
+@pytest.mark.parametrize('sizes,temperature', [((4,), 1.), ((3, 5, 2), 0.7), ((17,), 1.3)])
+def test_categorical_sample_logp_op_vs_oracle(lib, sizes, temperature):
+    """torch.ops.d4hip.categorical_sample_logp (d4_categorical_sample_logp): MultiCategorical.sample + log_prob, D4:485-497, 1374-1376, 1422-1423, against
+    oracle/restate.py on injected uniforms — indices bit-exact (rows whose top-2 score margin is below 1e-4 are excluded, none in practice)."""
+    from oracle import restate
+    cfg = restate.Config(dim=64, dim_latent=8, num_latent_tokens=4, num_discrete_actions=tuple(sizes))
+    g = torch.Generator().manual_seed(17)
+    logits = torch.randn(6, 37, sum(sizes), generator=g) * 2
+    u = torch.rand(6, 37, sum(sizes), generator=g)
+    ref_a = restate.sample_discrete(cfg, logits, u, temperature)
+    ref_lp = restate.discrete_log_probs(cfg, logits, ref_a)
+    acts, lps = torch.ops.d4hip.categorical_sample_logp(logits.cuda(), u.cuda(), list(sizes), temperature)
+    sc = logits / temperature - torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+    ok, o = torch.ones(6, 37, dtype=torch.bool), 0
+    for n in sizes:
+        top = sc[..., o:o + n].topk(min(2, n), dim=-1).values
+        if n > 1:
+            ok &= (top[..., 0] - top[..., 1]) > 1e-4
+        o += n
+    assert ok.float().mean() > 0.99
+    assert torch.equal(acts.cpu()[ok], ref_a[ok])
+    assert torch.allclose(lps.cpu()[ok], ref_lp[ok], atol=1e-5)
+    compiled = torch.compile(lambda l, uu: torch.ops.d4hip.categorical_sample_logp(l, uu, list(sizes), temperature), backend='eager', fullgraph=True)
+    a2, _ = compiled(logits.cuda(), u.cuda())
+    assert torch.equal(a2, acts)
+
+
+@pytest.mark.parametrize('two_hot', [False, True])
+def test_hl_gauss_ce_op_vs_oracle(lib, two_hot):
+    """torch.ops.d4hip.hl_gauss_ce (d4_hl_gauss_ce): the value branch's loss D4:6254-6295 — HL-Gauss / symexp two-hot targets, cross entropy, masked mean —
+    and its gradient, against autograd of oracle/restate.py's restatement."""
+    from oracle import restate
+    bins, vrange = 63, (-20., 20.)
+    cfg = restate.Config(dim=64, dim_latent=8, num_latent_tokens=4, reward_encoder_type='symexp_two_hot' if two_hot else 'hl_gauss')
+    g = torch.Generator().manual_seed(23)
+    logits = torch.randn(5, 40, bins, generator=g) * 2
+    returns = torch.randn(5, 40, generator=g) * (3. if two_hot else 9.)
+    mask = torch.rand(5, 40, generator=g) > 0.3
+    lr = logits.clone().requires_grad_()
+    probs = restate.symexp_two_hot(returns, vrange, bins) if two_hot else restate.hl_gauss_to_probs(cfg, returns, vrange, bins)
+    ref = (-(probs * lr.log_softmax(dim=-1)).sum(dim=-1))[mask].mean()
+    ref.backward()
+    if two_hot:
+        support, vmin, vmax = restate.symexp_bin_values(vrange, bins), float(restate.symexp_bin_values(vrange, bins)[0]), float(restate.symexp_bin_values(vrange, bins)[-1])
+    else:
+        support, vmin, vmax = restate.hl_gauss_centers(vrange, bins)[0], vrange[0], vrange[1]
+    sigma = cfg.hl_gauss_sigma_to_bin_ratio * (vrange[1] - vrange[0]) / bins
+    lg = logits.cuda().requires_grad_()
+    loss, _ = torch.ops.d4hip.hl_gauss_ce(lg, returns.cuda(), mask.cuda(), support.cuda(), vmin, vmax, sigma, cfg.hl_gauss_eps, two_hot)
+    (2. * loss).backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1., abs(ref.item()))
+    assert torch.allclose(lg.grad.cpu(), 2. * lr.grad, atol=1e-6, rtol=1e-4)
+    # no mask = every row
+    loss_all, _ = torch.ops.d4hip.hl_gauss_ce(logits.cuda(), returns.cuda(), None, support.cuda(), vmin, vmax, sigma, cfg.hl_gauss_eps, two_hot)
+    ref_all = (-(probs * logits.log_softmax(dim=-1)).sum(dim=-1)).mean()
+    assert abs(loss_all.item() - ref_all.item()) < 1e-5 * max(1., abs(ref_all.item()))
