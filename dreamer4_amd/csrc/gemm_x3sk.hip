@@ -48,7 +48,7 @@ namespace d4 {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-namespace {
+// (file-local names carry an sk_ / SK_ prefix; the kernel keeps the plain name d4::gemm_x3sk_kernel for the profiler)
 
 constexpr int SK_BM = 128, SK_BN = 128, SK_WGM = 4, SK_WGN = 2, SK_D = 3;
 constexpr int SK_BK = 32, SK_LD = SK_BK + 8, SK_NT = SK_WGM * SK_WGN * 64;
@@ -411,10 +411,10 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
 
 // one workspace (partial tiles + flags) per stream, allocated at first use outside graph capture
 struct SkWs { float* ws = nullptr; unsigned* flags = nullptr; };
-std::map<hipStream_t, SkWs> g_sk_ws;
-int g_sk_cus = 0;
+static std::map<hipStream_t, SkWs> g_sk_ws;
+static int g_sk_cus = 0;
 
-int sk_cus() {
+static int sk_cus() {
     if (g_sk_cus == 0) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -423,7 +423,6 @@ int sk_cus() {
     return g_sk_cus;
 }
 
-}  // namespace
 
 const char* gemm_x3sk_name() { return "gemm_x3sk_kernel"; }
 
