@@ -653,6 +653,48 @@ __global__ __launch_bounds__(256) void time_kv_append_kernel(TimeAttnArgs p) {
     p.cache[cols * p.H * p.Tcap * dh + off] = v;
 }
 
+// Head dim 64, four heads per wave: lane = (head of the group, feature quarter-row), a float4 of k / v / value residual per lane, so a wave
+// instruction moves 1 KB instead of 256 B and a quarter of the waves carry the same bytes (the one-head-per-wave form above is a chain of
+// 256-byte round trips: 0.36 of the HBM rate).  The key norm is a 16-lane DPP row reduction, the rotary partner (feature ^ 32) sits 8 lanes away.
+__global__ __launch_bounds__(256) void time_kv_append4_kernel(TimeAttnArgs p) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rows = p.B * p.Tq * p.S, HG = p.H >> 2;
+    if (wid >= rows * HG) return;
+    const int row = wid / HG, hg = wid % HG;
+    const int lane = threadIdx.x & 63, fg = lane & 15;
+    const int h = hg * 4 + (lane >> 4);
+    const int s = row % p.S, tq = (row / p.S) % p.Tq, b = row / (p.S * p.Tq);
+    const int hd = p.H * 64;
+    const int hl = h * 64 + 4 * fg;
+    const float* pr = p.proj + (int64_t)row * p.ldp;
+    f32x4 k = *reinterpret_cast<const f32x4*>(pr + hd + hl);
+    f32x4 v = *reinterpret_cast<const f32x4*>(pr + 2 * hd + hl);
+    const f32x4 vr = *reinterpret_cast<const f32x4*>(p.vres + (int64_t)row * p.ldv + hl);
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + hl);
+    const float w = sigmoidf(pr[3 * hd + p.H + h]);
+    const int pos = (p.t0_dev ? *p.t0_dev : p.t0) + tq;
+    const f32x4 fr = *reinterpret_cast<const f32x4*>(p.inv_freq + 4 * (fg & 7));
+    const float nrm = sqrtf(row_sum16(((k[0] * k[0] + k[1] * k[1]) + k[2] * k[2]) + k[3] * k[3]));
+    const float den = fmaxf(nrm, 1e-12f);
+    f32x4 ko;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = lerp_torch(v[e], vr[e], w);
+        const float kn = k[e] / den * ((g4[e] + 1.f) * 8.f);
+        const float partner = __shfl_xor(kn, 8);                   // feature ^ 32: the other half of the head
+        const float half = fg < 8 ? -partner : partner;
+        float sn, cs;
+        sincosf((float)pos * fr[e], &sn, &cs);
+        ko[e] = kn * cs + half * sn;
+    }
+    const int cS = p.cache_S > 0 ? p.cache_S : p.S;
+    const int64_t col = (int64_t)b * cS + s;
+    const int64_t cols = (int64_t)p.cache_batch * cS;
+    const int64_t off = ((col * p.H + h) * p.Tcap + pos) * 64 + 4 * fg;
+    *reinterpret_cast<f32x4*>(p.cache + off) = ko;
+    *reinterpret_cast<f32x4*>(p.cache + cols * p.H * p.Tcap * 64 + off) = v;
+}
+
 template <int DH>
 __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -836,7 +878,12 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     if (waves == 0) return 0;
     // algorithmic bytes: k, v, value residual read from the projection rows; K and V written into the cache
     const double ka_bytes = 4.0 * waves * p.dh * 5.0;
-    if (p.dh == 64) D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    static const bool one_head = getenv("D4_KV_APPEND_LEGACY") != nullptr;         // the one-head-per-wave form
+    const bool al4 = (p.ldp % 4) == 0 && (p.ldv % 4) == 0 && ((uintptr_t)p.proj % 16) == 0 && ((uintptr_t)p.vres % 16) == 0 && ((uintptr_t)p.cache % 16) == 0 &&
+                     ((uintptr_t)p.k_gamma % 16) == 0 && ((uintptr_t)p.inv_freq % 16) == 0 && (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
+    if (p.dh == 64 && (p.H % 4) == 0 && al4 && !one_head)
+        D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append4_kernel, dim3(cdiv(waves / 4, 4)), dim3(256), 0, stream, p);
+    else if (p.dh == 64) D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else if (p.dh == 32) hipLaunchKernelGGL(time_kv_append_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(time_kv_append_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
