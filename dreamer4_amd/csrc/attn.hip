@@ -872,6 +872,81 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
     }
 }
 
+// Cached decode over a SHORT history (<= TA_FEW keys: the first frames of a rollout), head dim 64: four heads per wave — lane = (head of the
+// group, feature quarter-row) — and the few keys walked in sequence, all K / V rows requested before anything depends on them.  The four-keys-per-
+// pass kernel above leaves three quarters of its lanes idle at t < 4 and runs one wave per head: 32 us per launch at t = 0 for 15 MB.
+constexpr int TA_FEW = 4;
+__global__ __launch_bounds__(256) void time_attn64_few_kernel(TimeAttnArgs p) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int HG = p.H >> 2;
+    if (wid >= p.B * p.S * HG) return;
+    const int hg = wid % HG, s = (wid / HG) % p.S, b = wid / (HG * p.S);
+    const int lane = threadIdx.x & 63, fg = lane & 15;
+    const int h = hg * 4 + (lane >> 4);
+    const int pos = p.t0;                                                      // host-known (the launcher takes this kernel only then), Tq == 1
+    const int hd = p.H * 64;
+    const int cS = p.cache_S > 0 ? p.cache_S : p.S;
+    const int64_t col = (int64_t)b * cS + s, cols = (int64_t)p.cache_batch * cS;
+    const f32x4* ck = reinterpret_cast<const f32x4*>(p.cache + ((col * p.H + h) * p.Tcap) * 64) + fg;
+    const f32x4* cv = reinterpret_cast<const f32x4*>(p.cache + cols * p.H * p.Tcap * 64 + ((col * p.H + h) * p.Tcap) * 64) + fg;
+    const int row = b * p.S + s;
+    const float* pr = p.proj + (int64_t)row * p.ldp;
+    f32x4 q4 = *reinterpret_cast<const f32x4*>(pr + h * 64 + fg * 4);
+    const float gate_logit = pr[3 * hd + h];
+    f32x4 k4[TA_FEW], v4[TA_FEW];
+#pragma unroll
+    for (int j = 0; j < TA_FEW; ++j) {
+        const bool ok = j <= pos;
+        k4[j] = ok ? ck[j * 16] : f32x4{0.f, 0.f, 0.f, 0.f};
+        v4[j] = ok ? cv[j * 16] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+        const f32x4 fr = *reinterpret_cast<const f32x4*>(p.inv_freq + 4 * (fg & 7));
+        f32x4 part;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[e] = __shfl_xor(q4[e], 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sn, cs;
+            sincosf((float)pos * fr[e], &sn, &cs);
+            q4[e] = q4[e] * cs + (fg < 8 ? -part[e] : part[e]) * sn;
+        }
+    }
+    float sc[TA_FEW], m = -FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < TA_FEW; ++j) {
+        float d = row_sum16(q4[0] * k4[j][0] + q4[1] * k4[j][1] + q4[2] * k4[j][2] + q4[3] * k4[j][3]) * 0.125f;
+        if (p.softclamp > 0.f) d = tanhf(d / p.softclamp) * p.softclamp;
+        sc[j] = j <= pos ? d : -FLT_MAX;
+        m = fmaxf(m, sc[j]);
+    }
+    float l = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TA_FEW; ++j) {
+        if (j <= pos) {
+            const float e_ = expf(sc[j] - m);
+            l += e_;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += e_ * v4[j][e];
+        }
+    }
+    f32x4 vi = v4[0];                                                          // this step's (mixed) value row = key `pos`
+#pragma unroll
+    for (int j = 1; j < TA_FEW; ++j) if (j == pos) vi = v4[j];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = acc[e] / l;
+    // belief: orthogonalise against this step's (mixed) value            D4:2049-2054
+    const float vn2 = row_sum16(vi[0] * vi[0] + vi[1] * vi[1] + vi[2] * vi[2] + vi[3] * vi[3]);
+    const float inv = 1.f / fmaxf(sqrtf(vn2), 1e-12f);
+    const float dot = row_sum16(o[0] * vi[0] + o[1] * vi[1] + o[2] * vi[2] + o[3] * vi[3]) * inv;
+    const float gate = sigmoidf(gate_logit);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (o[e] - dot * (vi[e] * inv)) * gate;
+    *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.ldo + h * 64 + fg * 4) = o;
+}
+
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.t0 + p.Tq <= p.Tcap, "time attention: cache capacity %d exceeded (t0=%d, Tq=%d)", p.Tcap, p.t0, p.Tq);
     const int waves = p.B * p.Tq * p.S * p.H;
@@ -898,7 +973,12 @@ int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
         const int units = p.B * p.S * p.H;
         // algorithmic bytes (cached decode): the K and V of frames 0..t0 of every (column, head) read once + q read + out written
         const double ta_bytes = 4.0 * units * 64.0 * (2.0 * (p.t0 + 1) + 2.0);
-        if (p.Tq == 1) D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
+        static const bool no_few = getenv("D4_TIME_ATTN_FEW") && atoi(getenv("D4_TIME_ATTN_FEW")) == 0;
+        const bool al4 = ((uintptr_t)p.proj % 16) == 0 && ((uintptr_t)p.cache % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.inv_freq % 16) == 0 &&
+                         (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
+        if (p.Tq == 1 && !p.t0_dev && p.t0 < TA_FEW && (p.H % 4) == 0 && al4 && !no_few)      // a short history: four heads per wave
+            D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
+        else if (p.Tq == 1) D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
         else {
             // one block per (column, head): min(Tq, 4) waves = query frames, the chunk's K / V staged once in LDS
             const int nwv = p.Tq < 4 ? p.Tq : 4;
