@@ -42,6 +42,7 @@
 #include <hip/hip_ext.h>
 #include "kernels.h"
 #include <map>
+#include <mutex>
 #include <type_traits>
 
 namespace d4 {
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
     }
 }
 
-// one workspace (partial tiles + flags) per stream, allocated at first use outside graph capture
+// one workspace (partial tiles + counters, 17 MB) per stream for the k-cut mode ONLY, allocated at its first use outside graph capture and kept for
+// the life of the process (the half-tile mode the engine uses allocates nothing)
 struct SkWs { float* ws = nullptr; unsigned* flags = nullptr; };
 static std::map<hipStream_t, SkWs> g_sk_ws;
 static int g_sk_cus = 0;
@@ -482,6 +484,8 @@ int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
     if (a.S > 1) {
         const int nfree = a.P - a.R * a.S, third = cdiv(a.R, 3);
         a.nfb = nfree > third ? nfree : third;         // the workgroups without a slice take the fix-ups, up to three each; else more share them
+        static std::mutex ws_mu;                       // d4_gemm_split reaches this without the dispatcher's lock
+        std::lock_guard<std::mutex> lock(ws_mu);
         SkWs& w = g_sk_ws[stream];
         if (!w.ws) {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
