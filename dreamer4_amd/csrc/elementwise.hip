@@ -228,10 +228,67 @@ __global__ void assemble_kernel(AssembleArgs p) {
         }
     }
 }
+// the same, four features per thread (16-byte loads / stores, one set of index divisions per four elements): D % 8 == 0, 16-byte aligned tables
+__global__ __launch_bounds__(256) void assemble4_kernel(AssembleArgs p) {
+    const int D4 = p.D / 4;
+    const int64_t n4 = (int64_t)p.B * p.Tq * p.S * D4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D4) * 4;
+        const int s = (int)((i / D4) % p.S);
+        const int64_t f = i / ((int64_t)D4 * p.S);        // frame index (b * Tq + t)
+        const int b = (int)(f / p.Tq);
+        auto ld4 = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (s == 0) {
+            const int half = p.D / 2;
+            v = d < half ? ld4(p.signal_embed + (int64_t)(p.signal_levels ? p.signal_levels[f] : p.signal_uniform) * half + d)
+                         : ld4(p.step_embed + (int64_t)p.step_log2 * half + (d - half));
+        } else if (s <= p.ns) {
+            v = ld4(p.space + (f * p.ns + (s - 1)) * p.D + d);
+        } else if (s <= p.ns + p.nr) {
+            v = ld4(p.registers + (int64_t)(s - 1 - p.ns) * p.D + d);
+        } else if ((p.na > 0 || p.nc > 0) && s == p.ns + p.nr + 1) {
+            const bool have = p.na > 0 ? (p.prev_actions && p.prev_actions[f * p.na] >= 0) : (p.prev_cont && p.prev_cont[f * p.nc] == p.prev_cont[f * p.nc]);
+            if (have) {
+                for (int a = 0; a < p.na; ++a) {
+                    const f32x4 e = ld4(p.action_embed + (p.prev_actions[f * p.na + a] + p.action_offsets[a]) * p.D + d);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] += e[c];
+                }
+                if (p.prev_cont)
+                    for (int c = 0; c < p.nc; ++c) {
+                        const f32x4 e = ld4(p.cont_embed + (int64_t)c * p.D + d);
+                        const float x = p.prev_cont[f * p.nc + c];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += e[q] * x;
+                    }
+                const f32x4 e = ld4(p.action_learned + d);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += e[c];
+            }
+        } else {
+            v = ld4(p.agent_embed + d);
+            if (p.tasks) {
+                const f32x4 e = ld4(p.task_embed + p.tasks[b] * p.D + d);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] += e[c];
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.tokens + i * 4) = v;
+        if (p.compact) {
+            const int rank = (s >= 1 && s <= p.ns) ? s - 1 : ((p.has_agent && s == p.S - 1) ? p.ns : -1);
+            if (rank >= 0) *reinterpret_cast<f32x4*>(p.compact + (f * (p.ns + p.has_agent) + rank) * p.D + d) = v;
+        }
+    }
+}
 int assemble_tokens(const AssembleArgs& p, hipStream_t s) {
     const int64_t n = (int64_t)p.B * p.Tq * p.S * p.D;
     if (n == 0) return 0;
-    D4_GLUE_LAUNCH(GL_ASSEMBLE, 4.0 * (double)n + 4.0 * p.B * p.Tq * p.ns * p.D, assemble_kernel, grid1d(n), dim3(256), 0, s, p);
+    auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    const bool vec = (p.D % 8) == 0 && al(p.tokens) && al(p.compact) && al(p.signal_embed) && al(p.step_embed) && al(p.space) && al(p.registers) &&
+                     al(p.action_embed) && al(p.cont_embed) && al(p.action_learned) && al(p.agent_embed) && al(p.task_embed);
+    if (vec) D4_GLUE_LAUNCH(GL_ASSEMBLE, 4.0 * (double)n + 4.0 * p.B * p.Tq * p.ns * p.D, assemble4_kernel, grid1d(n / 4), dim3(256), 0, s, p);
+    else D4_GLUE_LAUNCH(GL_ASSEMBLE, 4.0 * (double)n + 4.0 * p.B * p.Tq * p.ns * p.D, assemble_kernel, grid1d(n), dim3(256), 0, s, p);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -253,9 +310,52 @@ __global__ __launch_bounds__(256) void gather_space_kernel(const float* tokens, 
     float* yr = out + (int64_t)r * D;
     for (int c = lane; c < D; c += 64) yr[c] = (xr[c] * r0 * g0[c]) * r1 * g1[c];
 }
+// the same with the row held in registers (ITER float4 per lane: D = 256 ITER), one read of the row instead of three
+template <int ITER>
+__global__ __launch_bounds__(256) void gather_space4_kernel(const float* tokens, float* out, const float* g0, const float* g1,
+                                                            int frames, int S, int first, int ns, float eps) {
+    constexpr int D = 256 * ITER;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= frames * ns) return;
+    const int lane = threadIdx.x & 63;
+    const int f = r / ns, j = r % ns;
+    const float* xr = tokens + ((int64_t)f * S + first + j) * D;
+    f32x4 x[ITER], a[ITER], b[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        x[k] = *reinterpret_cast<const f32x4*>(xr + k * 256 + lane * 4);
+        a[k] = *reinterpret_cast<const f32x4*>(g0 + k * 256 + lane * 4);
+        b[k] = *reinterpret_cast<const f32x4*>(g1 + k * 256 + lane * 4);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += x[k][e] * x[k][e];
+    const float r0 = rsqrtf(wave_sum(ss) / (float)D + eps);
+    float ss1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[k][e] = x[k][e] * r0 * a[k][e]; ss1 += x[k][e] * x[k][e]; }
+    const float r1 = rsqrtf(wave_sum(ss1) / (float)D + eps);
+    float* yr = out + (int64_t)r * D;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = x[k][e] * r1 * b[k][e];
+        *reinterpret_cast<f32x4*>(yr + k * 256 + lane * 4) = y;
+    }
+}
 int gather_space_double_norm(const float* tokens, float* out, const float* g0, const float* g1,
                              int frames, int S, int first, int D, int ns, float eps, hipStream_t s) {
     if (frames == 0) return 0;
+    const bool al = ((uintptr_t)tokens % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)g0 % 16) == 0 && ((uintptr_t)g1 % 16) == 0;
+    if (al && D == 512) hipLaunchKernelGGL(gather_space4_kernel<2>, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, first, ns, eps);
+    else if (al && D == 1024) hipLaunchKernelGGL(gather_space4_kernel<4>, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, first, ns, eps);
+    else if (al && D == 256) hipLaunchKernelGGL(gather_space4_kernel<1>, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, first, ns, eps);
+    else
     hipLaunchKernelGGL(gather_space_kernel, dim3(cdiv(frames * ns, 4)), dim3(256), 0, s, tokens, out, g0, g1, frames, S, first, D, ns, eps);
     D4_LAUNCH_CHECK();
     return 0;
@@ -539,7 +639,16 @@ __global__ void mean_tokens_kernel(const float* x, float* out, int B, int n, int
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(i / d), c = (int)(i % d);
         float s = 0.f;
-        for (int j = 0; j < n; ++j) s += x[((int64_t)b * n + j) * d + c];
+        const float* xb = x + (int64_t)b * n * d + c;
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {                      // eight loads in flight, summed in token order (the order is part of the result)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xb[(int64_t)(j + u) * d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; j < n; ++j) s += xb[(int64_t)j * d];
         out[i] = s / (float)n;
     }
 }
