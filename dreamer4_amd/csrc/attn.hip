@@ -872,10 +872,11 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
     }
 }
 
-// Cached decode over a SHORT history (<= TA_FEW keys: the first half of a 15-frame horizon; measured 4 / 8 / 16: 39.0 / 36.8 / 39.7 us averaged over the horizon), head dim 64: four heads per wave — lane = (head of the
+// Cached decode over a SHORT history (<= TA_FEW keys; one instantiation for up to 8 keys, one for 9 .. 16: a single 16-key form measured slower on the
+// first frames — 4 / 8 / 16 keys for every frame: 39.0 / 36.8 / 39.7 us averaged over a 15-frame horizon), head dim 64: four heads per wave — lane = (head of the
 // group, feature quarter-row) — and the few keys walked in sequence, all K / V rows requested before anything depends on them.  The four-keys-per-
 // pass kernel above leaves three quarters of its lanes idle at t < 4 and runs one wave per head: 32 us per launch at t = 0 for 15 MB.
-constexpr int TA_FEW = 8;
+template <int TA_FEW>
 __global__ __launch_bounds__(256) void time_attn64_few_kernel(TimeAttnArgs p) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int HG = p.H >> 2;
@@ -976,8 +977,10 @@ int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
         static const bool no_few = getenv("D4_TIME_ATTN_FEW") && atoi(getenv("D4_TIME_ATTN_FEW")) == 0;
         const bool al4 = ((uintptr_t)p.proj % 16) == 0 && ((uintptr_t)p.cache % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.inv_freq % 16) == 0 &&
                          (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
-        if (p.Tq == 1 && !p.t0_dev && p.t0 < TA_FEW && (p.H % 4) == 0 && al4 && !no_few)      // a short history: four heads per wave
-            D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
+        if (p.Tq == 1 && !p.t0_dev && p.t0 < 8 && (p.H % 4) == 0 && al4 && !no_few)           // a short history: four heads per wave
+            D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel<8>, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
+        else if (p.Tq == 1 && !p.t0_dev && p.t0 < 16 && (p.H % 4) == 0 && al4 && !no_few)
+            D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel<16>, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
         else if (p.Tq == 1) D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
         else {
             // one block per (column, head): min(Tq, 4) waves = query frames, the chunk's K / V staged once in LDS
