@@ -302,9 +302,11 @@ def _ff(W, pre, x):
 
 
 def _pool(W, pre, x, hiddens):
-    """Residual(AttentionPool) (dreamer4.py:2143-2177 + 1869): one query per token over the stack of layer hiddens."""
+    """Residual(AttentionPool) (dreamer4.py:2143-2177 + 1869): one query per token over the stack of layer hiddens.
+    hiddens: a list of layer hiddens, or the stack itself (L, rows, D) — `transformer` grows ONE stack by concatenation, so that in the
+    backward every pool's context gradient meets the previous pools' as one (L, rows, D) sum instead of L per-hidden sums per pool."""
     shape = x.shape
-    ctx = torch.stack([h.reshape(-1, shape[-1]) for h in hiddens], dim=0)                 # (L, rows, D): item major
+    ctx = hiddens if torch.is_tensor(hiddens) else torch.stack([h.reshape(-1, shape[-1]) for h in hiddens], dim=0)     # (L, rows, D): item major
     p = pre + 'fn.attn.'
     nw, wq, wk, wv, wo, wg, gam = _attn_w(W, p)
     out = cross_attention(x.reshape(-1, 1, shape[-1]), ctx, nw, W[p + 'norm_context.weight'], wq, wk, wv, wo, wg, gam, context_item_major=True)
@@ -324,7 +326,7 @@ def transformer(W, tokens, *, is_time, softclamp_value=50., num_special=1, pre='
     eps = torch.finfo(torch.float32).eps
     vres = _norm_linear(tokens, W[pre + 'to_value_residual.0.weight'], W[pre + 'to_value_residual.1.weight'])
     vres = vres.reshape(b, t, s, h, dh)
-    hiddens = [tokens]
+    hiddens = tokens.reshape(1, -1, d)                    # the growing stack (L, rows, D) of layer hiddens
     depth = len(is_time)
     for i, tl in enumerate(is_time):
         ap = f'{pre}layers.{i}.2.fn.'
@@ -337,9 +339,9 @@ def transformer(W, tokens, *, is_time, softclamp_value=50., num_special=1, pre='
             out = space_attention(tokens.reshape(b * t, s, d), nw, wq, wk, wv, wo, wg, gam, residual_values=vres.reshape(b * t, s, h, dh),
                                   mix_weight=mw, mix_bias=mb, softclamp_value=softclamp_value, num_special=num_special).reshape(b, t, s, d)
         tokens = tokens + out
-        hiddens.append(tokens)
+        after_attn = tokens
         tokens = tokens + _ff(W, f'{pre}layers.{i}.3.fn.', tokens)
-        hiddens.append(tokens)
+        hiddens = torch.cat((hiddens, after_attn.reshape(1, -1, d), tokens.reshape(1, -1, d)), dim=0)
         if i != depth - 1:
             tokens = _pool(W, f'{pre}attn_pools.{i}.', tokens, hiddens)
     # the special tokens cross-attend the ordinary tokens of their frame, then their own feedforward   dreamer4.py:3227-3238
