@@ -593,9 +593,13 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     if (p.M == 0) return 0;
     dim3 grid(cdiv(p.M, 4)), block(256);
     static const bool rows_on = !(getenv("D4_POOL_MIX_ROWS") && atoi(getenv("D4_POOL_MIX_ROWS")) == 0);
-    if (p.M <= 64 && p.D <= 512 && rows_on) {            // few rows: one block per row (by M alone)
+    // one block per row (its four waves split the hiddens) while that leaves the CUs short of waves — by M alone: measured at B = 256, L = 13:
+    // M = 1280 (the final stage's compacted rows) 24.1 -> 14.3 us, M = 3584 25.3 -> 27.8 us (the wave-per-row form wins once it fills the chip)
+    static const int rows_max = getenv("D4_POOL_MIX_ROWS_MAX") ? atoi(getenv("D4_POOL_MIX_ROWS_MAX")) : 2048;
+    if (p.M <= rows_max && p.D <= 512 && rows_on) {
+        const double rb = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
         if (p.D <= 256) hipLaunchKernelGGL(pool_mix_rows_kernel<1>, dim3(p.M), block, 0, stream, p);
-        else hipLaunchKernelGGL(pool_mix_rows_kernel<2>, dim3(p.M), block, 0, stream, p);
+        else D4_GLUE_LAUNCH(GL_POOL_MIX, rb, pool_mix_rows_kernel<2>, dim3(p.M), block, 0, stream, p);
         D4_LAUNCH_CHECK();
         return 0;
     }
