@@ -378,6 +378,18 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
             tile_of(b + i * s.P, tm, tn);
             sk_item<2>(s, tm * SK_BM, tn * SK_BN, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
         }
+        // remaining tile j's two halves go to workgroups j and R8 + j (R8 = R rounded up to 8): both sit on XCD j % 8, the XCD whose L2 the banded
+        // walk gave tile F P + j's neighbours to (with h / 2 on workgroup h the halves landed on other XCDs: +18 MB of fabric reads per launch)
+        const int R8 = (s.R + 7) & ~7;
+        if (R8 + s.R <= s.P) {
+            const int j = b < s.R ? b : b - R8, half = b < s.R ? 0 : 1;
+            if (j >= 0 && j < s.R && (b < s.R || b >= R8)) {
+                tile_of(s.F * s.P + j, tm, tn);
+                const int bn0 = tn * SK_BN + half * 64;
+                if (bn0 < p.N) sk_item<1>(s, tm * SK_BM, bn0, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
+            }
+            return;
+        }
         for (int h = b; h < 2 * s.R; h += s.P) {
             tile_of(s.F * s.P + h / 2, tm, tn);
             const int bn0 = tn * SK_BN + (h & 1) * 64;
