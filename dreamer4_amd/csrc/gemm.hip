@@ -839,8 +839,10 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         // Round 3, late: the persistent form (gemm_x3sk.hip) runs the whole rounds of a launch as before and a last round that is at most
         // half full as 128 x 64 half tiles (bit-identical; nothing crosses between workgroups).  gemm_x3sk_rule names the calls: at cfg 2
         // the SiLU-GLU input projection of the denoising evaluations (616 tiles = 2 rounds + 104).  D4_GEMM_X3SK=0: never.
-        static const bool sk_on = !(getenv("D4_GEMM_X3SK") && atoi(getenv("D4_GEMM_X3SK")) == 0);
-        if (sk_on && mode >= 1 && g_forced_cfg < 0 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p) && gemm_x3sk_rule(p))
+        static const int sk_mode = getenv("D4_GEMM_X3SK") ? atoi(getenv("D4_GEMM_X3SK")) : 1;      // 2 (experiment): every split-operand call of >= 1024 rows on the persistent form
+        const bool sk_on = sk_mode != 0;
+        if (sk_on && mode >= 1 && g_forced_cfg < 0 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p) &&
+            (gemm_x3sk_rule(p) || (sk_mode == 2 && gemm_x3sk_applicable(p) && p.M >= 1024)))
             return launch_v3sk(p, stream);
         const bool preferred = mode >= 2 || (mode == 1 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && p.M >= 256);
         if (preferred && gemm_x3_applicable(p) && !gemm_skinny_applicable(p)) return gemm_v3(p, stream);
