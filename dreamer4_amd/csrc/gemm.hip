@@ -844,6 +844,9 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         if (sk_on && mode >= 1 && g_forced_cfg < 0 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p) &&
             (gemm_x3sk_rule(p) || (sk_mode == 2 && gemm_x3sk_applicable(p) && p.M >= 1024)))
             return launch_v3sk(p, stream);
+        // 3 (experiment): also the long-K output projections (SiLU-GLU output: N = 512, K = 1376) as half tiles on 224 CUs
+        if (sk_mode == 3 && g_forced_cfg < 0 && p.K >= 1024 && p.N >= 512 && p.M >= 2048 && !gemm_skinny_applicable(p) && gemm_x3sk_applicable(p))
+            return launch_v3sk(p, stream);
         const bool preferred = mode >= 2 || (mode == 1 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && p.M >= 256);
         if (preferred && gemm_x3_applicable(p) && !gemm_skinny_applicable(p)) return gemm_v3(p, stream);
         GemmArgs q = p;
