@@ -839,7 +839,10 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         // Round 3, late: the persistent form (gemm_x3sk.hip) runs the whole rounds of a launch as before and a last round that is at most
         // half full as 128 x 64 half tiles (bit-identical; nothing crosses between workgroups).  gemm_x3sk_rule names the calls: at cfg 2
         // the SiLU-GLU input projection of the denoising evaluations (616 tiles = 2 rounds + 104).  D4_GEMM_X3SK=0: never.
-        static const int sk_mode = getenv("D4_GEMM_X3SK") ? atoi(getenv("D4_GEMM_X3SK")) : 1;      // 2 (experiment): every split-operand call of >= 1024 rows on the persistent form
+        // Every split-operand call of >= 1024 rows runs on the persistent form (default 2; 1 = only the calls whose last round becomes half tiles):
+        // same-box A/B pairs (profiles/r03l_ab_late_changes.txt) put the step at 188.8 / 191.8-192.4 / 199.3-200.0 ms for 2 / 1 / 0 on a mid-speed box
+        // and 181.1-181.6 / 180.2-180.4 / 180.0 ms on the fastest one seen — the balanced end of a persistent launch is what the FOLLOWING kernels gain from.
+        static const int sk_mode = getenv("D4_GEMM_X3SK") ? atoi(getenv("D4_GEMM_X3SK")) : 2;
         const bool sk_on = sk_mode != 0;
         if (sk_on && mode >= 1 && g_forced_cfg < 0 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p) &&
             (gemm_x3sk_rule(p) || (sk_mode == 2 && gemm_x3sk_applicable(p) && p.M >= 1024)))
