@@ -22,7 +22,11 @@
 // dispatched in index order: no residency assumption, no deadlock.  The wait is bounded all the same (a lost counter poisons the tile
 // with NaN instead of hanging the queue).  The fix-up clears the counter it consumed: a launch leaves the counters zero.
 //
-// HALF TILES (the form the engine uses): when the remaining tiles number at most half the workgroups, they are not cut along k but along N — 2 R
+// IN THE ENGINE every split-operand call of >= 1024 rows runs here (gemm.hip; D4_GEMM_X3SK): whole tiles walked by 256 long-lived workgroups are
+// bit-identical to gemm_x3_kernel and, measured in situ on mid-speed boxes, leave the FOLLOWING kernels ~3-4 % faster than 476-660 short-lived
+// 120 KB workgroups do (profiles/r03l_ab_late_changes.txt: 188 / 191 / 199 ms per step for all calls / half-tile calls only / none).
+//
+// HALF TILES: when the remaining tiles number at most half the workgroups, they are not cut along k but along N — 2 R
 // work items of 128 x 64 (the 8 waves as 4 x 2 with 32 x 32 wave tiles; a SiLU-GLU column group is one such item: its value wave and its
 // gate wave meet through LDS in the epilogue), one per workgroup, after the whole rounds.  Nothing is exchanged between workgroups and
 // every element keeps its k order: bit-identical to gemm_x3_kernel, 2.4 rounds -> 2 rounds + one shorter one (a half tile takes ~0.88 of a
