@@ -13,11 +13,12 @@ Weights: default init of that architecture under torch.manual_seed(0) with non-t
 the timed region.  Rank 0 prints ONE JSON line.
 
   value        = N * B * (H+1) * K / wall     imagined steps per second over the WHOLE step (rollout + learner)
-  roofline     = the dominant kernel (the fp32 MFMA GEMM tile configuration with the largest share of GPU time, found in the
-                 warm-up step): algorithmic flops of its launches in the timed region / their summed HIP-event durations,
-                 against the 157.3 TFLOP/s fp32 matrix peak
+  roofline     = the dominant kernel (the GEMM class with the largest share of GPU time, found in an extra event-timed step before the
+                 timed region): algorithmic flops of its launches / their summed HIP-event durations in an event-timed REPEAT of the timed
+                 steps right after the timed region (events cannot ride inside replayed hipGraphs; the timed region is the default path),
+                 against the 157.3 TFLOP/s fp32 matrix peak (2500 / 6 for a split-operand class)
   glue_kernels_hbm = the non-GEMM kernel classes of the rollout (attention cores, KV append, pool mix, ...): ALGORITHMIC bytes of
-                 their launches in the last warm-up step / their HIP-event durations, against the 8 TB/s HBM peak — measured live
+                 their launches in the extra event-timed step / their HIP-event durations, against the 8 TB/s HBM peak — measured live
                  in this process (d4_profile_glue_*), not replayed from a file
   cpu_baseline = the CPU oracle (oracle/restate.py, torch fp32) running the FULL workload once on 16 host threads, rank 0 at N=1
                  only; cpu_baseline_sharded = the same workload sharded by trajectory over 16 processes x 4 threads (the best sharded form measured; the fair
@@ -42,7 +43,7 @@ CFG2 = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8,
             num_spatial_tokens=4, num_register_tokens=8, max_steps=64, multi_token_pred_len=8, num_discrete_actions=4)
 B_LOCAL, HORIZON, NUM_STEPS = 256, 15, 4
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
-EVENT_STRIDE = 7                       # timed region: every 7th launch of the dominant GEMM configuration carries an event pair (7 is co-prime to the ~30-launch per-evaluation pattern, so every shape is sampled)
+EVENT_STRIDE = 7                       # roofline pass: every 7th launch of the dominant GEMM configuration carries an event pair (7 is co-prime to the ~30-launch per-evaluation pattern, so every shape is sampled)
 FLOP_PER_IMAGINED_STEP = 5.23e9        # GEMM flops per generated frame of one trajectory (cfg 2)
 
 
@@ -274,45 +275,44 @@ def main():
     is_split = [n.startswith(('gemm_x3_kernel', 'gemm_x3sk_kernel')) for n in raw_names]     # fp32 GEMM on the bf16 matrix cores: split operands, 6 bf16 MFMA products per fp32 product
     names = [n + ((' (persistent 128 x 128 / 128 x 64 form)' if n.startswith('gemm_x3sk') else ', *>') + ' fp32 by split operands on the bf16 MFMA' if sp else ', *> fp32 MFMA')
              for n, sp in zip(raw_names, is_split)]
-    # warm-up: first-use tile autotuning of every GEMM shape happens here; the last warm-up step is also used to find the
-    # dominant tile configuration (all configurations event-timed), so that the timed region only carries events for it
+    # warm-up: first-use tile autotuning of every GEMM shape and the capture of the decode frames' hipGraphs happen here
     dom, dom2, warm_classes, warm_exec, glue_measured, fused_flops = None, None, None, (0., 0.), None, 0.
     for w in range(args.warmup):
-        last = timing and w == args.warmup - 1
-        if last:
-            torch.cuda.synchronize()
-            lib.d4_profile_enable((1 << ncls) - 1)
-            lib.d4_profile_glue_enable((1 << lib.d4_profile_glue_classes()) - 1)
+        trainer.train_step()                             # the default path: tile autotuning at first use, the decode frames' hipGraphs captured
+    if timing:
+        # one EXTRA untimed step with every GEMM / glue class event-timed: finds the dominant class and measures the glue kernels.  Per-launch
+        # events cannot ride inside a replayed hipGraph, so this step enqueues its frames eagerly — the same kernels by the same rules
+        # (tests/test_gpu_generate.py::test_eager_and_graph_replayed_frames_run_the_same_kernels_bitwise), a different launch mechanism.
+        torch.cuda.synchronize()
+        lib.d4_profile_enable((1 << ncls) - 1)
+        lib.d4_profile_glue_enable((1 << lib.d4_profile_glue_classes()) - 1)
         trainer.train_step()
-        if last:
-            torch.cuda.synchronize()
-            lib.d4_profile_enable(0)
-            lib.d4_profile_glue_enable(0)
-            ng = lib.d4_profile_glue_classes()
-            gms = (C.c_double * ng)(); gby = (C.c_double * ng)(); gcnt = (C.c_int64 * ng)(); gfl = (C.c_double * ng)()
-            _lib.check(lib.d4_profile_glue_read_flops(gfl, ng))
-            _lib.check(lib.d4_profile_glue_read(gms, gby, gcnt, ng))
-            fused_flops = sum(gfl[i] for i in range(ng))          # GEMM work done inside the per-frame fused kernels (frame_fused.hip)
-            glue_measured = {lib.d4_profile_glue_class_name(i).decode(): dict(
-                hbm_gbs=round(gby[i] / max(gms[i], 1e-9) / 1e6, 1), frac_of_8tbs=round(gby[i] / max(gms[i], 1e-9) / 1e6 / 8000., 3),
-                avg_us=round(1e3 * gms[i] / gcnt[i], 2), launches=int(gcnt[i]), ms_per_step=round(gms[i], 2),
-                algorithmic_mb_per_launch=round(gby[i] / gcnt[i] / 1e6, 2),
-                **({'matrix_gflop_per_launch': round(gfl[i] / gcnt[i] / 1e9, 2)} if gfl[i] > 0 else {})) for i in range(ng) if gcnt[i]}
-            ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
-            _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
-            dom = max(range(ncls), key=lambda i: ms[i])
-            # ... and the largest class of the OTHER instruction family (f32-input MFMA vs split operands on the bf16 MFMA): the two lead the table
-            # within a fraction of a millisecond of each other, so which one is "dominant" flips from box to box — both are event-timed and reported
-            others = [i for i in range(ncls) if is_split[i] != is_split[dom] and ms[i] > 0]
-            dom2 = max(others, key=lambda i: ms[i]) if others else None
-            warm_classes = {names[i]: dict(ms=round(ms[i], 2), tflops=round(fl[i] / max(ms[i], 1e-9) / 1e9, 2), launches=int(cnt[i]))
-                            for i in range(ncls) if cnt[i]}
-            warm_exec = (sum(fl[i] for i in range(ncls)), sum(ms[i] for i in range(ncls)))      # EXECUTED flops / GEMM time of one step
+        torch.cuda.synchronize()
+        lib.d4_profile_enable(0)
+        lib.d4_profile_glue_enable(0)
+        ng = lib.d4_profile_glue_classes()
+        gms = (C.c_double * ng)(); gby = (C.c_double * ng)(); gcnt = (C.c_int64 * ng)(); gfl = (C.c_double * ng)()
+        _lib.check(lib.d4_profile_glue_read_flops(gfl, ng))
+        _lib.check(lib.d4_profile_glue_read(gms, gby, gcnt, ng))
+        fused_flops = sum(gfl[i] for i in range(ng))          # GEMM work done inside the per-frame fused kernels (frame_fused.hip)
+        glue_measured = {lib.d4_profile_glue_class_name(i).decode(): dict(
+            hbm_gbs=round(gby[i] / max(gms[i], 1e-9) / 1e6, 1), frac_of_8tbs=round(gby[i] / max(gms[i], 1e-9) / 1e6 / 8000., 3),
+            avg_us=round(1e3 * gms[i] / gcnt[i], 2), launches=int(gcnt[i]), ms_per_step=round(gms[i], 2),
+            algorithmic_mb_per_launch=round(gby[i] / gcnt[i] / 1e6, 2),
+            **({'matrix_gflop_per_launch': round(gfl[i] / gcnt[i] / 1e9, 2)} if gfl[i] > 0 else {})) for i in range(ng) if gcnt[i]}
+        ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
+        _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
+        dom = max(range(ncls), key=lambda i: ms[i])
+        # ... and the largest class of the OTHER instruction family (f32-input MFMA vs split operands on the bf16 MFMA): the two lead the table
+        # within a fraction of a millisecond of each other, so which one is "dominant" flips from box to box — both are event-timed and reported
+        others = [i for i in range(ncls) if is_split[i] != is_split[dom] and ms[i] > 0]
+        dom2 = max(others, key=lambda i: ms[i]) if others else None
+        warm_classes = {names[i]: dict(ms=round(ms[i], 2), tflops=round(fl[i] / max(ms[i], 1e-9) / 1e9, 2), launches=int(cnt[i]))
+                        for i in range(ncls) if cnt[i]}
+        warm_exec = (sum(fl[i] for i in range(ncls)), sum(ms[i] for i in range(ncls)))      # EXECUTED flops / GEMM time of one step
     torch.cuda.synchronize()
 
-    if timing:
-        # the dominant configuration only: keeps the event overhead in the timed region small (--warmup 0: all of them)
-        lib.d4_profile_enable(((1 << dom) | ((1 << dom2) if dom2 is not None else 0) if dom is not None else (1 << ncls) - 1) | (EVENT_STRIDE << 26))
+    # ---- the timed region: the DEFAULT product path (no per-launch events; decode frames replayed from hipGraphs where the engine's rule says so)
     gen_ms, learn_ms = [], []
     frames_total = 0
     parallel.barrier()
@@ -329,11 +329,23 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    if timing:
-        lib.d4_profile_enable(0)
     for k in range(args.steps):
         gen_ms.append(ev[3 * k].elapsed_time(ev[3 * k + 1]))
         learn_ms.append(ev[3 * k + 1].elapsed_time(ev[3 * k + 2]))
+
+    # ---- roofline pass: the SAME steps repeated right after the timed region with a HIP-event pair on every EVENT_STRIDE-th launch of the dominant
+    # GEMM class (and of the largest class of the other instruction family).  Outside `value`: events force the eager launch mechanism.
+    ev_ms_per_step = None
+    if timing:
+        psteps = max(1, min(args.steps, 3))
+        lib.d4_profile_enable(((1 << dom) | ((1 << dom2) if dom2 is not None else 0)) | (EVENT_STRIDE << 26))
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for k in range(psteps):
+            trainer.learn(trainer.generate())
+        torch.cuda.synchronize()
+        ev_ms_per_step = 1e3 * (time.perf_counter() - tp) / psteps
+        lib.d4_profile_enable(0)
 
     wall_t = torch.tensor([wall], device=device, dtype=torch.float64)
     parallel.all_reduce_max_(wall_t)
@@ -345,8 +357,6 @@ def main():
     if timing:
         ms = (C.c_double * ncls)(); fl = (C.c_double * ncls)(); cnt = (C.c_int64 * ncls)()
         _lib.check(lib.d4_profile_read(ms, fl, cnt, ncls))
-        if dom is None:
-            dom = max(range(ncls), key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.
         traffic = None     # HBM bytes per launch of the dominant class from the committed rocprofv3 PMC passes (separate runs; profiles/pmc_traffic.json):
         try:               # the class has an RMS and a non-RMS instantiation -> the one with the larger share of GPU time
@@ -365,6 +375,11 @@ def main():
                         frac=round(ach / peak, 4), traffic=traffic, kernel=names[dom],
                         launches_timed=int(cnt[dom]), event_stride=EVENT_STRIDE, avg_launch_us=round(1e3 * ms[dom] / max(cnt[dom], 1), 2),
                         flops_per_launch=round(fl[dom] / max(cnt[dom], 1)),
+                        measured_in=('an event-timed repeat of the timed steps, run right after the timed region in the same process (per-launch HIP events '
+                                     'cannot ride inside replayed hipGraphs, so that pass enqueues the decode frames eagerly: the same kernels by the same rules, '
+                                     'asserted bit-identical in tests/test_gpu_generate.py); `value` / `ms_per_step` are the default path without events'),
+                        ms_per_step_event_timed_pass=round(ev_ms_per_step, 2),
+                        traffic_source='profiles/pmc_traffic.json: builder-run rocprofv3 --pmc passes of this workload (separate runs), not measured in this process',
                         all_gemm_configs_one_warmup_step=warm_classes,
                         # algorithmic = SURVEY's 5.23 GFLOP per imagined step (what the reference would execute); executed = the 2MNK of
                         # the GEMM launches this engine actually makes (it drops ~26 % of the reference's work: agent row, compacted

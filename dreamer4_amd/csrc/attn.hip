@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void time_attn64_few_kernel(TimeAttnArgs p) {
     const int hg = wid % HG, s = (wid / HG) % p.S, b = wid / (HG * p.S);
     const int lane = threadIdx.x & 63, fg = lane & 15;
     const int h = hg * 4 + (lane >> 4);
-    const int pos = p.t0;                                                      // host-known (the launcher takes this kernel only then), Tq == 1
+    const int pos = p.t0_dev ? *p.t0_dev : p.t0;                               // Tq == 1; pos < TA_FEW (the launcher picks by time_history_bucket(p.t0), which a replayed graph is keyed on)
     const int hd = p.H * 64;
     const int cS = p.cache_S > 0 ? p.cache_S : p.S;
     const int64_t col = (int64_t)b * cS + s, cols = (int64_t)p.cache_batch * cS;
@@ -981,9 +981,10 @@ int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
         static const bool no_few = getenv("D4_TIME_ATTN_FEW") && atoi(getenv("D4_TIME_ATTN_FEW")) == 0;
         const bool al4 = ((uintptr_t)p.proj % 16) == 0 && ((uintptr_t)p.cache % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.inv_freq % 16) == 0 &&
                          (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
-        if (p.Tq == 1 && !p.t0_dev && p.t0 < 8 && (p.H % 4) == 0 && al4 && !no_few)           // a short history: four heads per wave
+        const int bucket = time_history_bucket(p.t0);                           // the same rule eagerly and under graph replay (graphs are keyed on it)
+        if (p.Tq == 1 && bucket == 0 && (p.H % 4) == 0 && al4 && !no_few)           // a short history: four heads per wave
             D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel<8>, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
-        else if (p.Tq == 1 && !p.t0_dev && p.t0 < 16 && (p.H % 4) == 0 && al4 && !no_few)
+        else if (p.Tq == 1 && bucket == 1 && (p.H % 4) == 0 && al4 && !no_few)
             D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel<16>, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
         else if (p.Tq == 1) D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
         else {

@@ -63,8 +63,10 @@ struct d4_engine {
     size_t ws_bytes = 0, ws_need = 0;
     bool prepared = false;
     int cache_frames = 0;
-    // captured decode frames: key = (batch, num_steps, step_log2, has_tasks) -> executable graph of the K+1 evaluations
-    struct FrameGraph { int B, K, sl, tasks; hipGraphExec_t exec; };
+    // captured decode frames: key = (batch, num_steps, step_log2, has_tasks, history bucket) -> executable graph of the K+1 evaluations.
+    // The history bucket (d4::time_history_bucket of the frame offset) is part of the key because the time-attention launcher picks its
+    // kernel by it: a replayed frame runs exactly the kernels the same frame runs when enqueued eagerly.
+    struct FrameGraph { int B, K, sl, tasks, bucket; hipGraphExec_t exec; };
     std::vector<FrameGraph> graphs;
     int graph_max_rows = 4096;
     bool warm = false;

@@ -1211,7 +1211,8 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                 tasks = e->tasks_dev;
             }
             hipGraphExec_t exec = nullptr;
-            for (auto& g : e->graphs) if (g.B == B && g.K == K && g.sl == sl && g.tasks == (tasks != nullptr)) exec = g.exec;
+            const int bucket = e->Lt > 0 ? d4::time_history_bucket(t0) : 0;
+            for (auto& g : e->graphs) if (g.B == B && g.K == K && g.sl == sl && g.tasks == (tasks != nullptr) && g.bucket == bucket) exec = g.exec;
             if (!exec) {
                 if (!e->warm) {
                     // first decode frame of this engine: run it eagerly once (function attributes, lazy module load)
@@ -1239,7 +1240,7 @@ int d4_rollout(d4_engine* e, const d4_rollout_io* io, void* stream) {
                     D4_HIP(ce);
                     D4_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                     (void)hipGraphDestroy(graph);
-                    e->graphs.push_back({B, K, sl, tasks != nullptr, exec});
+                    e->graphs.push_back({B, K, sl, tasks != nullptr, bucket, exec});
                 }
             }
             if (exec) {

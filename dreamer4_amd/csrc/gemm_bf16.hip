@@ -42,20 +42,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
+    int bid = blockIdx.x;
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-    const int bz = blockIdx.y;
-    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wb) + bz * p.strideW;
-    p.A += bz * p.strideA; p.C += bz * p.strideC;
-    if (p.R) p.R += bz * p.strideC;
-    // tile loop: one pass when the grid has a workgroup per tile; a grid of resident workgroups only (D4_BF16_PERSIST=1) walks the tiles in strides
-    for (int tile = blockIdx.x; tile < nbm * nbn; tile += gridDim.x) {
-    int bid = tile;
     {
         const int nblk = nbm * nbn, nx = 8;
         const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
     }
     const int bm0 = (bid / nbn) * BM, bn0 = (bid % nbn) * BN;
+    const int bz = blockIdx.y;
+    const __bf16* Wb = reinterpret_cast<const __bf16*>(p.Wb) + bz * p.strideW;
+    p.A += bz * p.strideA; p.C += bz * p.strideC;
+    if (p.R) p.R += bz * p.strideC;
 
     const int rowsA = min(BM, p.M - bm0), rowsB = min(BN, p.N - bn0);
     auto uniform_rsrc = [](const void* base, int64_t bytes) {
@@ -200,8 +198,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
             }
         }
     }
-    __syncthreads();                                   // LDS tiles / row scales are rewritten by the next tile
-    }
 }
 
 // ---- fp32 -> bf16 weight images (engine prepare) ---------------------------------------------------------------
@@ -246,19 +242,7 @@ static int launch_bf16(const GemmArgs& p, hipStream_t stream) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1);
-    const dim3 block(WGM * WGN * 64);
-    static const bool persist = getenv("D4_BF16_PERSIST") && atoi(getenv("D4_BF16_PERSIST")) != 0;    // experiment: resident workgroups walk the tiles
-    if (persist && grid.y == 1) {
-        static int slots = 0;
-        if (slots == 0) {
-            int per_cu = 1, dev = 0, cus = 256;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), (int)block.x, lds);
-            (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            slots = (per_cu > 0 ? per_cu : 1) * cus;
-        }
-        if ((int)grid.x > slots) grid.x = slots;
-    }
+    const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
     if (g_bprof_stride > 0 && (g_bprof_tick++ % g_bprof_stride) == 0) {
         Bf16Prof r{};
         D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));

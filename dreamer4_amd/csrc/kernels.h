@@ -166,10 +166,13 @@ struct TimeAttnArgs {
     int B, S, H, Tq, t0, Tcap;
     int cache_batch;                     // batch capacity the cache was laid out for
     int cache_S = 0;                     // tokens per frame the cache was laid out for (0: same as S)
-    const int* t0_dev = nullptr;         // when set, the frame offset is read from device memory (hipGraph replay)
+    const int* t0_dev = nullptr;         // when set, the frame offset is read from device memory (hipGraph replay); t0 must then lie in the same
+                                         // time_history_bucket as the value read (the launcher picks its kernel by the bucket of t0)
     float softclamp;
     int dh = 64;                         // head dim (16 / 32 / 64); cache rows are dh wide
 };
+// History-length class the cached-decode launcher picks its kernel by: 0: <= 8 keys (t0 < 8), 1: <= 16 keys, 2: general.
+inline int time_history_bucket(int t0) { return t0 < 8 ? 0 : (t0 < 16 ? 1 : 2); }
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream);   // normalise/rotate/mix new K,V -> cache[t0 .. t0+Tq)
 int time_attn(const TimeAttnArgs& p, hipStream_t stream);        // attend over cache[0 .. t0+i], belief + gates
 

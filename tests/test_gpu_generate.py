@@ -295,6 +295,46 @@ def test_full_size_config_vs_oracle(B):
     assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
 
 
+@pytest.mark.parametrize('graph_rows', ['0', '4096'])
+def test_short_history_time_attention_eager_and_graph_replay_vs_oracle(graph_rows, monkeypatch):
+    """Cached time attention (D4:1683-1756, 2032-2035) at BASELINE config 2's architecture (8 x 64 heads, so the four-heads-per-wave
+    `time_attn64_few_kernel<8>` / `<16>` are the ones taken for histories of <= 8 / <= 16 keys and the general kernel beyond) over an 18-frame
+    rollout: every history bucket, every multi-key branch.  Run once with the frames enqueued eagerly (D4_GRAPH_MAX_ROWS=0, the path a
+    B*S > 4096 rollout and an event-timed bench step take) and once with the frames replayed from hipGraphs (the default at B*S <= 4096):
+    both must match the oracle, integers exact — the launcher picks its kernel by the history bucket in both modes."""
+    from dreamer4_amd import DynamicsWorldModel
+    monkeypatch.setenv('D4_GRAPH_MAX_ROWS', graph_rows)        # read at engine creation
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = 2, 18
+    nz = make_noise(cfg, T, B, 11)
+    ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, return_terminals=False)
+    e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
+                          return_log_probs_and_values=True, noise=nz)
+    assert e.latents.shape[1] == T
+    close(e.latents, ref['latents'], atol=5e-4); close(e.agent_embed, ref['agent_embed'], atol=1e-3)
+    close(e.values, ref['values'], atol=5e-4); close(e.log_probs.discrete, ref['log_probs'], atol=1e-3)
+    assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
+
+
+def test_eager_and_graph_replayed_frames_run_the_same_kernels_bitwise(monkeypatch):
+    """The same rollout enqueued eagerly and replayed from hipGraphs is bit-identical: kernel selection does not depend on the launch
+    mechanism (the graphs are keyed on the history bucket the time-attention launcher selects by)."""
+    from dreamer4_amd import DynamicsWorldModel
+    outs = []
+    for rows in ('0', '4096'):
+        monkeypatch.setenv('D4_GRAPH_MAX_ROWS', rows)
+        torch.manual_seed(0)
+        m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+        nz = make_noise(oracle_config(m), 18, 8, 3)
+        outs.append(m.generate(18, batch_size=8, return_for_policy_optimization=True, noise=nz))
+    a, b = outs
+    assert torch.equal(a.latents, b.latents) and torch.equal(a.agent_embed, b.agent_embed) and torch.equal(a.values, b.values)
+    assert torch.equal(a.actions.discrete, b.actions.discrete) and torch.equal(a.log_probs.discrete, b.log_probs.discrete)
+
+
 def test_config5_shape_vs_oracle():
     """BASELINE config 5 architecture in fp32: dim 1024, depth 12 -> time layers 4, 8, 12, attention inner width 8 x 64 = 512 < dim,
     64 x 32 latents, 6 continuous (Beta) actions.  (The engine is not specialised to dim 512; the bf16 form of this config is
