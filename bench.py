@@ -261,6 +261,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     parallel.init_from_env('nccl')                       # RCCL over xGMI
+    if world > 1 or os.environ.get('D4_BENCH_STRICT_TUNE') == '1':
+        # N ranks must not each time GEMM tile configurations on their own clock (different choices per rank, first-step skew): every shape
+        # of this workload has to come from the shipped table dreamer4_amd/gemm_tune_default.txt, else the first step fails with the shape named
+        os.environ['D4_GEMM_AUTOTUNE'] = 'strict'
     rank = parallel.rank()
 
     model = build_model(device)
@@ -350,6 +354,13 @@ def main():
     wall_t = torch.tensor([wall], device=device, dtype=torch.float64)
     parallel.all_reduce_max_(wall_t)
     wall = float(wall_t.item())
+    # rank skew in one line: min / max over ranks of each rank's mean rollout and learner time (MAX all-reduce of (x, -x))
+    mine = torch.tensor([sum(gen_ms) / len(gen_ms), sum(learn_ms) / len(learn_ms)], device=device, dtype=torch.float64)
+    skew = torch.cat([mine, -mine])
+    parallel.all_reduce_max_(skew)
+    skew = skew.tolist()
+    per_rank = dict(generate_ms_min=round(-skew[2], 2), generate_ms_max=round(skew[0], 2),
+                    actor_critic_step_ms_min=round(-skew[3], 2), actor_critic_step_ms_max=round(skew[1], 2))
     steps_done = world * B_LOCAL * frames_total              # every rank generates the same number of frames
     value = steps_done / wall
 
@@ -415,6 +426,7 @@ def main():
                              'generate(H+1=16 frames, num_steps=4, time cache) + learn_from_experience(ppo) + clip/AdamW both heads',
                     global_batch=world * B_LOCAL, per_gpu_batch=B_LOCAL, horizon=HORIZON, num_steps=NUM_STEPS, parallelism=f'dp{world}'),
         generate_ms=round(sum(gen_ms) / len(gen_ms), 2), actor_critic_step_ms=round(sum(learn_ms) / len(learn_ms), 2),
+        per_rank=per_rank,
         rollout_steps_per_sec=round(world * B_LOCAL * (HORIZON + 1) / (sum(gen_ms) / len(gen_ms) * 1e-3), 1),
         roofline=roofline,
     )

@@ -250,10 +250,13 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(SmallAttnArgs p) {
     const int unit = blockIdx.x * 4 + w;
     if (unit >= p.groups * p.heads) return;
     const int g = unit / p.heads, h = unit % p.heads;
-    float* op = p.out + g * p.o_group_stride + h * 64;
+    float* op = p.out ? p.out + g * p.o_group_stride + h * 64 : nullptr;
+    uint16_t* ob = p.out_b ? p.out_b + g * p.o_group_stride + h * 64 : nullptr;
     const int64_t ois = p.o_item_stride;
-    attn_mfma_unit<QT, KT>(p, g, h, lane, Vs_all[w], kinv_all[w], vinv_all[w],
-                           [&](int orank, int t, int tok, float v) { op[(int64_t)orank * ois + 16 * t + tok] = v; });
+    attn_mfma_unit<QT, KT>(p, g, h, lane, Vs_all[w], kinv_all[w], vinv_all[w], [&](int orank, int t, int tok, float v) {
+        if (op) op[(int64_t)orank * ois + 16 * t + tok] = v;
+        if (ob) ob[(int64_t)orank * ois + 16 * t + tok] = bf16_bits(v);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -353,16 +356,17 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(SmallAttnArgs p) {
     }
 }
 
-int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
+static int small_attn_impl(const SmallAttnArgs& p, hipStream_t stream, bool* wrote_b) {
+    *wrote_b = false;
     if (p.nk > 64 || (p.nq == p.nk && p.nk > 16 && p.belief && p.dh == 64)) {
         // wide form (tokenizer decoder): needs 16-byte aligned rows for the float4 q loads / out stores
         D4_REQUIRE(p.nk <= ATTN_MAXK && p.dh == 64, "attention: %d keys (max %d) / head dim %d (64) not supported by the wide kernel", p.nk, ATTN_MAXK, p.dh);
         D4_REQUIRE(p.q_lo == 0 && p.q_hi == 0, "attention: query restriction is not implemented in the wide kernel");
         const size_t lds = (size_t)(2 * p.nk * 64 + p.nk) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DeviceOnce attr_set;
+        if (attr_set.need()) {
             D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * ATTN_MAXK * 64 + ATTN_MAXK) * sizeof(float))));
-            attr_set = true;
+            attr_set.done();
         }
         if (p.groups * p.heads == 0) return 0;
         const double wide_bytes = 4.0 * p.groups * p.heads * p.dh * ((double)p.nq * 2 + (double)p.nk * (p.vres ? 3 : 2));
@@ -386,6 +390,7 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
         const bool mfma_ok = mfma_on && p.dh == 64 && al4(p.q, p.q_group_stride, p.q_item_stride) && al4(p.k, p.k_group_stride, p.k_item_stride) &&
                              al4(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4(p.vres, p.r_group_stride, p.r_item_stride)) &&
                              ((uintptr_t)p.k_gamma % 16) == 0;
+        *wrote_b = mfma_ok;
         if (mfma_ok) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, (attn_mfma_kernel<1, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
         else if (p.dh == 64) D4_GLUE_LAUNCH(GL_SPACE_ATTN, sp_bytes, space_attn_kernel<64>, dim3(waves), block, 0, stream, p);
         else if (p.dh == 32) hipLaunchKernelGGL(space_attn_kernel<32>, dim3(waves), block, 0, stream, p);
@@ -407,6 +412,7 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
         else if (p.dh == 32) hipLaunchKernelGGL((small_attn_kernel<NK, 32>), dim3(waves), block, 0, stream, p);   \
         else hipLaunchKernelGGL((small_attn_kernel<NK, 16>), dim3(waves), block, 0, stream, p);                   \
     } while (0)
+    *wrote_b = mfma_small;
     if (mfma_small) {         // one wave per (group, head) on the matrix pipe (attn_mfma_kernel): up to 32 x 16 or 16 x 32 (queries x keys)
         if (p.nq <= 16 && p.nk <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
         else if (p.nq <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 2>), dim3(cdiv(waves, 4)), block, 0, stream, p);
@@ -418,6 +424,24 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
 #undef D4_SMALL_ATTN
     D4_LAUNCH_CHECK();
     return 0;
+}
+
+// bf16 engine: `out_b` asks for a bf16 copy of the output (the next GEMM's activation image).  The matrix-pipe kernels write it themselves; the
+// other forms are followed by one conversion pass over the (contiguous) output rows.
+int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
+    bool wrote_b = false;
+    D4_REQUIRE(p.out != nullptr || p.out_b != nullptr, "small_attn: no output");
+    if (p.out_b && !p.out) {
+        // only the kernels that write the bf16 copy themselves can run without the fp32 output
+        D4_REQUIRE(false, "small_attn: out_b without out is not supported");
+    }
+    if (int rc = small_attn_impl(p, stream, &wrote_b)) return rc;
+    if (!p.out_b || wrote_b || p.groups * p.heads == 0) return 0;
+    const int nq_out = p.q_hi > 0 ? (p.q_hi - p.q_lo + p.q_last) : p.nq;
+    const int cols = p.heads * p.dh;
+    if (nq_out == 1 || p.o_item_stride == 0) return cvt_rows_bf16(p.out, p.o_group_stride, p.out_b, p.o_group_stride, p.groups, cols, stream);
+    D4_REQUIRE(p.o_group_stride == (int64_t)nq_out * p.o_item_stride, "small_attn: bf16 output copy needs contiguous output rows");
+    return cvt_rows_bf16(p.out, p.o_item_stride, p.out_b, p.o_item_stride, p.groups * nq_out, cols, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,7 +463,8 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     if (m >= p.M) return;
     const int lane = threadIdx.x & 63;
     pool_mix_row<ITER>(p, m, lane, psh[wslot], gws, [&](int h, int c4, const f32x4& v) {
-        reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = v;
+        if (p.u) reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = v;
+        if (p.u_b) store_bf16x4(p.u_b + ((int64_t)m * PH + h) * D + 4 * c4, v);
     });
 }
 
@@ -583,7 +608,9 @@ __global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
         const int h = idx / (ITER * 64), c4 = idx % (ITER * 64);
         if (c4 >= nf4) continue;
         const f32x4 sum = ((accs[0][h][c4] + accs[1][h][c4]) + accs[2][h][c4]) + accs[3][h][c4];
-        reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = sum * sigmoidf(gsh[h]);
+        const f32x4 gated = sum * sigmoidf(gsh[h]);
+        if (p.u) reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = gated;
+        if (p.u_b) store_bf16x4(p.u_b + ((int64_t)m * PH + h) * D + 4 * c4, gated);
     }
 }
 
@@ -872,7 +899,10 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
         const float gate = sigmoidf(gate_logit);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (o[e] - dot * (vi[e] * inv)) * gate;
-        if (kr == 0) *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.ldo + h * 64 + fg * 4) = o;
+        if (kr == 0) {
+            *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.ldo + h * 64 + fg * 4) = o;
+            if (p.out_b) store_bf16x4(p.out_b + (int64_t)row * p.ldo + h * 64 + fg * 4, o);
+        }
     }
 }
 
@@ -950,6 +980,7 @@ __global__ __launch_bounds__(256) void time_attn64_few_kernel(TimeAttnArgs p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (o[e] - dot * (vi[e] * inv)) * gate;
     *reinterpret_cast<f32x4*>(p.out + (int64_t)row * p.ldo + h * 64 + fg * 4) = o;
+    if (p.out_b) store_bf16x4(p.out_b + (int64_t)row * p.ldo + h * 64 + fg * 4, o);
 }
 
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
@@ -993,9 +1024,14 @@ int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
             hipLaunchKernelGGL(time_attn64_kernel<true>, dim3(units), dim3(64 * nwv), (size_t)2 * TA_CHUNK * 64 * sizeof(float), stream, p);
         }
     }
-    else if (p.dh == 64) hipLaunchKernelGGL(time_attn_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
-    else if (p.dh == 32) hipLaunchKernelGGL(time_attn_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(time_attn_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    else {
+        if (p.dh == 64) hipLaunchKernelGGL(time_attn_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+        else if (p.dh == 32) hipLaunchKernelGGL(time_attn_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(time_attn_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+        D4_LAUNCH_CHECK();
+        if (p.out_b) return cvt_rows_bf16(p.out, p.ldo, p.out_b, p.ldo, p.B * p.Tq * p.S, p.H * p.dh, stream);       // (the one-key-per-reduction form writes fp32 only)
+        return 0;
+    }
     D4_LAUNCH_CHECK();
     return 0;
 }

@@ -461,13 +461,13 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(XAttnArgs p) {
 static int xattn_core(const XAttnArgs& a, int dh, hipStream_t s) {
     if (a.G * a.heads == 0) return 0;
     const size_t lds = sizeof(float) * ((size_t)(3 * a.nk + 4 * a.nq) * AB_LD + a.nk + a.nq + 256);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         const int mx = (int)(sizeof(float) * ((size_t)7 * XA_N * AB_LD + 2 * XA_N + 256));
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-        attr_set = true;
+        attr_set.done();
     }
     if (dh == 64) hipLaunchKernelGGL(xattn_bwd_kernel<64>, dim3(a.G * a.heads), dim3(256), lds, s, a);
     else if (dh == 32) hipLaunchKernelGGL(xattn_bwd_kernel<32>, dim3(a.G * a.heads), dim3(256), lds, s, a);

@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the dreamer4 imagination path.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -80,6 +81,24 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float siluf(float x) { return x / (1.f + expf(-x)); }
 
+// fp32 -> bf16 (round to nearest even) bit patterns, for the bf16 activation images the bf16 engine's GEMMs read
+__device__ __forceinline__ uint16_t bf16_bits(float v) { const __bf16 h = (__bf16)v; return __builtin_bit_cast(uint16_t, h); }
+__device__ __forceinline__ void store_bf16x4(uint16_t* dst, const f32x4& v) {      // dst 8-byte aligned
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    bf16x4_t o;
+    o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4_t*>(dst) = o;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Once-per-DEVICE guard for function attributes (hipFuncSetAttribute applies to the current device only): bit d = done on device d.
+// Two host threads racing set the same value twice, which is harmless.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool need() const { return !((mask.load(std::memory_order_acquire) >> dev()) & 1); }
+    void done() { mask.fetch_or((uint64_t)1 << dev(), std::memory_order_release); }
+};
 
 }  // namespace d4

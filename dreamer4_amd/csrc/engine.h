@@ -88,6 +88,20 @@ struct d4_engine {
     uint16_t* bf16_arena = nullptr; size_t bf16_cap = 0, bf16_used = 0;
     struct Mirror { const float* src; size_t n; uint16_t* dst; };
     std::vector<Mirror> mirrors;
+    // bf16 mode (not split): bf16 IMAGES of the activation buffers the trunk GEMMs read (same element offsets / leading dimensions as the fp32
+    // buffer).  Producers write them (GEMM epilogue `Cb`, attention / pool-mix `out_b`, a conversion pass elsewhere) and consumers read them
+    // through gemm_bf16a.hip (both operands by LDS-DMA) — numerically the rounding the fp32-activation kernel applied on its way into LDS.
+    // `only`: nothing reads the fp32 buffer when the image exists (the producer may skip the fp32 store).
+    struct Shadow { const float* src; size_t n; uint16_t* dst; bool only; };
+    std::vector<Shadow> shadows;
+    uint16_t* shadow_of(const float* p) const {
+        for (const auto& sh : shadows) if (p >= sh.src && p < sh.src + sh.n) return sh.dst + (p - sh.src);
+        return nullptr;
+    }
+    bool shadow_only(const float* p) const {
+        for (const auto& sh : shadows) if (p >= sh.src && p < sh.src + sh.n) return sh.only;
+        return false;
+    }
 
     // ---- bound (raw) weights
     std::vector<d4::AttnW> layer_attn;

@@ -119,6 +119,21 @@ int engine_layout(d4_engine* e, bool assign) {
     e->pool_kv = fl((size_t)e->nslab * M * 2 * hp);
     e->pool_att = fl(M * hp);
     e->pool_u = fl(M * (size_t)e->php * D);
+    e->shadows.clear();
+    if (e->bf16 && !e->split && !e->decoder && !e->encoder) {
+        static const bool shadows_on = !(getenv("D4_BF16_ACT") && atoi(getenv("D4_BF16_ACT")) == 0);       // 0: fp32 activations into every bf16 GEMM (the round-2 form)
+        auto sh = [&](const float* src, size_t n, bool only) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(alloc_bytes(n * sizeof(uint16_t)));
+            if (shadows_on) e->shadows.push_back({src, n, dst, only});
+        };
+        sh(e->slabs, (size_t)e->nslab * M * D, false);
+        sh(e->xpool, M * D, false);
+        sh(e->att, M * hd, false);
+        // `only` (the producer skips the fp32 store) where the ONE consumer is certain to take the bf16-activation kernel: its K % 64 == 0
+        sh(e->ffh, M * e->inner_pad, e->inner_pad % 64 == 0 && D % 64 == 0);
+        sh(e->pool_att, M * hp, hp % 64 == 0 && D % 64 == 0);
+        sh(e->pool_u, M * (size_t)e->php * D, D % 64 == 0);
+    }
     e->cq = fl(Fr * KQ * e->ldcq);
     e->ckv = fl(M * 2 * hd);
     e->catt = fl(Fr * KQ * hd);
@@ -376,6 +391,27 @@ static int engine_gemm(GemmArgs& g, hipStream_t s) {
             if (!gemm_x3_applicable(g)) { g.Wb = nullptr; g.wplane = 0; }
         } else
         if (!gemm_bf16_applicable(g)) g.Wb = nullptr;       // e.g. K not a multiple of 32: this call stays on the fp32 kernel
+        if (!e->split && !e->shadows.empty()) {
+            // bf16 activation images: read A's when it has one (and the bf16-activation kernel takes the call), refresh C's either in the
+            // epilogue of that kernel or by a conversion pass after any other kernel
+            uint16_t* cb = e->shadow_of(g.C);
+            g.Ab = g.Wb ? e->shadow_of(g.A) : nullptr;
+            if (g.Ab && !gemm_bf16a_applicable(g)) g.Ab = nullptr;
+            D4_REQUIRE(g.Ab || !e->shadow_only(g.A), "bf16 engine: a GEMM (M=%d N=%d K=%d) reads a bf16-only activation buffer but cannot take the bf16-activation kernel", g.M, g.N, g.K);
+            if (g.Ab) {
+                g.Cb = cb;
+                if (cb && e->shadow_only(g.C) && !(g.flags & GEMM_ACCUMULATE)) g.C = nullptr;
+                return gemm(g, s);
+            }
+            if (int rc = gemm(g, s)) return rc;
+            if (!cb) return 0;
+            const int nb = g.batch > 1 ? g.batch : 1;
+            const int ncol = (g.flags & GEMM_SWIGLU) ? g.N / 2 : g.N;
+            if (nb == 1) return cvt_rows_bf16(g.C, g.ldc, cb, g.ldc, g.M, ncol, s);
+            for (int b = 0; b < nb; ++b)
+                if (int rc = cvt_rows_bf16(g.C + b * g.strideC, g.ldc, cb + b * g.strideC, g.ldc, g.M, ncol, s)) return rc;
+            return 0;
+        }
     }
     return gemm(g, s);
 }
@@ -597,6 +633,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         PoolMixArgs pm{};
         pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
+        if (t_bf16) if (uint16_t* ub = t_bf16->shadow_of(e->pool_u)) { pm.u_b = ub; if (t_bf16->shadow_only(e->pool_u)) pm.u = nullptr; }   // only the value GEMM reads the mixes
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
         // D4_FRAME_FUSED=2: the mix stays its own kernel and only the tail is fused
         if (S > 0 && M % S == 0 && !e->pv_t.empty() && (!t_bf16 || t_bf16->split) && frame_pool_tail_applicable(M / S, S, D, c.pool_heads)) {
@@ -620,6 +657,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     sa.k_gamma = a.k_gamma;
     sa.out = e->pool_att; sa.o_group_stride = hp; sa.o_item_stride = 0;
     sa.groups = M; sa.heads = c.pool_heads; sa.nq = 1; sa.nk = L;
+    sa.out_b = t_bf16 ? t_bf16->shadow_of(e->pool_att) : nullptr;
     if ((rc = small_attn(sa, s))) return rc;
     }
     if (y_compact) return gemm_c2(e->pool_att, hp, a.to_out, hp, y, D, M, D, hp, 0, nullptr, x, D, y_compact, S, e->keep_hi - e->keep_lo, has_agent, s);
@@ -717,6 +755,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
         if ((rc = assemble_tokens(a, s))) return rc;
     }
     }
+    if (t_bf16) if (uint16_t* sb = t_bf16->shadow_of(slab0)) { if ((rc = cvt_rows_bf16(slab0, D, sb, D, M, D, s))) return rc; }
 
     // ---- trunk (AxialSpaceTimeTransformer.forward, D4:3040-3223)
     const float* x_in = slab0;
@@ -736,6 +775,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
             ta.softclamp = c.attn_softclamp_value;
             ta.cache_batch = e->maxB; ta.cache_S = e->S;
             ta.t0_dev = t0_dev;
+            ta.out_b = t_bf16 ? t_bf16->shadow_of(e->att) : nullptr;
             if ((rc = time_kv_append(ta, s))) return rc;
             if ((rc = time_attn(ta, s))) return rc;
         } else {
@@ -752,9 +792,10 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
             sa.out = e->att; sa.o_group_stride = (int64_t)S * hd; sa.o_item_stride = hd;
             sa.groups = Fr; sa.heads = h; sa.nq = S; sa.nk = S;
             sa.softclamp = c.attn_softclamp_value; sa.mask_special = e->encoder ? n : has_agent; sa.belief = 1;
+            sa.out_b = t_bf16 ? t_bf16->shadow_of(e->att) : nullptr;
             if (denoise_only && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8) {
                 sa.q_lo = 1; sa.q_hi = 1 + ns; sa.q_last = 0;
-                sa.out = e->att_c; sa.o_group_stride = (int64_t)nkeep * hd;
+                sa.out = e->att_c; sa.o_group_stride = (int64_t)nkeep * hd; sa.out_b = nullptr;
             }
             // per-frame fused form: attention of all heads of a frame, then its output projection + residual, in one kernel
             const bool tail_compact = denoise_only && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8;

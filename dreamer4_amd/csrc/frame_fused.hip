@@ -266,10 +266,10 @@ int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const floa
     const double bytes = 4.0 * sa.groups * sa.nk * ((sa.vres ? 4.0 : 3.0) * hd + 2.0 * D) + 8.0 * 4.0 * D * hd;
     const double flops = 2.0 * sa.groups * sa.nk * (double)D * hd;
     const size_t lds = (size_t)(16 * (512 + 4) + FF_NW * 16 * SM_LDV + 2 * FF_NW * 16) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_attn_out_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     D4_GLUE_LAUNCH_F(GL_FRAME_ATTN_OUT, bytes, flops, frame_attn_out_kernel<512>, dim3(sa.groups), dim3(FF_NW * 64), lds, s, sa, wo_t, D, fo);
     D4_LAUNCH_CHECK();
@@ -286,10 +286,10 @@ int frame_pool_tail(const float* u, const float* wv_t, const float* wo_t, int fr
     FrameOut fo{resid, ldr, out, ldo, c2, ldc2, c2_lo, c2_hi, c2_last, S};
     constexpr int DD = 512, PH = 4;
     const size_t lds = (size_t)(PH * 16 * (DD + 4) + 16 * (PH * 64 + 4)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pool_tail_kernel<DD, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     const double bytes = 4.0 * frames * S * ((double)PH * D + 2.0 * D) + 8.0 * 4.0 * 2.0 * PH * 64 * D;
     const double flops = 2.0 * frames * S * ((double)PH * 64 * D + (double)D * PH * 64);
@@ -306,10 +306,10 @@ int frame_pool(const PoolMixArgs& pm, const float* wv_t, const float* wo_t, int 
     FrameOut fo{resid, ldr, out, ldo, c2, ldc2, c2_lo, c2_hi, c2_last, S};
     constexpr int DD = 512, PH = 4;
     const size_t lds = (size_t)(PH * 16 * (DD + 4) + 16 * (PH * 64 + 4)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pool_kernel<DD, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     // algorithmic bytes: L hiddens + L projected keys per token row, queries + the row itself, the block output (+ the two weight matrices per XCD)
     const double bytes = 4.0 * pm.M * ((double)pm.L * (pm.D + pm.ldk) + pm.ldq + 2.0 * pm.D) + 8.0 * 4.0 * 2.0 * PH * 64 * pm.D;

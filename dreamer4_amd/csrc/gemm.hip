@@ -21,6 +21,7 @@
 // operand for four consecutive k-steps is one ds_read_b128 (summation order inside a k-tile is a
 // fixed permutation; results are deterministic).
 #include "common.h"
+#include <string.h>
 #include <hip/hip_ext.h>
 #include "kernels.h"
 #include <mutex>
@@ -408,10 +409,10 @@ static int launch_cfg(const GemmArgs& p, hipStream_t stream, int cls) {
     const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD + BM) * sizeof(float);
     const bool ktail = (p.K % BK) != 0;
     auto k = ktail ? gemm_kernel<BM, BN, WGM, WGN, BK, KS, TA, TB, true> : gemm_kernel<BM, BN, WGM, WGN, BK, KS, TA, TB, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[ktail]) {
+    static DeviceOnce attr_set[2];
+    if (attr_set[ktail].need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[ktail] = true;
+        attr_set[ktail].done();
     }
     ProfRec rec{};
     const bool g_prof_on = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
@@ -559,6 +560,22 @@ static void tune_cache_append(const TuneKey& k, int id) {
     }
 }
 
+// D4_GEMM_AUTOTUNE: 1 / unset = time a new shape's configurations at first use; 0 = never time (static choice); strict = never time AND fail
+// on a shape that would have been timed (the multi-rank bench: every rank must take its choices from the shipped table, not from its own clock).
+static int tune_mode() {
+    static const int mode = [] {
+        const char* v = getenv("D4_GEMM_AUTOTUNE");
+        if (!v) return 1;
+        if (!strcmp(v, "strict")) return 2;
+        return atoi(v) == 0 ? 0 : 1;
+    }();
+    return mode;
+}
+#define D4_TUNE_STRICT_CHECK(p, nb)                                                                                                            \
+    D4_REQUIRE(tune_mode() != 2, "gemm: shape M=%d N=%d K=%d flags=%d batch=%d is not in the shipped tile table (dreamer4_amd/gemm_tune_default.txt) and " \
+               "D4_GEMM_AUTOTUNE=strict forbids timing it here: run the workload once on one GPU with D4_GEMM_TUNE_CACHE=<file> and merge the new lines",  \
+               (p).M, (p).N, (p).K, (p).flags, (nb))
+
 template <bool TA, bool TB>
 static int autotune(const GemmArgs& p, hipStream_t stream, int* best_out) {
     hipEvent_t e0 = prof_event(), e1 = prof_event();
@@ -596,7 +613,7 @@ static int autotune(const GemmArgs& p, hipStream_t stream, int* best_out) {
 
 template <bool TA, bool TB>
 static int launch_t(const GemmArgs& p, hipStream_t stream) {
-    static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
+    const bool tune_on = tune_mode() != 0;
     const int nb = p.batch > 0 ? p.batch : 1;
     const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
     if (g_forced_cfg >= 0 && g_forced_cfg < N_TILE_CFG && cfg_valid<TA, TB>(g_forced_cfg, p)) return launch_id<TA, TB>(g_forced_cfg, p, stream);
@@ -610,6 +627,7 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     (void)hipStreamIsCapturing(stream, &cap);
     if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
         return launch_id<TA, TB>(heuristic_cfg<TA, TB>(p), p, stream);
+    D4_TUNE_STRICT_CHECK(p, nb);
     int best = 0;
     if (int rc = autotune<TA, TB>(p, stream, &best)) return rc;
     g_tuned[key] = best;
@@ -679,7 +697,7 @@ static bool use_v2(const GemmArgs& p) {
 }
 
 static int gemm_v2(const GemmArgs& p, hipStream_t stream) {
-    static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
+    const bool tune_on = tune_mode() != 0;
     const int nb = p.batch > 0 ? p.batch : 1;
     const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
     tune_cache_load();
@@ -690,6 +708,7 @@ static int gemm_v2(const GemmArgs& p, hipStream_t stream) {
     (void)hipStreamIsCapturing(stream, &cap);
     if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
         return launch_v2(heuristic_v2(p), p, stream);
+    D4_TUNE_STRICT_CHECK(p, nb);
     int best = 0;
     if (int rc = autotune_v2(p, stream, &best)) return rc;
     g_tuned2[key] = best;
@@ -760,7 +779,7 @@ static int autotune_v3(const GemmArgs& p, hipStream_t stream, int* best_out) {
 }
 
 static int gemm_v3(const GemmArgs& p, hipStream_t stream) {
-    static const bool tune_on = !(getenv("D4_GEMM_AUTOTUNE") && atoi(getenv("D4_GEMM_AUTOTUNE")) == 0);
+    const bool tune_on = tune_mode() != 0;
     const int nb = p.batch > 0 ? p.batch : 1;
     if (g_forced_cfg >= 300 && gemm_x3_config_valid(g_forced_cfg - 300, p)) return launch_v3(g_forced_cfg - 300, p, stream);
     const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
@@ -772,6 +791,7 @@ static int gemm_v3(const GemmArgs& p, hipStream_t stream) {
     (void)hipStreamIsCapturing(stream, &cap);
     if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
         return launch_v3(gemm_x3_heuristic(p), p, stream);
+    D4_TUNE_STRICT_CHECK(p, nb);
     int best = 0;
     if (int rc = autotune_v3(p, stream, &best)) return rc;
     g_tuned3[key] = best;
@@ -856,6 +876,7 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         q.Wb = nullptr; q.wplane = 0;
         return gemm(q, stream);
     }
+    if (p.Wb && p.Ab && gemm_bf16a_applicable(p)) return gemm_bf16a(p, stream);     // bf16 engine, the activation has a bf16 image: both operands by LDS-DMA
     if (p.Wb) return gemm_bf16(p, stream);
     // test hook: 100 + c forces configuration c of the second family, 0 .. N_TILE_CFG-1 a configuration of this one
     if (g_forced_cfg >= 100 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);

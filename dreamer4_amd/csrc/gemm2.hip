@@ -357,10 +357,10 @@ static int launch2(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEven
     const size_t lds = (size_t)(NS * (BM + BN) * BK + BM) * sizeof(float);
     const bool rms = (p.flags & GEMM_RMS_ROWSCALE) != 0;
     auto k = rms ? gemm2_kernel<WGM, WGN, TM, TN, NS, BK, true> : gemm2_kernel<WGM, WGN, TM, TN, NS, BK, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[rms]) {
+    static DeviceOnce attr_set[2];
+    if (attr_set[rms].need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[rms] = true;
+        attr_set[rms].done();
     }
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
     if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, p);
@@ -375,10 +375,10 @@ static int launch2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream
     const size_t lds = (size_t)(NS * (BM + BN) * BK + BM) * sizeof(float);
     const bool rms = (a.flags & GEMM_RMS_ROWSCALE) != 0;
     auto k = rms ? gemm2_pair_kernel<WGM, WGN, TM, TN, NS, BK, true> : gemm2_pair_kernel<WGM, WGN, TM, TN, NS, BK, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[rms]) {
+    static DeviceOnce attr_set[2];
+    if (attr_set[rms].need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[rms] = true;
+        attr_set[rms].done();
     }
     const int na = cdiv(a.M, BM) * cdiv(a.N, BN), nb = cdiv(b.M, BM) * cdiv(b.N, BN);
     const dim3 grid(na + nb), block(WGM * WGN * 64);

@@ -17,6 +17,7 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 
@@ -213,21 +214,60 @@ int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s) {
     return 0;
 }
 
+// strided rows -> bf16 (the activation images of the bf16 engine where a producer cannot write them itself); cols % 4 == 0 takes the 16-byte path
+__global__ __launch_bounds__(256) void cvt_rows_bf16_kernel(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols) {
+    const int c4 = cols >> 2;
+    const int64_t n4 = (int64_t)rows * c4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4; const int c = (int)(i % c4) * 4;
+        store_bf16x4(dst + r * ldd + c, *reinterpret_cast<const f32x4*>(src + r * lds + c));
+    }
+}
+__global__ __launch_bounds__(256) void cvt_rows_bf16_scalar_kernel(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[(i / cols) * ldd + i % cols] = bf16_bits(src[(i / cols) * lds + i % cols]);
+}
+int cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const bool v4 = (cols % 4) == 0 && (lds % 4) == 0 && (ldd % 4) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0;
+    const int64_t n = (int64_t)rows * (v4 ? cols / 4 : cols);
+    int64_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (v4) hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3((unsigned)g), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    else hipLaunchKernelGGL(cvt_rows_bf16_scalar_kernel, dim3((unsigned)g), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- per-launch timing (bench.py's cfg-5 leg) ----------------------------------------------------------------------------------
-struct Bf16Prof { hipEvent_t a, b; double flops; };
+struct Bf16Prof { hipEvent_t a, b; double flops; int M, N, K, flags, batch; };
 static std::vector<Bf16Prof> g_bprof;
 static int g_bprof_stride = 0, g_bprof_tick = 0;        // 0 = off; n = every n-th launch carries an event pair
 void gemm_bf16_profile_enable(int stride) { g_bprof_stride = stride; g_bprof_tick = 0; }
 bool gemm_bf16_profile_active() { return g_bprof_stride > 0; }
 int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count) {
     *ms = 0; *flops = 0; *count = 0;
+    static const bool log_shapes = getenv("D4_GEMM_LOG") != nullptr;       // per-shape table on stderr
+    struct Agg { Bf16Prof r; double ms, fl; int64_t n; };
+    std::vector<Agg> shapes;
     for (auto& r : g_bprof) {
         D4_HIP(hipEventSynchronize(r.b));
         float t = 0.f;
         D4_HIP(hipEventElapsedTime(&t, r.a, r.b));
         *ms += t; *flops += r.flops; *count += 1;
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        if (log_shapes) {
+            bool hit = false;
+            for (auto& a : shapes)
+                if (a.r.M == r.M && a.r.N == r.N && a.r.K == r.K && a.r.flags == r.flags && a.r.batch == r.batch) { a.ms += t; a.fl += r.flops; a.n += 1; hit = true; break; }
+            if (!hit) shapes.push_back(Agg{r, t, r.flops, 1});
+        }
     }
+    if (log_shapes)
+        for (auto& a : shapes)
+            fprintf(stderr, "[d4 gemm bf16] M %6d N %5d K %5d batch %2d flags %3d : %6lld launches %9.3f ms (%5.1f %%) avg %7.1f us %6.1f TF/s\n", a.r.M, a.r.N, a.r.K,
+                    a.r.batch, a.r.flags, (long long)a.n, a.ms, 100 * a.ms / (*ms > 0 ? *ms : 1), 1e3 * a.ms / a.n, a.fl / a.ms / 1e9);
     g_bprof.clear();
     return 0;
 }
@@ -237,16 +277,17 @@ static int launch_bf16(const GemmArgs& p, hipStream_t stream) {
     constexpr int LDS_LD = BK + 8;
     const size_t lds = (size_t)(2 * BM * LDS_LD + 2 * BN * LDS_LD) * 2 + BM * sizeof(float);
     auto k = gemm_bf16_kernel<BM, BN, WGM, WGN, BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
     if (g_bprof_stride > 0 && (g_bprof_tick++ % g_bprof_stride) == 0) {
         Bf16Prof r{};
         D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));
         r.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+        r.M = p.M; r.N = p.N; r.K = p.K; r.flags = p.flags; r.batch = p.batch;
         hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, r.a, r.b, 0, p);
         g_bprof.push_back(r);
     } else {
@@ -254,6 +295,25 @@ static int launch_bf16(const GemmArgs& p, hipStream_t stream) {
     }
     D4_LAUNCH_CHECK();
     return 0;
+}
+
+// bf16 activations + bf16 weights (gemm_bf16a.hip): tile by shape rule, with this file's optional per-launch event pair
+static int g_bf16a_forced = -1;          // test / microbenchmark hook (d4_gemm_force_config(400 + c))
+void gemm_bf16a_force_config(int id) { g_bf16a_forced = id; }
+int gemm_bf16a(const GemmArgs& p, hipStream_t stream) {
+    D4_REQUIRE(gemm_bf16a_applicable(p), "gemm_bf16a: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
+    D4_REQUIRE(p.C || p.Cb, "gemm_bf16a: no output");
+    const int c = gemm_bf16a_config_valid(g_bf16a_forced, p) ? g_bf16a_forced : gemm_bf16a_rule(p);
+    if (g_bprof_stride > 0 && (g_bprof_tick++ % g_bprof_stride) == 0) {
+        Bf16Prof r{};
+        D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));
+        r.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+        r.M = p.M; r.N = p.N; r.K = p.K; r.flags = p.flags | 1024; r.batch = p.batch;          // (1024 marks the bf16-activation kernel in the shape log)
+        const int rc = gemm_bf16a_launch(c, p, stream, r.a, r.b);
+        g_bprof.push_back(r);
+        return rc;
+    }
+    return gemm_bf16a_launch(c, p, stream, nullptr, nullptr);
 }
 
 bool gemm_bf16_applicable(const GemmArgs& p) {
@@ -290,6 +350,7 @@ static int launch_dma(int c, const GemmArgs& p, hipStream_t stream) {
         Bf16Prof r{};
         D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));
         r.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+        r.M = p.M; r.N = p.N; r.K = p.K; r.flags = p.flags; r.batch = p.batch;
         const int rc = gemm_bf16_dma_launch(c, p, stream, r.a, r.b);
         g_bprof.push_back(r);
         return rc;

@@ -256,10 +256,10 @@ static int launch_bd(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
     const size_t lds = (size_t)NS * (BM * 128 + BN * 64) + BM * sizeof(float);
     const bool rms = (p.flags & GEMM_RMS_ROWSCALE) != 0;
     auto k = rms ? gemm_bf16_dma_kernel<WGM, WGN, TM, TN, NS, true> : gemm_bf16_dma_kernel<WGM, WGN, TM, TN, NS, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[rms]) {
+    static DeviceOnce attr_set[2];
+    if (attr_set[rms].need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[rms] = true;
+        attr_set[rms].done();
     }
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
     if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, p);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     const int bz = blockIdx.y;
     const uint16_t* Ab = p.Ab + bz * p.strideA;
     const uint16_t* Wb = p.Wb + bz * p.strideW;
-    p.C += bz * p.strideC;
+    if (p.C) p.C += bz * p.strideC;                  // (C may be null: only the bf16 copy Cb is wanted)
     if (p.Cb) p.Cb += bz * p.strideC;
     if (p.R) p.R += bz * p.strideC;
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
 
     // ---- epilogue (gemm2.hip's): D[i][j]: i = W row (n) = 4 * (lane >> 4) + reg, j = A row (m) = lane & 15 -> four consecutive n per lane
     const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
-    const bool vecC = (p.ldc % 4) == 0 && ((uintptr_t)p.C % 16) == 0;
+    const bool vecC = p.C && (p.ldc % 4) == 0 && ((uintptr_t)p.C % 16) == 0;
     const bool vecR = p.R && (p.ldr % 4) == 0 && ((uintptr_t)p.R % 16) == 0;
     const bool vecC2 = p.C2 && (p.ldc2 % 4) == 0 && ((uintptr_t)p.C2 % 16) == 0;
     auto store_b = [&](int64_t row, int col, const f32x4& v, bool full, int ncols) {          // bf16 copy for the next GEMM
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
                     const int on = (gn / 64) * 32 + (gn % 64);
                     float* cp = p.C + (int64_t)gm * p.ldc + on;
                     if (vecC) *reinterpret_cast<f32x4*>(cp) = o;
-                    else { cp[0] = o[0]; cp[1] = o[1]; cp[2] = o[2]; cp[3] = o[3]; }
+                    else if (p.C) { cp[0] = o[0]; cp[1] = o[1]; cp[2] = o[2]; cp[3] = o[3]; }
                     store_b(gm, on, o, true, p.N / 2);
                 }
             }
@@ -262,12 +262,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
                 }
             }
             float* cp = p.C + (int64_t)gm * p.ldc + gn;
-            if (p.flags & GEMM_ACCUMULATE) {
+            if ((p.flags & GEMM_ACCUMULATE) && p.C) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (full || gn + e < p.N) v[e] += cp[e];
             }
             if (vecC && full) *reinterpret_cast<f32x4*>(cp) = v;
-            else {
+            else if (p.C) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (full || gn + e < p.N) cp[e] = v[e];
             }
@@ -319,10 +319,10 @@ static int launch_va(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
     const size_t lds = (size_t)NS * (BM + BN) * 128 + BM * sizeof(float);
     const bool rms = (p.flags & GEMM_RMS_ROWSCALE) != 0;
     auto k = rms ? gemm_bf16a_kernel<WGM, WGN, TM, TN, NS, true> : gemm_bf16a_kernel<WGM, WGN, TM, TN, NS, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[rms]) {
+    static DeviceOnce attr_set[2];
+    if (attr_set[rms].need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[rms] = true;
+        attr_set[rms].done();
     }
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
     if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, p);

@@ -368,10 +368,10 @@ static int launch_x3(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
     constexpr int LDS_LD = 32 + 8;
     const size_t lds = (size_t)(NBUF * 3 * (BM + BN) * LDS_LD) * 2 + BM * sizeof(float);
     auto k = gemm_x3_kernel<BM, BN, WGM, WGN, D, NBUF, OCC, STAG>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.done();
     }
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
     if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, p);

@@ -430,15 +430,18 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
 // the life of the process (the half-tile mode the engine uses allocates nothing)
 struct SkWs { float* ws = nullptr; unsigned* flags = nullptr; };
 static std::map<hipStream_t, SkWs> g_sk_ws;
-static int g_sk_cus = 0;
+static std::atomic<int> g_sk_cus[64];            // per device id (a process may drive several devices); 0 = not queried yet
 
 static int sk_cus() {
-    if (g_sk_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_sk_cus = n;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::atomic<int>& c = g_sk_cus[dev & 63];
+    int n = c.load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        c.store(n, std::memory_order_relaxed);
     }
-    return g_sk_cus;
+    return n;
 }
 
 
@@ -514,10 +517,10 @@ int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
         }
         a.ws = w.ws; a.flags = w.flags;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS));
-        attr_set = true;
+        attr_set.done();
     }
     const dim3 grid(a.P), block(SK_NT);
     if (ea) hipExtLaunchKernelGGL(gemm_x3sk_kernel, grid, block, (uint32_t)SK_LDS, stream, ea, eb, 0, a);

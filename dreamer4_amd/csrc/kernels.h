@@ -51,6 +51,8 @@ const char* gemm_bf16_dma_config_name(int c);
 int gemm_bf16_dma_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);
 int gemm_bf16_force_config(int id);                          // test / microbenchmark hook; returns the number of configurations
 int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
+int cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, hipStream_t s);      // strided rows -> bf16
+int gemm_bf16a(const GemmArgs& p, hipStream_t stream);        // bf16 activations + bf16 weights: tile by rule, optional event pair (gemm_bf16.hip)
 // bf16 GEMM with bf16 activations, LDS-DMA ring (gemm_bf16a.hip): p.Ab / p.Wb in, fp32 C (+ bf16 copy p.Cb) out
 bool gemm_bf16a_applicable(const GemmArgs& p);
 bool gemm_bf16a_config_valid(int c, const GemmArgs& p);
@@ -116,6 +118,7 @@ struct SmallAttnArgs {
     // rank (i - q_lo, or q_hi - q_lo for the last token).  q_hi == 0 -> all queries, natural order.
     int q_lo = 0, q_hi = 0, q_last = 1;   // q_last = 0: do not add the last token to the restricted query set
     int dh = 64;                          // head dim (16 / 32 / 64): lanes >= dh of the wavefront idle; rows are packed h * dh + lane
+    uint16_t* out_b = nullptr;            // optional bf16 copy of the output (same strides as `out`): the next GEMM's bf16 activation image (bf16 engine)
 };
 int small_attn(const SmallAttnArgs& p, hipStream_t stream);
 
@@ -129,9 +132,10 @@ struct PoolMixArgs {
     const float* k; int ldk;           // [L*M][ldk]: projected keys, row l*M + m
     const float* hid; int D;           // [L*M][D] hiddens
     const float* k_gamma;              // [heads][64]
-    float* u;                          // [M][heads][D]
+    float* u;                          // [M][heads][D]; may be null when u_b is set
     int M, L, heads;
     float eps;
+    uint16_t* u_b = nullptr;           // optional bf16 image of u (bf16 engine: the per-head value GEMM reads this one)
 };
 int pool_mix(const PoolMixArgs& p, hipStream_t stream);
 
@@ -170,6 +174,7 @@ struct TimeAttnArgs {
                                          // time_history_bucket as the value read (the launcher picks its kernel by the bucket of t0)
     float softclamp;
     int dh = 64;                         // head dim (16 / 32 / 64); cache rows are dh wide
+    uint16_t* out_b = nullptr;           // optional bf16 copy of the output rows (same ldo)
 };
 // History-length class the cached-decode launcher picks its kernel by: 0: <= 8 keys (t0 < 8), 1: <= 16 keys, 2: general.
 inline int time_history_bucket(int t0) { return t0 < 8 ? 0 : (t0 < 16 ? 1 : 2); }

@@ -102,10 +102,10 @@ class Experience:
         per_step, per_episode = self.to_buffer_dict()
         batch = self.payload.shape[0]
         episode_kw = {k: (v if torch.is_tensor(v) else [v] * batch) for k, v in per_episode.items()}
-        names = list(per_step)
+        steps = self.payload.shape[1]                      # the payload's time length drives the loop (dreamer4.py:205-213): a shorter field raises
         with buffer.batched_episode(batch_size=batch, **episode_kw):
-            for step_values in zip(*(per_step[k].unbind(1) for k in names)):
-                buffer.store_batch(**dict(zip(names, step_values)))
+            for step in range(steps):
+                buffer.store_batch(**{k: v[:, step] for k, v in per_step.items()})
 
     def cpu(self):
         return self.to(torch.device('cpu'))

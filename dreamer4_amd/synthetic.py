@@ -9,7 +9,7 @@ def randomize_weights(m, seed=0, unembed_scale=30., terminal_bias=-2.5):
     g = torch.Generator().manual_seed(seed)
     post_ln = getattr(m, 'head_mlp_recipe', 'pre_rms') == 'post_layer'
     for name, p in m.named_parameters():
-        if p.numel() == 0:
+        if p.numel() == 0 or name.startswith('video_tokenizer.'):          # a nested tokenizer keeps the weights it came with
             continue
         if name.endswith('gamma'):
             p.copy_(torch.randn(p.shape, generator=g) * 0.2)

@@ -149,6 +149,15 @@ class VideoTokenizer(SaveLoad, nn.Module):
                 out[k] = v
         return out
 
+    def __deepcopy__(self, memo):
+        # engine handles are per-instance device state: a copy starts without any (DynamicsWorldModel deep-copies its tokenizer, dreamer4.py:4788)
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == '_engines' else copy.deepcopy(v, memo)
+        return new
+
     def __del__(self):
         try:
             lib = _lib.load()

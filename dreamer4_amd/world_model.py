@@ -154,6 +154,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         num_discrete_actions: int | tuple = 0,
         num_continuous_actions=0,
         video_tokenizer=None,
+        copy_video_tokenizer=True,
         multi_token_pred_len=8,
         value_head_mlp_depth=3,
         policy_head_mlp_depth=3,
@@ -219,9 +220,17 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         self.reward_encoder_type = reward_encoder_type
         if attn_kwargs or transformer_kwargs or ff_kwargs:
             raise NotImplementedError('attn_kwargs / transformer_kwargs / ff_kwargs must be empty (reference defaults)')
-        # the tokenizer is only used to decode generated latents (generate(return_decoded_video=True), dreamer4.py:6694-6711); like
-        # the reference, its latent shape provides the defaults.  Kept out of the module tree (its weights are not this model's).
-        object.__setattr__(self, 'video_tokenizer', video_tokenizer)
+        # the tokenizer decodes generated latents (generate(return_decoded_video=True), dreamer4.py:6694-6711) and tokenizes video prompts; like
+        # the reference, its latent shape provides the defaults and it is a registered SUBMODULE (dreamer4.py:4787-4794: a frozen deep copy in
+        # eval mode unless copy_video_tokenizer=False), so its weights travel in this model's state_dict under 'video_tokenizer.*' and a
+        # checkpoint restores them.  The dynamics engine never binds those keys (the tokenizer owns its engines).
+        if video_tokenizer is not None:
+            if copy_video_tokenizer:
+                import copy
+                video_tokenizer = copy.deepcopy(video_tokenizer)
+                video_tokenizer.requires_grad_(False)
+            video_tokenizer = video_tokenizer.eval()
+        self.video_tokenizer = video_tokenizer
         if video_tokenizer is not None:
             num_latent_tokens = num_latent_tokens if num_latent_tokens is not None else video_tokenizer.num_latent_tokens
             assert video_tokenizer.num_latent_tokens == num_latent_tokens and video_tokenizer.dim_latent == dim_latent, \
@@ -568,8 +577,8 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
             for p in g['params']:
                 grads[id(p)] = g['grad'][off:off + p.numel()]
                 off += p.numel()
-        tensors = dict(self.named_parameters())
-        tensors.update({k: v for k, v in self.named_buffers() if k not in _NOT_BOUND and not k.startswith(_LOSS_NORMALIZERS)})
+        tensors = {k: v for k, v in self.named_parameters() if not k.startswith('video_tokenizer.')}
+        tensors.update({k: v for k, v in self.named_buffers() if k not in _NOT_BOUND and not k.startswith(_LOSS_NORMALIZERS + ('video_tokenizer.',))})
         sig = tuple((k, t.data_ptr(), t.numel()) for k, t in tensors.items())
         if sig != self._bound_sig:
             for k, t in tensors.items():

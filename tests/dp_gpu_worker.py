@@ -26,9 +26,13 @@ def run(model, noise, B, T, group):
 
 def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    parallel.init_from_env('gloo')
+    backend = os.environ.get('D4_DP_BACKEND', 'gloo')          # 'nccl' = RCCL: one device per rank (tests/test_gpu_dp.py, needs >= 2 GPUs)
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    else:
+        torch.cuda.set_device(0)
+    parallel.init_from_env(backend)
     rank, world = parallel.rank(), parallel.world_size()
-    torch.cuda.set_device(0)
     Bg, T = 6, 4
     m = small_model().cuda()
     cfg = oracle_config(m)
@@ -52,6 +56,8 @@ def main():
         assert (pol - p_ref).abs().mean() < 1e-6 and (val - v_ref).abs().mean() < 1e-6
     # every rank must hold identical weights after the step
     chk = torch.stack([pol.double().sum(), val.double().sum()])
+    if backend == 'nccl':
+        chk = chk.cuda()
     gathered = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(gathered, chk)
     assert all(torch.equal(g, gathered[0]) for g in gathered), gathered

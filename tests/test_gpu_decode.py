@@ -80,7 +80,7 @@ def test_generate_returns_the_decoded_video():
     tok = _fresh(dict(dim=32, dim_latent=8, patch_size=4, image_size=16, num_latent_tokens=6, decoder_depth=2, time_block_every=2, attn_heads=2), seed=3)
     torch.manual_seed(0)
     m = randomize_weights(DynamicsWorldModel(dim=64, dim_latent=8, depth=4, time_block_every=2, attn_heads=2, num_discrete_actions=4, video_tokenizer=tok))
-    assert m.num_latent_tokens == 6 and not any(k.startswith('video_tokenizer') for k in m.state_dict())
+    assert m.num_latent_tokens == 6 and 'video_tokenizer.latents_to_decoder.weight' in m.state_dict()      # a submodule, as in the reference (dreamer4.py:4794)
     m, tok = m.cuda(), tok.cuda()
     cfg = oracle_config(m)
     nz = make_noise(cfg, 3, 2, 11)

@@ -17,3 +17,18 @@ def test_two_ranks_equal_one_process_at_the_global_batch():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count('DPGPU_OK_') == 2, out.stdout
+
+
+def test_two_ranks_over_rccl_equal_one_process_at_the_global_batch():
+    """The same check with one MI355X per rank and backend "nccl" (= RCCL over xGMI): the gradient buckets, the global statistics and the
+    parameter checks cross devices through the collective library the 8-GPU run uses (trainers.py:1388-1396, 1436-1452 — the reference's
+    implicit DDP all-reduce).  Skipped on a one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (one per rank for RCCL)')
+    env = dict(os.environ, D4_DP_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29673', os.path.join(ROOT, 'tests', 'dp_gpu_worker.py')]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count('DPGPU_OK_') == 2, out.stdout

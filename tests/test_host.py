@@ -245,8 +245,19 @@ def test_checkpoint_files_laid_out_as_the_reference_trainer_writes_them(tmp_path
     assert set(pkg) >= {'model', 'config', 'step'} and pkg['step'] == 7 and isinstance(pkg['config'], bytes)
     args, kwargs = pickle.loads(pkg['config'])                       # unpickles without this package's classes: plain containers only
     assert args == () and kwargs['video_tokenizer']['__d4_module__'] == 'VideoTokenizer'
+    # the tokenizer is a frozen deep copy registered as a submodule (dreamer4.py:4787-4794): its weights travel in the state_dict
+    assert m.video_tokenizer is not tok and not any(p.requires_grad for p in m.video_tokenizer.parameters()) and not m.video_tokenizer.training
+    tok_keys = [k for k in pkg['model'] if k.startswith('video_tokenizer.')]
+    assert len(tok_keys) == len(tok.state_dict()) > 0
+    with torch.no_grad():
+        for p in m.video_tokenizer.parameters():
+            p.add_(0.37)                                                 # not the constructor's init any more
+    m.save(tmp_path / 'a.pt', step=7)
     m2 = DynamicsWorldModel.init_and_load(tmp_path / 'a.pt')
     assert isinstance(m2.video_tokenizer, VideoTokenizer) and m2.video_tokenizer.image_height == 16
+    for k, v in m.video_tokenizer.state_dict().items():
+        assert torch.equal(m2.video_tokenizer.state_dict()[k], v), k
+    assert not torch.equal(m2.video_tokenizer.state_dict()['latents_to_decoder.weight'], tok.state_dict()['latents_to_decoder.weight'])
     assert m2.latent_flow_loss_weight == 0.5 and torch.equal(m2.reward_loss_weight, torch.tensor([1., 0.25]))
     # by hand, the way save_checkpoint does it, with an already-plain config and a step
     plain = dict(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, num_discrete_actions=4, multi_token_pred_len=2)
