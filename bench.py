@@ -238,7 +238,7 @@ def cfg5_bf16(device, lib, B=128, frames=16, reps=2):
     return dict(value=round(steps / dt, 1), unit='imagined steps/s', ms_per_rollout=round(1e3 * dt, 2), dtype='bf16 MFMA (fp32 accumulate / norms / softmax)',
                 workload=f'cfg5: dim=1024 depth=12 latents=64x32, 6 continuous actions, B={B}, H={frames - 1}, num_steps={NUM_STEPS}; rollout only',
                 rollout_algorithmic_tflops=round(FLOP_PER_IMAGINED_STEP_CFG5 * steps / dt / 1e12, 1),
-                roofline=dict(bound='mfma', kernel='gemm_bf16_kernel (all bf16 trunk GEMMs)', achieved=round(ach, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s',
+                roofline=dict(bound='mfma', kernel='gemm_bf16a_kernel / gemm_bf16_kernel (all bf16 trunk GEMMs: bf16 activation images by LDS-DMA where the activation has one)', achieved=round(ach, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s',
                               frac=round(ach / PEAK_BF16_MFMA_TFLOPS, 4), launches_timed=int(cnt.value), event_stride=5,
                               avg_launch_us=round(1e3 * ms.value / max(cnt.value, 1), 2)))
 

@@ -446,7 +446,7 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------
 // AttentionPool (D4:2143-2177) with the value side restructured (see PoolMixArgs).  One wave per token row.
-template <int ITER>
+template <int ITER, bool DEEP = false>
 __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     constexpr int PH = 4, LMAX = 64;
     __shared__ float psh[4][LMAX * PH];
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     const int m = blockIdx.x * 4 + wslot;
     if (m >= p.M) return;
     const int lane = threadIdx.x & 63;
-    pool_mix_row<ITER>(p, m, lane, psh[wslot], gws, [&](int h, int c4, const f32x4& v) {
+    pool_mix_row<ITER, DEEP>(p, m, lane, psh[wslot], gws, [&](int h, int c4, const f32x4& v) {
         if (p.u) reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = v;
         if (p.u_b) store_bf16x4(p.u_b + ((int64_t)m * PH + h) * D + 4 * c4, v);
     });
@@ -634,6 +634,9 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     const double pm_bytes = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
     if (p.D <= 256) hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p);
     else if (p.D <= 512) D4_GLUE_LAUNCH(GL_POOL_MIX, pm_bytes, pool_mix_kernel<2>, grid, block, 0, stream, p);
+    // D > 512 (BASELINE config 5: dim 1024): few rows leave a SIMD with under two waves, and a row is then 2 L dependent memory round trips —
+    // the deep form requests the key rows in batches of 8 and the hidden rows 3 ahead
+    else if (p.M < 8192) hipLaunchKernelGGL((pool_mix_kernel<4, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL(pool_mix_kernel<4>, grid, block, 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;

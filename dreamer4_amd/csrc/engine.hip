@@ -633,6 +633,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         PoolMixArgs pm{};
         pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
+        if (t_bf16 && D > 512) pm.hid_b = t_bf16->shadow_of(hiddens);     // (D <= 512 may take the block-per-row form, which reads fp32)
         if (t_bf16) if (uint16_t* ub = t_bf16->shadow_of(e->pool_u)) { pm.u_b = ub; if (t_bf16->shadow_only(e->pool_u)) pm.u = nullptr; }   // only the value GEMM reads the mixes
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
         // D4_FRAME_FUSED=2: the mix stays its own kernel and only the tail is fused
@@ -1474,6 +1475,7 @@ int d4_gemm_bf16a(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, floa
     d4::GemmArgs g{nullptr, lda, nullptr, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
     g.Ab = Ab; g.Wb = Wb; g.Cb = Cb;
     D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a: call not supported (K %% 64, lda / ldw %% 8, 16-byte aligned operands)");
+    if (config >= 100) { g.group_m = -1; config -= 100; }       // 100 + c: configuration c with the plain row-major tile order (A/B of the grouped order)
     return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
 }
 

@@ -42,12 +42,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     constexpr int STAGE_B = STAGE_ROWS * BKB;       // bytes per ring stage
     constexpr int NSLOT = STAGE_ROWS / RPP;
     constexpr int LPW = (NSLOT + NW - 1) / NW;
-    static_assert(NS >= 3 && NS <= 4 && 2 * LPW <= 63, "ring depth / vmcnt range");
+    static_assert(NS >= 3 && NS <= 8 && (NS - 2) * LPW <= 63, "ring depth / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];   // [NS][STAGE_ROWS][128 B] | rowscale[BM] floats
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    constexpr bool LATE = false;             // (measured: issuing the ring refill behind the first half's MFMAs changes nothing)
 
     int bid = blockIdx.x;
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
@@ -56,7 +57,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
         const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
     }
-    const int bm0 = (bid / nbn) * BM, bn0 = (bid % nbn) * BN;
+    int tr = bid / nbn, tc = bid % nbn;
+    if (p.group_m > 0) {                                     // grouped order: bid -> (group of row panels, column, row inside the group)
+        const int per = p.group_m * nbn, g = bid / per, r = bid % per;
+        const int gm_eff = min(p.group_m, nbm - g * p.group_m);
+        tr = g * p.group_m + r % gm_eff; tc = r / gm_eff;
+    }
+    const int bm0 = tr * BM, bn0 = tc * BN;
     const int bz = blockIdx.y;
     const uint16_t* Ab = p.Ab + bz * p.strideA;
     const uint16_t* Wb = p.Wb + bz * p.strideW;
@@ -110,8 +117,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     for (int i = 0; i < SQI; ++i) ssq[i] = 0.f;
 
     const int nk = p.K / 64;
-    auto wait_allow = [&](int stages) {
-        if (stages >= 2) wait_vmcnt_b<2 * LPW>();
+    auto wait_allow = [&](int stages) {              // at most NS - 2 stages are ever allowed to stay in flight
+        if (NS >= 8 && stages >= 6) wait_vmcnt_b<(NS >= 8 ? 6 : 0) * LPW>();
+        else if (NS >= 7 && stages == 5) wait_vmcnt_b<(NS >= 7 ? 5 : 0) * LPW>();
+        else if (NS >= 6 && stages == 4) wait_vmcnt_b<(NS >= 6 ? 4 : 0) * LPW>();
+        else if (NS >= 5 && stages == 3) wait_vmcnt_b<(NS >= 5 ? 3 : 0) * LPW>();
+        else if (stages >= 2) wait_vmcnt_b<2 * LPW>();
         else if (stages == 1) wait_vmcnt_b<LPW>();
         else wait_vmcnt_b<0>();
     };
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
         if (kt + 1 < nk) {
             wait_allow(min(kt + NS - 2, nk - 1) - (kt + 1));
             __builtin_amdgcn_s_barrier();
-            if (kt + NS - 1 < nk) { D4_ISSUE_STAGE_B(kt + NS - 1, (kt + NS - 1) % NS) }
+            if (!LATE && kt + NS - 1 < nk) { D4_ISSUE_STAGE_B(kt + NS - 1, (kt + NS - 1) % NS) }
         }
         const char* st = smem_b + (kt % NS) * STAGE_B;
         const char* nxt = smem_b + ((kt + 1) % NS) * STAGE_B;
@@ -165,6 +176,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
         }
         read_frags(st, S1{}, 1);
         mfma_set(S0{});
+        // LATE: the ring refill is issued BEHIND the first half's MFMAs, so the matrix pipe has work queued while the DMA pieces issue
+        if (LATE && kt + 1 < nk && kt + NS - 1 < nk) { D4_ISSUE_STAGE_B(kt + NS - 1, (kt + NS - 1) % NS) }
         if (kt + 1 < nk) read_frags(nxt, S0{}, 0);
         mfma_set(S1{});
     }
@@ -297,8 +310,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
 // 64x64/s     4 x 1    16 x 64     64 x 64     4 x 16 KB       2          SiLU-GLU capable
 // 32x64       2 x 2    16 x 32     32 x 64     4 x 12 KB       3
 // 256x128     4 x 2    64 x 64    256 x 128    3 x 48 KB       1          SiLU-GLU capable (large problems)
-enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_N };
-static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128};
+enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_128x128_4, VA_128x64_6, VA_64x64_8, VA_64x64_s8, VA_32x64_8, VA_N };
+static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256, 128, 128, 64, 64, 32}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128, 128, 64, 64, 64, 64};
 
 int gemm_bf16a_configs() { return VA_N; }
 
@@ -309,7 +322,7 @@ bool gemm_bf16a_applicable(const GemmArgs& p) {
 
 bool gemm_bf16a_config_valid(int c, const GemmArgs& p) {
     if (c < 0 || c >= VA_N || !gemm_bf16a_applicable(p)) return false;
-    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128;
+    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128 || c == VA_128x128_4 || c == VA_64x64_s8;
     return true;
 }
 
@@ -325,8 +338,21 @@ static int launch_va(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
         attr_set[rms].done();
     }
     const dim3 grid(cdiv(p.M, BM) * cdiv(p.N, BN), p.batch > 0 ? p.batch : 1), block(WGM * WGN * 64);
-    if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, p);
-    else hipLaunchKernelGGL(k, grid, block, lds, stream, p);
+    GemmArgs q = p;
+    if (q.group_m == 0) {
+        // rows of operand panels the ~32 concurrent tiles of one XCD touch: gm * BM + ceil(32 / gm) * BN, minimised over the group height
+        const int nbm = cdiv(p.M, BM), nbn = cdiv(p.N, BN);
+        int best = 1; long best_cost = -1;
+        for (int gm = 1; gm <= 16 && gm <= nbm; ++gm) {
+            const int cols = (32 + gm - 1) / gm;
+            const long cost = (long)gm * BM + (long)(cols < nbn ? cols : nbn) * BN;
+            if (best_cost < 0 || cost < best_cost) { best = gm; best_cost = cost; }
+        }
+        static const bool grouped = !(getenv("D4_BF16A_GROUPED") && atoi(getenv("D4_BF16A_GROUPED")) == 0);
+        q.group_m = grouped ? best : 0;
+    } else if (q.group_m < 0) q.group_m = 0;
+    if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, q);
+    else hipLaunchKernelGGL(k, grid, block, lds, stream, q);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -340,6 +366,12 @@ int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t e
         case VA_64x64_s: return launch_va<4, 1, 1, 4, 4>(p, stream, ea, eb);
         case VA_32x64: return launch_va<2, 2, 1, 2, 4>(p, stream, ea, eb);
         case VA_256x128: return launch_va<4, 2, 4, 4, 3>(p, stream, ea, eb);
+        // deep rings (one workgroup per CU, the whole LDS in flight)
+        case VA_128x128_4: return launch_va<4, 2, 2, 4, 4>(p, stream, ea, eb);
+        case VA_128x64_6: return launch_va<4, 2, 2, 2, 6>(p, stream, ea, eb);
+        case VA_64x64_8: return launch_va<2, 2, 2, 2, 8>(p, stream, ea, eb);
+        case VA_64x64_s8: return launch_va<4, 1, 1, 4, 8>(p, stream, ea, eb);
+        case VA_32x64_8: return launch_va<2, 2, 1, 2, 8>(p, stream, ea, eb);
     }
     return 2;
 }

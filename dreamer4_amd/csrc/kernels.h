@@ -35,6 +35,8 @@ struct GemmArgs {
                                        // bf16-activation kernel (gemm_bf16a.hip) and never touches the fp32 A
     uint16_t* Cb = nullptr;            // optional bf16 copy of the output ([M][ldc]; SiLU-GLU: [M][N/2] at ldc), for the next GEMM's Ab
     uint16_t* C2b = nullptr;           // ... and of the row-compacted second output ([rows][ldc2])
+    int group_m = 0;                   // > 0 (gemm_bf16a.hip): tiles are walked in groups of `group_m` row panels, column-major inside a group, so the
+                                       // ~32 tiles an XCD runs at a time share few operand panels (its 4 MB L2 then holds them); 0: row-major
     int64_t wplane = 0;                // > 0: Wb holds THREE bf16 planes (W = W1 + W2 + W3, plane stride in elements) and the call runs as
                                        // an fp32 GEMM on the bf16 matrix cores (split operands, six products: gemm_x3.hip)
 };
@@ -136,6 +138,8 @@ struct PoolMixArgs {
     int M, L, heads;
     float eps;
     uint16_t* u_b = nullptr;           // optional bf16 image of u (bf16 engine: the per-head value GEMM reads this one)
+    const uint16_t* hid_b = nullptr;   // optional bf16 image of the hiddens (bf16 engine): read instead of `hid` by the one-wave-per-row form — the
+                                       // values the pool's key GEMM consumed, at half the bytes of the kernel's dominant stream
 };
 int pool_mix(const PoolMixArgs& p, hipStream_t stream);
 

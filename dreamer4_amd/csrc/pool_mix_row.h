@@ -71,6 +71,17 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
     constexpr int RD = DEEP ? 3 : 1;
     f32x4 vn[RD][ITER];
     auto load_row = [&](int l, f32x4 (&dst)[ITER]) {
+        if (p.hid_b) {                                   // bf16 image of the hiddens: 8 bytes per lane and group
+            const uint2* hb = reinterpret_cast<const uint2*>(p.hid_b + ((int64_t)l * p.M + m) * D);
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                const int c4 = lane + 64 * i;
+                const uint2 raw = c4 < nf4 ? hb[c4] : uint2{0u, 0u};
+                dst[i] = f32x4{__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
+                               __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
+            }
+            return;
+        }
         const f32x4* hr = reinterpret_cast<const f32x4*>(p.hid + ((int64_t)l * p.M + m) * D);
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {

@@ -21,12 +21,12 @@ for M, N, K, name in shapes:
     g = torch.Generator(device='cuda').manual_seed(1)
     Ab = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16); Wb = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).to(torch.bfloat16)
     out = torch.empty(M, N, device='cuda'); outb = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-    for flags in (0, RMS, SWIGLU, RMS | SWIGLU):
+    for flags in (0, RMS | SWIGLU):
         if (flags & SWIGLU) and N % 64: continue
         Nout = N // 2 if flags & SWIGLU else N
-        for cb in (True, False):
+        for cb in (True,):
             ts = []
-            for c in range(NC):
+            for c in list(range(6)) + [100 + i for i in range(6)]:
                 call = lambda: lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(outb) if cb else None, None, None, 0, M, N, K, flags, 1e-6, c, s)
                 ts.append(timeit(call) if call() == 0 else float('nan'))
             print(f'{name:8s} M{M:6d} N{N:5d} K{K:5d} flags {flags} Cb {int(cb)}: ' + ' '.join(f'{t:7.1f}' for t in ts) + f' | best {2.0 * M * N * K / min(t for t in ts if t == t) / 1e6:6.0f} TF/s')
