@@ -251,9 +251,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the per-launch HIP-event timing of the GEMMs')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary cfg4 (decode latency) / cfg5 (bf16) measurements')
+    ap.add_argument('--allow-experiment-env', action='store_true', help='run although an experiment switch (dreamer4_amd/knobs.py) is set; it is reported in the JSON')
     args = ap.parse_args()
 
     from dreamer4_amd import DreamTrainer, _lib, parallel
+    from dreamer4_amd.knobs import experiment_overrides
+    env_over = experiment_overrides()
+    assert not env_over or args.allow_experiment_env, (f'experiment switches set: {env_over} - the bench measures the product defaults (the ones the GPU tests '
+                                                      'run under); unset them or pass --allow-experiment-env')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -426,7 +431,7 @@ def main():
                              'generate(H+1=16 frames, num_steps=4, time cache) + learn_from_experience(ppo) + clip/AdamW both heads',
                     global_batch=world * B_LOCAL, per_gpu_batch=B_LOCAL, horizon=HORIZON, num_steps=NUM_STEPS, parallelism=f'dp{world}'),
         generate_ms=round(sum(gen_ms) / len(gen_ms), 2), actor_critic_step_ms=round(sum(learn_ms) / len(learn_ms), 2),
-        per_rank=per_rank,
+        per_rank=per_rank, experiment_env=env_over,
         rollout_steps_per_sec=round(world * B_LOCAL * (HORIZON + 1) / (sum(gen_ms) / len(gen_ms) * 1e-3), 1),
         roofline=roofline,
     )

@@ -1479,6 +1479,21 @@ int d4_gemm_bf16a(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, floa
     return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
 }
 
+int d4_gemm_bf16a_batched(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
+                          int M, int N, int K, int flags, float rms_eps, int batch, int64_t strideA, int64_t strideW, int64_t strideC, int config, void* stream) {
+    d4::GemmArgs g{nullptr, lda, nullptr, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.Ab = Ab; g.Wb = Wb; g.Cb = Cb;
+    g.batch = batch; g.strideA = strideA; g.strideW = strideW; g.strideC = strideC;
+    D4_REQUIRE(C || Cb, "d4_gemm_bf16a_batched: no output");
+    D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a_batched: call not supported (K %% 64, lda / ldw / strides %% 8, 16-byte aligned operands)");
+    if (M == 0) return 0;
+    return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
+}
+int d4_cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, void* stream) {
+    D4_REQUIRE(src && dst && rows >= 0 && cols >= 0 && lds >= cols && ldd >= cols, "d4_cvt_rows_bf16: bad arguments");
+    return d4::cvt_rows_bf16(src, lds, dst, ldd, rows, cols, static_cast<hipStream_t>(stream));
+}
+
 int d4_rmsnorm(const float* x, int ldx, const float* gamma, float* y, int ldy, int rows, int dim, float eps, void* stream) {
     return d4::rmsnorm_rows(x, ldx, gamma, y, ldy, rows, dim, eps, static_cast<hipStream_t>(stream));
 }

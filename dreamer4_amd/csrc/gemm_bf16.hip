@@ -345,47 +345,12 @@ static bool bf16_cfg_valid(int id, const GemmArgs& p) {
     return true;
 }
 
-static int launch_dma(int c, const GemmArgs& p, hipStream_t stream) {
-    if (g_bprof_stride > 0 && (g_bprof_tick++ % g_bprof_stride) == 0) {
-        Bf16Prof r{};
-        D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));
-        r.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
-        r.M = p.M; r.N = p.N; r.K = p.K; r.flags = p.flags; r.batch = p.batch;
-        const int rc = gemm_bf16_dma_launch(c, p, stream, r.a, r.b);
-        g_bprof.push_back(r);
-        return rc;
-    }
-    return gemm_bf16_dma_launch(c, p, stream, nullptr, nullptr);
-}
-
-// the LDS-DMA form's tile for a call, by shape only (-1: stay on the register-staged form).  OFF unless D4_BF16_DMA=1: measured on
-// config 5's shapes (tools/gemm_bf16_bench.py, profiles/r02_gemm_bf16_dma.txt) it ties with the register-staged form (ff1 47.4 vs 47.7 us,
-// 426 TF/s) — the bf16 GEMMs here are bound by operand FETCH (fp32 activations: 468 MB through the L2s per ff1 launch = 9.7 TB/s, and
-// <= ~100 KB in flight per CU against ~2 us of loaded latency), not by how the tiles enter LDS.  bf16 activations between producer and
-// consumer + 256 x 256 tiles is what moves it; this form is kept as the base for that.
-static int dma_rule(const GemmArgs& p) {
-    static const bool on = getenv("D4_BF16_DMA") && atoi(getenv("D4_BF16_DMA")) != 0;
-    if (!on || !gemm_bf16_dma_applicable(p) || (p.strideW % 8) != 0) return -1;
-    const int nb = p.batch > 0 ? p.batch : 1;
-    const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
-    if (p.K < 128 || p.N < 128) return -1;
-    if (t128 >= 512 && p.N >= 256) return 1;            // 128 x 256
-    if (t128 >= 128) return 0;                          // 128 x 128
-    return -1;
-}
-
 // tile choice by rule
 int gemm_bf16(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(gemm_bf16_applicable(p), "gemm_bf16: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
     const bool swiglu = (p.flags & GEMM_SWIGLU) != 0;
     const int nb = p.batch > 0 ? p.batch : 1;
     const bool k64 = (p.K % 64) == 0;
-    if (g_bf16_forced >= 100) {
-        if (gemm_bf16_dma_config_valid(g_bf16_forced - 100, p)) return launch_dma(g_bf16_forced - 100, p, stream);
-    } else if (g_bf16_forced < 0) {
-        const int c = dma_rule(p);
-        if (c >= 0 && gemm_bf16_dma_config_valid(c, p)) return launch_dma(c, p, stream);
-    }
     int id;
     if (bf16_cfg_valid(g_bf16_forced, p)) id = g_bf16_forced;
     else {

@@ -310,8 +310,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
 // 64x64/s     4 x 1    16 x 64     64 x 64     4 x 16 KB       2          SiLU-GLU capable
 // 32x64       2 x 2    16 x 32     32 x 64     4 x 12 KB       3
 // 256x128     4 x 2    64 x 64    256 x 128    3 x 48 KB       1          SiLU-GLU capable (large problems)
-enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_128x128_4, VA_128x64_6, VA_64x64_8, VA_64x64_s8, VA_32x64_8, VA_N };
-static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256, 128, 128, 64, 64, 32}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128, 128, 64, 64, 64, 64};
+// Measured and retired (round 4, tools/bf16a_probe.py): rings of 4 - 8 stages at one workgroup per CU (the whole LDS in flight) are level or slower
+// than these — two co-resident workgroups hide more than a deeper ring; the k-loop step (~0.6 - 0.7 us for 128 x 128 x 64 even on a quarter of
+// the CUs) is bound inside the workgroup (barrier / DMA issue / fragment reads per k-tile), not by bytes in flight.
+enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_N };
+static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128};
 
 int gemm_bf16a_configs() { return VA_N; }
 
@@ -322,7 +325,7 @@ bool gemm_bf16a_applicable(const GemmArgs& p) {
 
 bool gemm_bf16a_config_valid(int c, const GemmArgs& p) {
     if (c < 0 || c >= VA_N || !gemm_bf16a_applicable(p)) return false;
-    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128 || c == VA_128x128_4 || c == VA_64x64_s8;
+    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128;
     return true;
 }
 
@@ -366,12 +369,6 @@ int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t e
         case VA_64x64_s: return launch_va<4, 1, 1, 4, 4>(p, stream, ea, eb);
         case VA_32x64: return launch_va<2, 2, 1, 2, 4>(p, stream, ea, eb);
         case VA_256x128: return launch_va<4, 2, 4, 4, 3>(p, stream, ea, eb);
-        // deep rings (one workgroup per CU, the whole LDS in flight)
-        case VA_128x128_4: return launch_va<4, 2, 2, 4, 4>(p, stream, ea, eb);
-        case VA_128x64_6: return launch_va<4, 2, 2, 2, 6>(p, stream, ea, eb);
-        case VA_64x64_8: return launch_va<2, 2, 2, 2, 8>(p, stream, ea, eb);
-        case VA_64x64_s8: return launch_va<4, 1, 1, 4, 8>(p, stream, ea, eb);
-        case VA_32x64_8: return launch_va<2, 2, 1, 2, 8>(p, stream, ea, eb);
     }
     return 2;
 }

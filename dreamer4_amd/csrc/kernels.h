@@ -45,12 +45,6 @@ int gemm(const GemmArgs& p, hipStream_t stream);
 // bf16 MFMA path (gemm_bf16.hip): A fp32 rounded to bf16 on the way into LDS, W pre-converted, fp32 accumulate / epilogue
 bool gemm_bf16_applicable(const GemmArgs& p);
 int gemm_bf16(const GemmArgs& p, hipStream_t stream);
-// second bf16 form (gemm_bf16_dma.hip): both operand tiles by LDS-DMA, A converted from the fp32 LDS tile at fragment-read time
-bool gemm_bf16_dma_applicable(const GemmArgs& p);
-bool gemm_bf16_dma_config_valid(int c, const GemmArgs& p);
-int gemm_bf16_dma_configs();
-const char* gemm_bf16_dma_config_name(int c);
-int gemm_bf16_dma_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb);
 int gemm_bf16_force_config(int id);                          // test / microbenchmark hook; returns the number of configurations
 int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
 int cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, hipStream_t s);      // strided rows -> bf16

@@ -516,7 +516,8 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
                           continuous_actions=None):
     """The agent-token losses of the training forward (dreamer4.py:7432-7598): multi-token-prediction reward cross entropy against HL-Gauss
     soft targets, terminal BCE with label smoothing, behaviour-cloning log-likelihood of the discrete actions (multi-token prediction,
-    `shift_action_tokens=True`).  Plain torch ops on the device (the heads are three small MLPs on (b, t) rows); their gradients reach the
+    `shift_action_tokens=True`).  Every Linear / RMSNorm runs on the differentiable HIP operators (torch.ops.d4hip.linear / rmsnorm: no vendor
+    BLAS); the loss algebra on their outputs (log-softmax, masks, means) is elementwise torch on the device; gradients reach the
     trunk through `agent_embed`.  Returns a dict of the terms that were asked for: rewards (mtp,), terminals (), discrete_actions (mtp,), continuous_actions (mtp,)."""
     from torch.nn import functional as F
     out = {}
@@ -527,7 +528,11 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
     if rewards is not None:
         two_hot = hl_gauss_probs(rewards, reward_range, reward_num_bins, hl_sigma_ratio, hl_eps)
         x = agent_embed[:, :-1]
-        pred = torch.stack([F.linear(F.rms_norm(x, x.shape[-1:], W['to_reward_pred.params.0'][i], eps), W['to_reward_pred.params.1'][i]) for i in range(mtp)], dim=2)
+        # the ensemble of mtp [RMSNorm -> Linear] members as ONE HIP GEMM: the members' norm gains are folded into their weights (as the engine
+        # does at prepare), so a single unit-gain normalisation of the rows feeds a [mtp * bins][D] weight            dreamer4.py:7440-7450
+        g_, w_ = W['to_reward_pred.params.0'], W['to_reward_pred.params.1']                                    # [mtp][D], [mtp][bins][D]
+        xhat = torch.ops.d4hip.rmsnorm(x.contiguous(), torch.ones_like(g_[0]), eps)
+        pred = torch.ops.d4hip.linear(xhat, (w_ * g_[:, None, :]).reshape(-1, w_.shape[-1]), None, None, 0, 0.).unflatten(-1, (mtp, w_.shape[1]))
         tgt, mask = _mtp_targets(two_hot[:, 1:], mtp)
         losses = -(tgt * pred.log_softmax(dim=-1)).sum(dim=-1).masked_fill(~mask, 0.)
         out['rewards'] = losses[lm[:, :-1]].mean(dim=0) if lm is not None else losses.mean(dim=(0, 1))
@@ -547,7 +552,8 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
         tgt, mask = tgt[:, 1:].clamp(1e-5, 1. - 1e-5), mask[:, 1:]
         per = []
         for i in range(mtp):
-            params = torch.einsum('...d,ndt->...nt', pe, W['action_embedder.continuous_action_unembed'][:, i])
+            wc = W['action_embedder.continuous_action_unembed'][:, i]                                          # [nc][4 D][2]
+            params = torch.ops.d4hip.linear(pe, wc.permute(0, 2, 1).reshape(-1, wc.shape[1]), None, None, 0, 0.).unflatten(-1, (wc.shape[0], 2))
             link = torch.exp if continuous_beta_param == 'exp_p1' else F.softplus
             a, b_ = link(params[..., 0]) + 1., link(params[..., 1]) + 1.
             x = tgt[:, :, i]
@@ -561,7 +567,7 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
         tgt, mask = tgt[:, 1:].clamp(min=0), mask[:, 1:]
         per = []
         for i in range(mtp):
-            logits = F.linear(pe, W['action_embedder.discrete_action_unembed'][:, i])
+            logits = torch.ops.d4hip.linear(pe, W['action_embedder.discrete_action_unembed'][:, i].contiguous(), None, None, 0, 0.)
             lps, o = [], 0
             for a, n in enumerate(num_discrete_actions):
                 lp = logits[..., o:o + n].log_softmax(dim=-1)

@@ -290,6 +290,13 @@ int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C,
 int d4_gemm_bf16a(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
                   int M, int N, int K, int flags, float rms_eps, int config, void* stream);
 int d4_cvt_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
+/* The producer -> consumer hand-off of the bf16 engine (the reference keeps one activation tensor per nn.Linear input, dreamer4.py:1983-2068,
+ * 2105-2116, 2143-2177; here a bf16 IMAGE of it is what the next Linear reads): C may be NULL when only the bf16 image Cb is wanted; `batch` > 1 runs
+ * `batch` independent products A + b * strideA, Wb + b * strideW -> C / Cb + b * strideC (the attention pool's per-head value projection).
+ * d4_cvt_rows_bf16: rows x cols of a strided fp32 matrix -> bf16 (round to nearest even), the pass behind producers that cannot write the image. */
+int d4_gemm_bf16a_batched(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
+                          int M, int N, int K, int flags, float rms_eps, int batch, int64_t strideA, int64_t strideW, int64_t strideC, int config, void* stream);
+int d4_cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, void* stream);
 /* fp32 GEMM on the bf16 matrix cores (csrc/gemm_x3.hip; the trunk's default `Linear` arithmetic): every fp32 operand is the exact sum of three
  * bf16 numbers and a product is accumulated from its six leading bf16 x bf16 terms in fp32 — fp32 accuracy (error against float64 no
  * larger than the f32-input MFMA kernels'), 6/16 of their matrix-pipe time.  d4_split_bf16x3 writes the three planes of W

@@ -87,38 +87,45 @@ def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
         _lib.check(lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, None, None, None, 0, M, N, 96, 0, eps, -1, stream()))
 
 
-@pytest.mark.parametrize('M,N,K,flags', [(3584, 512, 512, 0), (200, 300, 96, 1), (1920, 2752, 1024, 5), (1920, 1552, 1024, 1), (130, 64, 2752, 0)])
-def test_gemm_bf16_lds_dma_form_matches_the_register_staged_form(M, N, K, flags):
-    """The experimental LDS-DMA form (gemm_bf16_dma.hip, opt-in D4_BF16_DMA=1): every tile configuration walks k in the register-staged
-    form's order, so without the folded RMSNorm the two give the same bits; with it the 1/rms row sums are folded in a different
-    (fixed) order: 1e-6 relative."""
+@pytest.mark.parametrize('M,N,K,flags,batch', [(1792, 1024, 512, 0, 1), (1920, 2752, 1024, 5, 1), (1792, 64, 1024, 0, 4), (130, 256, 192, 1, 1)])
+def test_gemm_bf16a_bf16_only_output_and_batches(M, N, K, flags, batch):
+    """The bf16 engine's producer -> consumer hand-off: a GEMM whose fp32 output nobody reads writes only the bf16 image (C = null, Cb set),
+    bit-identical to the image written next to an fp32 output; the per-head batched form (the attention pool's value projection: A head slices
+    at stride K, outputs at stride N) gives each head's plain product.  d4_cvt_rows_bf16 (the conversion pass after non-GEMM producers) is
+    round-to-nearest-even of strided rows."""
     lib = _lib.load()
     g = torch.Generator(device='cuda').manual_seed(0)
-    A = torch.randn(M, K, device='cuda', generator=g); Wb = torch.randn(N, K, device='cuda', generator=g).to(torch.bfloat16).contiguous()
-    b = torch.randn(N, device='cuda', generator=g)
+    A = torch.randn(M, batch * K, device='cuda', generator=g)
+    Ab = A.to(torch.bfloat16).contiguous(); Wb = (torch.randn(batch * N, K, device='cuda', generator=g) / K ** 0.5).to(torch.bfloat16).contiguous()
     swiglu = bool(flags & _lib.GEMM_SWIGLU)
-    R = None if swiglu else torch.randn(M, N, device='cuda', generator=g)
-    Nout = N // 2 if swiglu else N
+    Nout = (N // 2 if swiglu else N) * batch
+    eps = 1.1920929e-07
 
-    def run(cfg):
-        out = torch.full((M, Nout), float('nan'), device='cuda')
-        lib.d4_gemm_force_config(cfg)
-        try:
-            _lib.check(lib.d4_gemm_bf16(_lib.ptr(A), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, 1.1920929e-07, stream()))
-            torch.cuda.synchronize()
-        finally:
-            lib.d4_gemm_force_config(-1)
-        return out
+    def run(with_c):
+        out = torch.full((M, Nout), float('nan'), device='cuda'); outb = torch.zeros(M, Nout, device='cuda', dtype=torch.bfloat16)
+        _lib.check(lib.d4_gemm_bf16a_batched(_lib.ptr(Ab), batch * K, _lib.ptr(Wb), K, _lib.ptr(out) if with_c else None, Nout, _lib.ptr(outb), None, None, 0,
+                                             M, N, K, flags, eps, batch, K, N * K, Nout // batch, -1, stream()))
+        torch.cuda.synchronize()
+        return out, outb
 
-    ref = run(200)
-    for c in range(5):
-        if swiglu and c == 2:
-            continue                                     # 64 x 128 with 32-column waves cannot pair values with gates
-        out = run(300 + c)
-        if flags & _lib.GEMM_RMS_ROWSCALE:
-            assert (out - ref).abs().max().item() <= 1e-6 * ref.abs().max().item(), c
-        else:
-            assert torch.equal(out, ref), c
+    out, outb = run(True)
+    _, only = run(False)
+    assert torch.equal(outb, out.to(torch.bfloat16)) and torch.equal(only, outb)
+    Ad, Wd = Ab.double().view(M, batch, K), Wb.double().view(batch, N, K)
+    X = Ad * torch.rsqrt(Ad.pow(2).mean(-1, keepdim=True) + eps) if flags & _lib.GEMM_RMS_ROWSCALE else Ad
+    ref = torch.einsum('mbk,bnk->mbn', X, Wd)
+    if swiglu:
+        r = ref.reshape(M, batch, N // 64, 2, 32)
+        ref = (r[:, :, :, 0] * torch.nn.functional.silu(r[:, :, :, 1])).reshape(M, batch, N // 2)
+    ref = ref.reshape(M, Nout)
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * max(1., ref.abs().max().item()) * (K / 64) ** 0.5
+    # the conversion pass: strided rows, a width that is not a multiple of 4 included
+    src = torch.randn(37, 100, device='cuda', generator=g)
+    for cols in (100, 98, 64):
+        dst = torch.zeros(37, 104, device='cuda', dtype=torch.bfloat16)
+        _lib.check(lib.d4_cvt_rows_bf16(_lib.ptr(src), 100, _lib.ptr(dst), 104, 37, cols, stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:, :cols], src[:, :cols].to(torch.bfloat16)) and not dst[:, cols:].any()
 
 
 def _pair(kw, seed=0, dtypes=('fp32', 'bf16')):

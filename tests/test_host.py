@@ -304,3 +304,22 @@ def test_loss_normalizer_state_and_beta_zero_property():
     assert torch.allclose(second, torch.ones(2))
     frozen = m._normalize_loss('flow_loss_normalizer', torch.tensor(2.), False)
     assert frozen.item() == 2. and m.flow_loss_normalizer.exp_avg_sq.item() == 1.
+
+
+def test_every_environment_switch_is_in_the_knob_table():
+    """dreamer4_amd/knobs.py is the one table of D4_* switches: every getenv / os.environ name in the sources is in it (with a default and a
+    kind), and nothing in the table is stale.  tests/conftest.py and bench.py refuse to run with an 'experiment' switch set, so the defaults
+    the GPU tests run under are the defaults the bench runs under."""
+    import glob, os, re
+    from dreamer4_amd.knobs import KNOBS, experiment_overrides
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for path in glob.glob(os.path.join(root, 'dreamer4_amd', 'csrc', '*')) + glob.glob(os.path.join(root, 'dreamer4_amd', '*.py')) + [
+            os.path.join(root, 'bench.py'), os.path.join(root, 'tests', 'dp_gpu_worker.py')]:
+        if os.path.isfile(path) and not path.endswith('knobs.py'):
+            src = open(path, errors='ignore').read()
+            found |= set(re.findall(r'getenv\("(D4_[A-Z0-9_]+)"\)', src)) | set(re.findall(r"environ(?:\.get|\.setdefault)?[\(\[]\s*'(D4_[A-Z0-9_]+)'", src))
+    assert found - set(KNOBS) == set(), f'switches missing from dreamer4_amd/knobs.py: {sorted(found - set(KNOBS))}'
+    assert set(KNOBS) - found == set(), f'stale entries in dreamer4_amd/knobs.py: {sorted(set(KNOBS) - found)}'
+    assert all(kind in ('experiment', 'mode', 'io') and doc for _, kind, doc in KNOBS.values())
+    assert experiment_overrides({'D4_GEMM_X3': '0', 'D4_FORCE_PG': '1'}) == {'D4_GEMM_X3': '0'}
