@@ -729,6 +729,31 @@ __global__ __launch_bounds__(256) void time_kv_append4_kernel(TimeAttnArgs p) {
     *reinterpret_cast<f32x4*>(p.cache + cols * p.H * p.Tcap * 64 + off) = v;
 }
 
+// The new K / V row of (token row, head h) at frame `pos`, features 4 fg .. 4 fg + 3, on a 16-lane group (fg = lane & 15): the arithmetic of
+// time_kv_append4_kernel — value-residual lerp, K l2-norm * (gamma + 1) * sqrt(64), rotary — shared with the cached-decode kernels that append
+// their own row before they attend (one frame per pass: a (column, head) needs no other row of this pass).
+__device__ __forceinline__ void time_new_kv(const TimeAttnArgs& p, const float* pr, int row, int h, int fg, int pos, f32x4& ko, f32x4& vo) {
+    const int hd = p.H * 64, hl = h * 64 + 4 * fg;
+    const f32x4 k = *reinterpret_cast<const f32x4*>(pr + hd + hl);
+    f32x4 v = *reinterpret_cast<const f32x4*>(pr + 2 * hd + hl);
+    const f32x4 vr = *reinterpret_cast<const f32x4*>(p.vres + (int64_t)row * p.ldv + hl);
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + hl);
+    const float w = sigmoidf(pr[3 * hd + p.H + h]);
+    const f32x4 fr = *reinterpret_cast<const f32x4*>(p.inv_freq + 4 * (fg & 7));
+    const float nrm = sqrtf(row_sum16(((k[0] * k[0] + k[1] * k[1]) + k[2] * k[2]) + k[3] * k[3]));
+    const float den = fmaxf(nrm, 1e-12f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vo[e] = lerp_torch(v[e], vr[e], w);
+        const float kn = k[e] / den * ((g4[e] + 1.f) * 8.f);
+        const float partner = __shfl_xor(kn, 8);                   // feature ^ 32: the other half of the head
+        const float half = fg < 8 ? -partner : partner;
+        float sn, cs;
+        sincosf((float)pos * fr[e], &sn, &cs);
+        ko[e] = kn * cs + half * sn;
+    }
+}
+
 template <int DH>
 __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -779,8 +804,9 @@ __global__ __launch_bounds__(256) void time_attn_kernel(TimeAttnArgs p) {
 //                 ONCE in LDS by the block's waves (coalesced float4), every wave (= query frame) then reads them from LDS;
 //   STAGE = false (cached decode, one query per (column, head)): each K / V float4 is read exactly once — straight to registers.
 constexpr int TA_CHUNK = 64;
-template <bool STAGE>
+template <bool STAGE, bool APPEND = false>
 __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
+    static_assert(!(STAGE && APPEND), "the appending form is the cached decode (one query per column and head)");
     extern __shared__ __attribute__((aligned(16))) float kv_s[];              // STAGE: [2][TA_CHUNK][64]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int unit = STAGE ? blockIdx.x : blockIdx.x * nw + w;                // (b, s, h)
@@ -817,8 +843,18 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
                 q4[e] = q4[e] * cs + (d < 32 ? -part[e] : part[e]) * sn;
             }
         }
+        // APPEND: this (column, head)'s new K / V row is computed here (every 16-lane key-residue group computes the same quarter-rows), written
+        // to the cache by the first group, and used from registers as key `pos`
+        f32x4 knew = {0.f, 0.f, 0.f, 0.f}, vnew = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (APPEND) {
+            time_new_kv(p, pr, row, h, fg, pos, knew, vnew);
+            if (kr == 0) {
+                *reinterpret_cast<f32x4*>(const_cast<float*>(ck) + (int64_t)pos * 64 + fg * 4) = knew;
+                *reinterpret_cast<f32x4*>(const_cast<float*>(cv) + (int64_t)pos * 64 + fg * 4) = vnew;
+            }
+        }
         // the belief projection's own value row and the head gate: requested here, consumed at the very end
-        const f32x4 vi = *reinterpret_cast<const f32x4*>(cv + (int64_t)pos * 64 + fg * 4);
+        const f32x4 vi = APPEND ? vnew : *reinterpret_cast<const f32x4*>(cv + (int64_t)pos * 64 + fg * 4);
         const float gate_logit = pr[3 * hd + h];
         float m = -FLT_MAX, l = 0.f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -860,7 +896,8 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
                 if (ps < passes) {
                     const int j = ps * 4 + kr;
                     const bool ok = j <= last;
-                    const f32x4 k4 = ps < TA_PRE ? kpre[ps < TA_PRE ? ps : 0] : (ok ? kt[j * 16 + fg] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 k4 = ps < TA_PRE ? kpre[ps < TA_PRE ? ps : 0] : (ok ? kt[j * 16 + fg] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    if (APPEND && c0 + j == pos) k4 = knew;
                     float d = row_sum16(q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3]) * qscale;
                     if (p.softclamp > 0.f) d = tanhf(d / p.softclamp) * p.softclamp;
                     sc[ps] = ok ? d : -FLT_MAX;
@@ -879,7 +916,8 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
                 const int j = ps * 4 + kr;
                 if (ps < passes && sc[ps] > -FLT_MAX) {
                     const float e_ = expf(sc[ps] - mn);
-                    const f32x4 v4 = ps < TA_PRE ? vpre[ps < TA_PRE ? ps : 0] : vt[j * 16 + fg];
+                    f32x4 v4 = ps < TA_PRE ? vpre[ps < TA_PRE ? ps : 0] : vt[j * 16 + fg];
+                    if (APPEND && c0 + j == pos) v4 = vnew;
                     l += e_;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] += e_ * v4[e];
@@ -913,7 +951,7 @@ __global__ __launch_bounds__(256) void time_attn64_kernel(TimeAttnArgs p) {
 // first frames — 4 / 8 / 16 keys for every frame: 39.0 / 36.8 / 39.7 us averaged over a 15-frame horizon), head dim 64: four heads per wave — lane = (head of the
 // group, feature quarter-row) — and the few keys walked in sequence, all K / V rows requested before anything depends on them.  The four-keys-per-
 // pass kernel above leaves three quarters of its lanes idle at t < 4 and runs one wave per head: 32 us per launch at t = 0 for 15 MB.
-template <int TA_FEW>
+template <int TA_FEW, bool APPEND = false>
 __global__ __launch_bounds__(256) void time_attn64_few_kernel(TimeAttnArgs p) {
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int HG = p.H >> 2;
@@ -934,9 +972,19 @@ __global__ __launch_bounds__(256) void time_attn64_few_kernel(TimeAttnArgs p) {
     f32x4 k4[TA_FEW], v4[TA_FEW];
 #pragma unroll
     for (int j = 0; j < TA_FEW; ++j) {
-        const bool ok = j <= pos;
+        const bool ok = APPEND ? j < pos : j <= pos;                           // (APPEND: row `pos` is this kernel's own, below)
         k4[j] = ok ? ck[j * 16] : f32x4{0.f, 0.f, 0.f, 0.f};
         v4[j] = ok ? cv[j * 16] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (APPEND) {
+        // this (column, head)'s new K / V row: computed here (the lane layout is time_kv_append4_kernel's), written to the cache, used from registers
+        f32x4 knew, vnew;
+        time_new_kv(p, pr, row, h, fg, pos, knew, vnew);
+        const int64_t off = (int64_t)pos * 64;
+        *reinterpret_cast<f32x4*>(const_cast<float*>(reinterpret_cast<const float*>(ck)) + off) = knew;
+        *reinterpret_cast<f32x4*>(const_cast<float*>(reinterpret_cast<const float*>(cv)) + off) = vnew;
+#pragma unroll
+        for (int j = 0; j < TA_FEW; ++j) if (j == pos) { k4[j] = knew; v4[j] = vnew; }
     }
     {
         const f32x4 fr = *reinterpret_cast<const f32x4*>(p.inv_freq + 4 * (fg & 7));
@@ -1000,6 +1048,36 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     else if (p.dh == 64) D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else if (p.dh == 32) hipLaunchKernelGGL(time_kv_append_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(time_kv_append_kernel<16>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// Cached decode of ONE frame (Tq == 1): append + attend in one launch — every (column, head) computes its own new K / V row, stores it and
+// attends over its history with the new row taken from registers.  Same arithmetic and kernel choice (history bucket) as the two launches;
+// anything the fused forms do not cover (several frames per pass, head dims 16 / 32, unaligned rows) runs as the two launches.
+int time_attn_append(const TimeAttnArgs& p, hipStream_t stream) {
+    const char* fa = getenv("D4_TIME_ATTN_FUSED_APPEND");          // (read per call: the A/B test flips it inside one process)
+    const bool fused_on = !(fa && atoi(fa) == 0);
+    static const bool legacy = getenv("D4_TIME_ATTN_LEGACY") != nullptr || getenv("D4_KV_APPEND_LEGACY") != nullptr;
+    auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    const bool al4 = (p.ldp % 4) == 0 && (p.ldv % 4) == 0 && (p.ldo % 4) == 0 && al(p.proj) && al(p.vres) && al(p.cache) && al(p.out) && al(p.k_gamma) && al(p.inv_freq) &&
+                     (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
+    if (!(fused_on && !legacy && p.Tq == 1 && p.dh == 64 && al4)) {
+        if (int rc = time_kv_append(p, stream)) return rc;
+        return time_attn(p, stream);
+    }
+    D4_REQUIRE(p.t0 + 1 <= p.Tcap, "time attention: cache capacity %d exceeded (t0=%d)", p.Tcap, p.t0);
+    const int units = p.B * p.S * p.H;
+    if (units == 0) return 0;
+    // algorithmic bytes: the append's (k, v, value residual read; K, V written) + the attention's (history K / V, q read, out written)
+    const double bytes = 4.0 * units * 64.0 * 5.0 + 4.0 * units * 64.0 * (2.0 * (p.t0 + 1) + 2.0);
+    static const bool no_few = getenv("D4_TIME_ATTN_FEW") && atoi(getenv("D4_TIME_ATTN_FEW")) == 0;
+    const int bucket = time_history_bucket(p.t0);
+    if (bucket == 0 && (p.H % 4) == 0 && !no_few)
+        D4_GLUE_LAUNCH(GL_TIME_ATTN, bytes, (time_attn64_few_kernel<8, true>), dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
+    else if (bucket == 1 && (p.H % 4) == 0 && !no_few)
+        D4_GLUE_LAUNCH(GL_TIME_ATTN, bytes, (time_attn64_few_kernel<16, true>), dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
+    else D4_GLUE_LAUNCH(GL_TIME_ATTN, bytes, (time_attn64_kernel<false, true>), dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;
 }

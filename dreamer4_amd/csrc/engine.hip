@@ -777,8 +777,7 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
             ta.cache_batch = e->maxB; ta.cache_S = e->S;
             ta.t0_dev = t0_dev;
             ta.out_b = t_bf16 ? t_bf16->shadow_of(e->att) : nullptr;
-            if ((rc = time_kv_append(ta, s))) return rc;
-            if ((rc = time_attn(ta, s))) return rc;
+            if ((rc = time_attn_append(ta, s))) return rc;
         } else {
             SmallAttnArgs sa{};
             sa.dh = c.attn_dim_head;
@@ -802,6 +801,10 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
             const bool tail_compact = denoise_only && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8;
             if (!tail_compact && !e->wo_t.empty() && (!t_bf16 || t_bf16->split) && frame_attn_out_applicable(sa, D)) {
                 if ((rc = frame_attn_out(sa, e->wo_t[l], D, x_in, D, slab(2 * l + 1), D, cslab(2 * l + 1), D, e->keep_lo, e->keep_hi, has_agent, s))) return rc;
+                fused_out = true;
+            } else if (!tail_compact && hd == 512 && (!t_bf16 || t_bf16->split) && attn_out_cols_applicable(sa, D)) {
+                // few frames (launch-bound decode): attention recomputed inside every column workgroup of the output projection, one launch for two
+                if ((rc = attn_out_cols(sa, a.to_out, hd, D, x_in, D, slab(2 * l + 1), D, cslab(2 * l + 1), D, e->keep_lo, e->keep_hi, has_agent, s))) return rc;
                 fused_out = true;
             } else
             if ((rc = small_attn(sa, s))) return rc;

@@ -237,6 +237,70 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Few frames (the launch-bound decode regime, BASELINE config 4: one trajectory = one frame of 11 token rows): within-frame attention ->
+// output projection + residual in ONE launch, column-split.  A workgroup owns 16 output columns of ONE frame and all of K = heads * 64:
+//   * its weight rows are requested first (8 waves x 4 k-steps x 16 columns: the launch's longest memory round trip);
+//   * every wave then runs one head's attention of the frame on the matrix pipe (attn_mfma_unit) into LDS — the attention is RECOMPUTED by
+//     each of the D / 16 column workgroups of a frame: a few thousand MFMA cycles that hide under the weight fetch, instead of a launch;
+//   * the product runs as gemm_skinny_kernel<false, 8, 4> does (the 8 waves split K, partial tiles folded through LDS in wave order, the
+//     same permuted-k MFMA feed), with its A operand read from LDS: BIT-IDENTICAL to attn_mfma_kernel followed by the few-row GEMM.
+constexpr int AOC_NW = 8, AOC_U = 4, AOC_RED = 17;
+template <int HD>
+__global__ __launch_bounds__(AOC_NW * 64) void attn_out_cols_kernel(SmallAttnArgs sa, const float* __restrict__ W, int ldw, int D, FrameOut fo) {
+    static_assert(HD == AOC_NW * AOC_U * 16, "8 waves x 4 k-steps of 16 cover the attention width");
+    constexpr int LDA = HD + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_aoc[];
+    float* As = smem_aoc;                                                              // [16][LDA]
+    float* Vs_all = As + 16 * LDA;                                                     // [waves][16][SM_LDV]
+    float* kinv_all = Vs_all + AOC_NW * 16 * SM_LDV;
+    float* vinv_all = kinv_all + AOC_NW * 16;
+    float* red = vinv_all + AOC_NW * 16;                                               // [waves][16][17]
+    const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bx = blockIdx.x, g = blockIdx.y;
+    const int nl = lane & 15, kk = lane >> 4;
+    const int n = bx * 16 + nl;
+    const bool valid = n < D;
+    const float* wrow = W + (int64_t)(valid ? n : 0) * ldw;
+    f32x4 w4[AOC_U];
+#pragma unroll
+    for (int u = 0; u < AOC_U; ++u) w4[u] = valid ? *reinterpret_cast<const f32x4*>(wrow + 16 * (q * AOC_U + u) + 4 * kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // the epilogue's residual: thread = (row, column), requested with the weights
+    const int c = tid & 15, ml = tid >> 4;
+    const int gn = bx * 16 + c;
+    const int64_t grow = (int64_t)g * fo.S + ml;
+    float e_res = 0.f;
+    if (tid < 256 && ml < fo.S && gn < D) e_res = fo.resid[grow * fo.ldr + gn];
+    // rows past the frame's tokens are never written by the attention: they must read as zeros
+    for (int i = tid; i < (16 - sa.nq) * LDA; i += AOC_NW * 64) As[sa.nq * LDA + i] = 0.f;
+
+    for (int h = q; h < sa.heads; h += AOC_NW)
+        attn_mfma_unit<1, 1>(sa, g, h, lane, Vs_all + q * 16 * SM_LDV, kinv_all + q * 16, vinv_all + q * 16,
+                             [&](int orank, int t, int tok, float v) { As[orank * LDA + h * 64 + 16 * t + tok] = v; });
+    __syncthreads();
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < AOC_U; ++u) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(As + nl * LDA + 16 * (q * AOC_U + u) + 4 * kk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w4[u][e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(q * 16 + 4 * kk + r) * AOC_RED + nl] = acc[r];
+    __syncthreads();
+    if (tid >= 256 || ml >= fo.S || gn >= D) return;
+    float v = red[ml * AOC_RED + c];
+#pragma unroll
+    for (int w = 1; w < AOC_NW; ++w) v += red[(w * 16 + ml) * AOC_RED + c];
+    v += e_res;
+    fo.out[grow * fo.ldo + gn] = v;
+    if (fo.c2) {
+        const int rank = compact_rank(ml, fo.S, fo.c2_lo, fo.c2_hi, fo.c2_last);
+        if (rank >= 0) fo.c2[((int64_t)g * (fo.c2_hi - fo.c2_lo + fo.c2_last) + rank) * fo.ldc2 + gn] = v;
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------------------------------------
 static int g_frame_fused = -1;         // -1: from the environment (D4_FRAME_FUSED, default 1); 0 off; 1 on; 2 tails only (the pool mix stays its own kernel)
 int frame_fused_mode() {
@@ -272,6 +336,34 @@ int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const floa
         attr_set.done();
     }
     D4_GLUE_LAUNCH_F(GL_FRAME_ATTN_OUT, bytes, flops, frame_attn_out_kernel<512>, dim3(sa.groups), dim3(FF_NW * 64), lds, s, sa, wo_t, D, fo);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// few frames: the column-split form above.  By shape only: 8 heads x 64, <= 16 tokens, at most 4 frames — measured on one box (tools/cfg4_ab.sh,
+// BASELINE config 4): B = 1 1.73 -> 1.69 ms per env step, but B = 16 2.79 -> 2.87 ms: 16 frames x 32 column workgroups each recomputing a frame's
+// attention cost more than the launch they save
+bool attn_out_cols_applicable(const SmallAttnArgs& sa, int D) {
+    const char* ev = getenv("D4_ATTN_OUT_COLS");                  // (read per call: the A/B test flips it inside one process)
+    const bool on = !(ev && atoi(ev) == 0);
+    auto al4 = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
+    return on && frame_fused_on() && sa.groups >= 1 && sa.groups <= 4 && sa.dh == 64 && sa.heads == 8 && sa.nq == sa.nk && sa.nk >= 1 && sa.nk <= 16 && sa.q_hi == 0 &&
+           D % 16 == 0 && !sa.out_b &&
+           al4(sa.q, sa.q_group_stride, sa.q_item_stride) && al4(sa.k, sa.k_group_stride, sa.k_item_stride) && al4(sa.v, sa.v_group_stride, sa.v_item_stride) &&
+           (!sa.vres || al4(sa.vres, sa.r_group_stride, sa.r_item_stride)) && ((uintptr_t)sa.k_gamma % 16) == 0;
+}
+
+int attn_out_cols(const SmallAttnArgs& sa, const float* W, int ldw, int D, const float* resid, int ldr, float* out, int ldo, float* c2, int ldc2, int c2_lo,
+                  int c2_hi, int c2_last, hipStream_t s) {
+    D4_REQUIRE(attn_out_cols_applicable(sa, D) && ldw % 4 == 0 && ((uintptr_t)W % 16) == 0, "attn_out_cols: call not supported");
+    FrameOut fo{resid, ldr, out, ldo, c2, ldc2, c2_lo, c2_hi, c2_last, sa.nk};
+    const size_t lds = (size_t)(16 * (512 + 4) + AOC_NW * 16 * SM_LDV + 2 * AOC_NW * 16 + AOC_NW * 16 * AOC_RED) * sizeof(float);
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_out_cols_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.done();
+    }
+    hipLaunchKernelGGL(attn_out_cols_kernel<512>, dim3(D / 16, sa.groups), dim3(AOC_NW * 64), lds, s, sa, W, ldw, D, fo);
     D4_LAUNCH_CHECK();
     return 0;
 }

@@ -147,6 +147,10 @@ int frame_fused_set(int mode);          // test hook; returns the previous mode
 bool frame_attn_out_applicable(const SmallAttnArgs& sa, int D);
 int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const float* resid, int ldr, float* out, int ldo, float* c2, int ldc2, int c2_lo,
                    int c2_hi, int c2_last, hipStream_t s);
+// few frames (launch-bound decode): the same pair as ONE column-split launch that recomputes the frame's attention per 16 output columns
+bool attn_out_cols_applicable(const SmallAttnArgs& sa, int D);
+int attn_out_cols(const SmallAttnArgs& sa, const float* W, int ldw, int D, const float* resid, int ldr, float* out, int ldo, float* c2, int ldc2, int c2_lo,
+                  int c2_hi, int c2_last, hipStream_t s);
 // AttentionPool tail: per-head value projection of the mixes -> output projection + residual (+ row-compacted copy)
 bool frame_pool_tail_applicable(int frames, int S, int D, int pool_heads);
 int frame_pool(const PoolMixArgs& pm, const float* wv_t, const float* wo_t, int frames, int S, const float* resid, int ldr, float* out, int ldo, float* c2,
@@ -178,6 +182,7 @@ struct TimeAttnArgs {
 inline int time_history_bucket(int t0) { return t0 < 8 ? 0 : (t0 < 16 ? 1 : 2); }
 int time_kv_append(const TimeAttnArgs& p, hipStream_t stream);   // normalise/rotate/mix new K,V -> cache[t0 .. t0+Tq)
 int time_attn(const TimeAttnArgs& p, hipStream_t stream);        // attend over cache[0 .. t0+i], belief + gates
+int time_attn_append(const TimeAttnArgs& p, hipStream_t stream); // both; ONE launch for the cached decode of one frame (head dim 64, aligned rows)
 
 // ------------------------------------------------------------------------------------ elementwise / glue
 int fold_rows(const float* W, const float* gamma, float* out, int rows, int K, int ld_out, hipStream_t s);

@@ -12,6 +12,7 @@ KNOBS = {
     # --- launch mechanism / engine
     'D4_GRAPH_MAX_ROWS': ('4096', 'experiment', 'decode frames of <= this many token rows are replayed from hipGraphs (0: always enqueue eagerly); same kernels either way'),
     'D4_FRAME_FUSED': ('1', 'experiment', 'per-frame fused block tails (frame_fused.hip): 0 off, 1 on where the rule applies, 2 tails only'),
+    'D4_ATTN_OUT_COLS': ('1', 'experiment', 'few frames (decode): within-frame attention recomputed inside the column-split output projection, one launch (0: two)'),
     'D4_BF16_ACT': ('1', 'experiment', 'bf16 engine: bf16 activation images between producer and consumer (0: fp32 activations into every bf16 GEMM, the round-2 form)'),
     'D4_BF16A_GROUPED': ('1', 'experiment', 'gemm_bf16a: grouped (L2-friendly) tile order (0: row-major)'),
     # --- fp32 GEMM dispatch
@@ -29,6 +30,7 @@ KNOBS = {
     # --- glue kernels
     'D4_SPACE_ATTN_MFMA': ('1', 'experiment', 'within-frame / small cross attention on the matrix pipe (attn_mfma_kernel)'),
     'D4_TIME_ATTN_FEW': ('1', 'experiment', 'four-heads-per-wave time attention for histories of <= 16 keys'),
+    'D4_TIME_ATTN_FUSED_APPEND': ('1', 'experiment', 'cached decode of one frame: KV append and time attention in one launch (0: two launches)'),
     'D4_TIME_ATTN_LEGACY': ('unset', 'experiment', 'one-key-per-reduction time attention'),
     'D4_KV_APPEND_LEGACY': ('unset', 'experiment', 'one-head-per-wave KV append'),
     'D4_POOL_MIX_ROWS': ('1', 'experiment', 'block-per-row pool mix for few rows'),

@@ -335,6 +335,44 @@ def test_eager_and_graph_replayed_frames_run_the_same_kernels_bitwise(monkeypatc
     assert torch.equal(a.actions.discrete, b.actions.discrete) and torch.equal(a.log_probs.discrete, b.log_probs.discrete)
 
 
+def test_fused_kv_append_and_time_attention_equal_the_two_launches_bitwise(monkeypatch):
+    """Cached decode of one frame: the KV append and the time attention as ONE launch (every (column, head) computes its own new K / V row,
+    stores it and attends with it from registers) is bit-identical to the two launches, in all three history buckets (18 frames), and leaves
+    the same cache behind (a chained call continues from it)."""
+    from dreamer4_amd import DynamicsWorldModel
+    outs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('D4_TIME_ATTN_FUSED_APPEND', fused)
+        monkeypatch.setenv('D4_GRAPH_MAX_ROWS', '0')             # (a captured graph would bake the first arm's kernels in)
+        torch.manual_seed(0)
+        m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+        nz = make_noise(oracle_config(m), 18, 4, 3)
+        e, tc = m.generate(18, batch_size=4, return_for_policy_optimization=True, noise=nz, return_time_cache=True)
+        outs.append((e, tc.kv().clone()))
+    (a, ka), (b, kb) = outs
+    assert torch.equal(a.latents, b.latents) and torch.equal(a.agent_embed, b.agent_embed) and torch.equal(a.values, b.values)
+    assert torch.equal(a.actions.discrete, b.actions.discrete) and torch.equal(ka, kb)
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_few_frame_fused_attention_out_projection_equals_the_two_launches_bitwise(B, monkeypatch):
+    """BASELINE config 4's decode regime (dim 512, 8 x 64 heads, 4 x 16 latents -> 11 token rows per frame; the form is taken for up to 4 frames): the within-frame attention
+    recomputed inside the column-split output projection (attn_out_cols_kernel, one launch) is bit-identical to attn_mfma_kernel followed by the
+    few-row GEMM — same MFMA feed, same k slices, same fold order."""
+    from dreamer4_amd import DynamicsWorldModel
+    outs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('D4_ATTN_OUT_COLS', fused)
+        monkeypatch.setenv('D4_GRAPH_MAX_ROWS', '0')             # (a captured graph would bake the first arm's kernels in)
+        torch.manual_seed(0)
+        m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+        nz = make_noise(oracle_config(m), 6, B, 3)
+        outs.append(m.generate(6, batch_size=B, return_for_policy_optimization=True, noise=nz))
+    a, b = outs
+    assert torch.equal(a.latents, b.latents) and torch.equal(a.agent_embed, b.agent_embed) and torch.equal(a.values, b.values)
+    assert torch.equal(a.actions.discrete, b.actions.discrete)
+
+
 def test_config5_shape_vs_oracle():
     """BASELINE config 5 architecture in fp32: dim 1024, depth 12 -> time layers 4, 8, 12, attention inner width 8 x 64 = 512 < dim,
     64 x 32 latents, 6 continuous (Beta) actions.  (The engine is not specialised to dim 512; the bf16 form of this config is
