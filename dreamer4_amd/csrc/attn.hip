@@ -10,6 +10,7 @@
 // products are DPP row reductions + readlane; scores therefore live in SGPRs.  These kernels are
 // HBM/latency bound (S = 15 tokens per frame): each q/k/v element is read exactly once per wave.
 #include "common.h"
+#include <type_traits>
 #include "kernels.h"
 #include "prof.h"
 #include "attn_mfma.h"
@@ -634,9 +635,10 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     const double pm_bytes = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
     if (p.D <= 256) hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p);
     else if (p.D <= 512) D4_GLUE_LAUNCH(GL_POOL_MIX, pm_bytes, pool_mix_kernel<2>, grid, block, 0, stream, p);
-    // D > 512 (BASELINE config 5: dim 1024): few rows leave a SIMD with under two waves, and a row is then 2 L dependent memory round trips —
-    // the deep form requests the key rows in batches of 8 and the hidden rows 3 ahead
-    else if (p.M < 8192) hipLaunchKernelGGL((pool_mix_kernel<4, true>), grid, block, 0, stream, p);
+    // D > 512 (BASELINE config 5: dim 1024, 1792 rows x up to 25 hiddens: 32 us per launch = ~3.6 TB/s of hiddens + keys).  Measured in round 4 and NOT
+    // adopted, all level with this form: the deep-prefetch variant, reading the bf16 hidden images (kept: half the bytes), and a block-per-row kernel
+    // whose four waves split the features with every load issued up front — the launch is bound by what the memory side delivers for rows that
+    // were written many kernels ago, not by the wave structure
     else hipLaunchKernelGGL(pool_mix_kernel<4>, grid, block, 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     constexpr int STAGE_B = STAGE_ROWS * BKB;       // bytes per ring stage
     constexpr int NSLOT = STAGE_ROWS / RPP;
     constexpr int LPW = (NSLOT + NW - 1) / NW;
-    static_assert(NS >= 3 && NS <= 8 && (NS - 2) * LPW <= 63, "ring depth / vmcnt range");
+    static_assert(NS >= 2 && NS <= 8 && (NS - 2) * LPW <= 63, "ring depth / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];   // [NS][STAGE_ROWS][128 B] | rowscale[BM] floats
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -146,6 +146,35 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
+    if constexpr (NS == 2) {
+        // Two slots (the 256 x 256 tile: a stage is 64 KB): stage kt + 1 is in flight while stage kt is multiplied; one barrier per k-tile — it says
+        // "stage kt has landed in every wave's pieces AND everyone is done reading the other slot".  No fragment pre-read across the barrier.
+        D4_ISSUE_STAGE_B(0, 0)
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt_b<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) { D4_ISSUE_STAGE_B(kt + 1, (kt + 1) & 1) }
+            const char* st = smem_b + (kt & 1) * STAGE_B;
+            if constexpr (RMS) {
+#pragma unroll
+                for (int i = 0; i < SQI; ++i) {
+                    const int idx = tid + i * NT;
+                    if (BM * CH % NT == 0 || idx < BM * CH) {
+                        const bf16x8_b v = *reinterpret_cast<const bf16x8_b*>(st + idx * 16);
+                        float s = ssq[i];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s = __builtin_fmaf(f, f, s); }
+                        ssq[i] = s;
+                    }
+                }
+            }
+            read_frags(st, S0{}, 0);
+            mfma_set(S0{});
+            read_frags(st, S0{}, 1);
+            mfma_set(S0{});
+        }
+        __builtin_amdgcn_s_barrier();                        // (the row scales below reuse nothing of the ring, but keep the waves together for the epilogue)
+    } else {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) { D4_ISSUE_STAGE_B(s, s) }
@@ -180,6 +209,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
         if (LATE && kt + 1 < nk && kt + NS - 1 < nk) { D4_ISSUE_STAGE_B(kt + NS - 1, (kt + NS - 1) % NS) }
         if (kt + 1 < nk) read_frags(nxt, S0{}, 0);
         mfma_set(S1{});
+    }
     }
 #undef D4_ISSUE_STAGE_B
 
@@ -310,11 +340,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
 // 64x64/s     4 x 1    16 x 64     64 x 64     4 x 16 KB       2          SiLU-GLU capable
 // 32x64       2 x 2    16 x 32     32 x 64     4 x 12 KB       3
 // 256x128     4 x 2    64 x 64    256 x 128    3 x 48 KB       1          SiLU-GLU capable (large problems)
+// 256x256     4 x 4    64 x 64    256 x 256    2 x 64 KB       1          SiLU-GLU capable; 16 waves; half the operand bytes per flop of 128 x 128 (these
+//                                                                        kernels are bound by what the L2s deliver: ~14 TB/s measured on the cfg-5 shapes)
 // Measured and retired (round 4, tools/bf16a_probe.py): rings of 4 - 8 stages at one workgroup per CU (the whole LDS in flight) are level or slower
 // than these — two co-resident workgroups hide more than a deeper ring; the k-loop step (~0.6 - 0.7 us for 128 x 128 x 64 even on a quarter of
 // the CUs) is bound inside the workgroup (barrier / DMA issue / fragment reads per k-tile), not by bytes in flight.
-enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_N };
-static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128};
+enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_256x256, VA_N };
+static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256, 256}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128, 256};
 
 int gemm_bf16a_configs() { return VA_N; }
 
@@ -325,7 +357,7 @@ bool gemm_bf16a_applicable(const GemmArgs& p) {
 
 bool gemm_bf16a_config_valid(int c, const GemmArgs& p) {
     if (c < 0 || c >= VA_N || !gemm_bf16a_applicable(p)) return false;
-    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128;
+    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128 || c == VA_256x256;
     return true;
 }
 
@@ -369,6 +401,7 @@ int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t e
         case VA_64x64_s: return launch_va<4, 1, 1, 4, 4>(p, stream, ea, eb);
         case VA_32x64: return launch_va<2, 2, 1, 2, 4>(p, stream, ea, eb);
         case VA_256x128: return launch_va<4, 2, 4, 4, 3>(p, stream, ea, eb);
+        case VA_256x256: return launch_va<4, 4, 4, 4, 2>(p, stream, ea, eb);
     }
     return 2;
 }
@@ -380,6 +413,11 @@ int gemm_bf16a_rule(const GemmArgs& p) {
     const int64_t t128 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 128) * nb;
     const int64_t t128x64 = (int64_t)cdiv(p.M, 128) * cdiv(p.N, 64) * nb;
     const int64_t t64 = (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * nb;
+    // 256 x 256 (half the operand bytes per flop) once its tiles cover more than half the CUs — measured (tools/bf16a_probe.py, round 4): the SiLU-GLU
+    // input projection at 1792 rows (154 tiles) 46.6 -> 36.8 us, at 14336 rows 290 -> 202 us; the SiLU-GLU output projection at 14336 rows 131 -> 80 us;
+    // the pool key projection at 114688 rows 143 -> 91 us.  Below that it leaves CUs idle and loses (28 tiles: 65 vs 25 us).
+    const int64_t t256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) * nb;
+    if (t256 >= 140 && p.N >= 256) return VA_256x256;
     if (swiglu) return t128 >= 200 ? VA_128x128 : VA_64x64_s;
     if (t128 >= 400 && p.N >= 128) return VA_128x128;
     if (t128x64 >= 300) return VA_128x64;

@@ -6,7 +6,7 @@ from dreamer4_amd import _lib
 lib = _lib.load()
 s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 RMS, SWIGLU = 1, 4
-shapes = [(1792, 5504, 1024, 'ff1'), (1792, 1024, 2752, 'ff2'), (1792, 1024, 512, 'out'), (1792, 1552, 1024, 'proj'), (1792, 256, 1024, 'poolq'), (1792, 1024, 256, 'poolout'), (23296, 256, 1024, 'poolk13')]
+shapes = [(14336, 5504, 1024, 'ff1L'), (14336, 1024, 2752, 'ff2L'), (14336, 1552, 1024, 'projL'), (114688, 256, 1024, 'poolkL'), (1792, 5504, 1024, 'ff1'), (1792, 1024, 2752, 'ff2'), (1792, 1024, 512, 'out'), (1792, 1552, 1024, 'proj'), (1792, 256, 1024, 'poolq'), (1792, 1024, 256, 'poolout'), (23296, 256, 1024, 'poolk13')]
 reps = 30
 def timeit(run):
     for _ in range(3): run()
@@ -26,7 +26,7 @@ for M, N, K, name in shapes:
         Nout = N // 2 if flags & SWIGLU else N
         for cb in (True,):
             ts = []
-            for c in list(range(6)) + [100 + i for i in range(6)]:
+            for c in range(7):
                 call = lambda: lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(outb) if cb else None, None, None, 0, M, N, K, flags, 1e-6, c, s)
                 ts.append(timeit(call) if call() == 0 else float('nan'))
             print(f'{name:8s} M{M:6d} N{N:5d} K{K:5d} flags {flags} Cb {int(cb)}: ' + ' '.join(f'{t:7.1f}' for t in ts) + f' | best {2.0 * M * N * K / min(t for t in ts if t == t) / 1e6:6.0f} TF/s')
