@@ -183,9 +183,8 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
     const int NU2 = DD / 32;
     auto unit1 = [&](int v) { return fg_make_unit(wv_t, DD, 2 * v, 2 * v + 1, lane); };
     auto unit2 = [&](int v) { return fg_make_unit(wo_t, HP, 2 * v, 2 * v + 1, lane); };
-    FgRing ring;
-    fg_prefetch(ring, unit1(wave));               // NU1 == waves
-
+    FgRing ring;                                  // (filled AFTER the mix phase: its 64 registers held across the mix cost more — 187 vs 125 VGPRs —
+                                                  //  than the head start of the weight stream gives; 180.5 vs 181.3 ms per rollout, round 4)
     constexpr int nf4 = DD / 4;
     for (int i = tid; i < PH * ITER * 64; i += FF_NW * 64) {
         const int h = i / (ITER * 64), c4 = i % (ITER * 64);
@@ -199,6 +198,7 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
     for (int ml = wave; ml < fo.S; ml += FF_NW)
         pool_mix_row<ITER, true>(pm, g * fo.S + ml, lane, psh + wave * LMAX * PH, gws,
                            [&](int h, int c4, const f32x4& v) { *reinterpret_cast<f32x4*>(Us + (h * 16 + ml) * LDU + c4 * 4) = v; });
+    fg_prefetch(ring, unit1(wave));               // NU1 == waves
     __syncthreads();
 
     f32x4 acc0, acc1;

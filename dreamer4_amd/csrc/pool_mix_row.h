@@ -55,13 +55,24 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
     for (int h = 0; h < PH; ++h) mx[h] = readlane_f(mxl, h * 16);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // Softmax weights once per (hidden, head), spread over the lanes — the L x 4 exponentials and divisions are the same for every lane of the
+    // wave (they were the bulk of this function's instruction stream: 2 L x 4 exponentials + L x 4 divisions per LANE; the per-frame fused
+    // kernel's mix phase, 60 % of its time, is bound by VALU issue — removing every key load or deepening the prefetch changed nothing).
+    // Same values in the same order as before: e = exp(s - max), den = sum over l in order, w = e / den.
+    for (int idx = lane; idx < L * PH; idx += 64) ps[idx] = expf(ps[idx] - mx[idx & (PH - 1)]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     float den[PH];
 #pragma unroll
     for (int h = 0; h < PH; ++h) {
         float d = 0.f;
-        for (int l = 0; l < L; ++l) d += expf(ps[l * PH + h] - mx[h]);
+        for (int l = 0; l < L; ++l) d += ps[l * PH + h];
         den[h] = d;
     }
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < L * PH; idx += 64) ps[idx] = ps[idx] / den[idx & (PH - 1)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     f32x4 acc[PH][ITER];
 #pragma unroll
     for (int h = 0; h < PH; ++h)
@@ -108,7 +119,7 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
             const float rstd = rsqrtf(wave_sum(ss) / (float)D + p.eps);
 #pragma unroll
             for (int h = 0; h < PH; ++h) {
-                const float w = expf(ps[l * PH + h] - mx[h]) / den[h] * rstd;
+                const float w = ps[l * PH + h] * rstd;
 #pragma unroll
                 for (int i = 0; i < ITER; ++i) acc[h][i] += v[i] * w;
             }
