@@ -242,13 +242,13 @@ __global__ __launch_bounds__(256) void space_attn_kernel(SmallAttnArgs p) {
 // The kernel is a template over the number of 16-row query tiles QT and key tiles KT: <1, 1> is the within-frame self attention (value residual,
 // special-token mask, belief projection, restricted query set), <1, 2> / <2, 1> / <1, 1> the small cross forms (learned-query pools in / out with up
 // to 32 latents or queries, the agent token's cross attention).
-template <int QT, int KT>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(SmallAttnArgs p) {
-    __shared__ __attribute__((aligned(16))) float Vs_all[4][KT * 16 * SM_LDV];
-    __shared__ __attribute__((aligned(16))) float kinv_all[4][KT * 16];
-    __shared__ __attribute__((aligned(16))) float vinv_all[4][KT * 16];
+template <int QT, int KT, int NWB = 4>            // NWB waves (= (group, head) units) per block: 2 for the 64-key form, whose V' tiles are 17 KB per wave
+__global__ __launch_bounds__(NWB * 64) void attn_mfma_kernel(SmallAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) float Vs_all[NWB][KT * 16 * SM_LDV];
+    __shared__ __attribute__((aligned(16))) float kinv_all[NWB][KT * 16];
+    __shared__ __attribute__((aligned(16))) float vinv_all[NWB][KT * 16];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + w;
+    const int unit = blockIdx.x * NWB + w;
     if (unit >= p.groups * p.heads) return;
     const int g = unit / p.heads, h = unit % p.heads;
     float* op = p.out ? p.out + g * p.o_group_stride + h * 64 : nullptr;
@@ -402,7 +402,7 @@ static int small_attn_impl(const SmallAttnArgs& p, hipStream_t stream, bool* wro
     // algorithmic bytes: a batch-independent operand (group stride 0) is counted once
     static const bool mfma_small_on = !(getenv("D4_SPACE_ATTN_MFMA") && atoi(getenv("D4_SPACE_ATTN_MFMA")) == 0);
     auto al4s = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
-    const bool mfma_small = mfma_small_on && p.dh == 64 && p.nq <= 32 && p.nk <= 32 && (p.nq <= 16 || p.nk <= 16) && p.q_hi == 0 &&
+    const bool mfma_small = mfma_small_on && p.dh == 64 && p.nq <= 64 && p.nk <= 64 && (p.nq <= 16 || p.nk <= 16) && p.q_hi == 0 &&
                             al4s(p.q, p.q_group_stride, p.q_item_stride) && al4s(p.k, p.k_group_stride, p.k_item_stride) &&
                             al4s(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4s(p.vres, p.r_group_stride, p.r_item_stride)) &&
                             ((uintptr_t)p.k_gamma % 16) == 0;
@@ -416,8 +416,10 @@ static int small_attn_impl(const SmallAttnArgs& p, hipStream_t stream, bool* wro
     *wrote_b = mfma_small;
     if (mfma_small) {         // one wave per (group, head) on the matrix pipe (attn_mfma_kernel): up to 32 x 16 or 16 x 32 (queries x keys)
         if (p.nq <= 16 && p.nk <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
-        else if (p.nq <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 2>), dim3(cdiv(waves, 4)), block, 0, stream, p);
-        else D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<2, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
+        else if (p.nq <= 16 && p.nk <= 32) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 2>), dim3(cdiv(waves, 4)), block, 0, stream, p);
+        else if (p.nq <= 16) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<1, 4, 2>), dim3(cdiv(waves, 2)), dim3(128), 0, stream, p);    // <= 64 latents -> spatial tokens (cfg 5)
+        else if (p.nq <= 32) D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<2, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);
+        else D4_GLUE_LAUNCH(GL_SMALL_ATTN, sm_bytes, (attn_mfma_kernel<4, 1>), dim3(cdiv(waves, 4)), block, 0, stream, p);                           // spatial tokens -> <= 64 latents
     }
     else if (p.nk <= 16) D4_SMALL_ATTN(16);
     else if (p.nk <= 32) D4_SMALL_ATTN(32);

@@ -14,7 +14,7 @@ int g_tick[GL_N] = {0};
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 const char* const kNames[GL_N] = {"space_attn_kernel", "time_attn64_kernel", "time_kv_append_kernel", "pool_mix_kernel", "small_attn_kernel",
-                                  "assemble_kernel", "splitk_reduce_kernel", "attn_wide_kernel", "frame_attn_out_kernel", "frame_pool_tail_kernel"};
+                                  "assemble_kernel", "splitk_reduce_kernel", "attn_wide_kernel", "frame_attn_out_kernel", "frame_pool_kernel"};
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
