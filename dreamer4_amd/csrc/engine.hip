@@ -449,6 +449,23 @@ static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
         }
         return gemm_pair(a, b, s);
     }
+    // bf16 engine: both activations have bf16 images and neither output has one -> one grid on the bf16-activation kernel (the pool's query
+    // projection rides in the key projection's launch)
+    if (d4_engine* e = t_bf16) {
+        if (!e->split && !e->shadows.empty() && !e->shadow_of(a.C) && !e->shadow_of(b.C)) {
+            GemmArgs pa = a, pb = b;
+            bool ok = true;
+            for (GemmArgs* g : {&pa, &pb}) {
+                g->Wb = nullptr;
+                for (const auto& m : e->mirrors)
+                    if (g->W >= m.src && g->W < m.src + m.n) { g->Wb = m.dst + (g->W - m.src); break; }
+                g->Ab = e->shadow_of(g->A);
+                ok = ok && g->Wb && g->Ab;
+            }
+            static const bool pair_on = !(getenv("D4_BF16A_PAIR") && atoi(getenv("D4_BF16A_PAIR")) == 0);
+            if (ok && pair_on && gemm_bf16a_pair_applicable(pa, pb)) return gemm_bf16a_pair(pa, pb, s);
+        }
+    }
     int rc;
     if ((rc = engine_gemm(a, s))) return rc;
     return engine_gemm(b, s);

@@ -316,6 +316,19 @@ int gemm_bf16a(const GemmArgs& p, hipStream_t stream) {
     return gemm_bf16a_launch(c, p, stream, nullptr, nullptr);
 }
 
+int gemm_bf16a_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream) {
+    if (g_bprof_stride > 0 && (g_bprof_tick++ % g_bprof_stride) == 0) {
+        Bf16Prof r{};
+        D4_HIP(hipEventCreate(&r.a)); D4_HIP(hipEventCreate(&r.b));
+        r.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
+        r.M = a.M + b.M; r.N = a.N; r.K = a.K; r.flags = a.flags | 1024 | 2048; r.batch = 2;       // (2048 marks the pair form in the shape log)
+        const int rc = gemm_bf16a_pair_launch(a, b, stream, r.a, r.b);
+        g_bprof.push_back(r);
+        return rc;
+    }
+    return gemm_bf16a_pair_launch(a, b, stream, nullptr, nullptr);
+}
+
 bool gemm_bf16_applicable(const GemmArgs& p) {
     return p.Wb != nullptr && !(p.flags & (GEMM_TRANS_A | GEMM_TRANS_B)) && (p.K % 32) == 0 && (p.lda % 4) == 0 && (p.ldw % 8) == 0 &&
            ((uintptr_t)p.Wb % 16) == 0 && (p.strideW % 8) == 0;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void wait_vmcnt_b() {
 }
 
 template <int WGM, int WGN, int TM, int TN, int NS, bool RMS>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_bf16a_body(GemmArgs p, const int block_x, const int block_y) {
     constexpr int BKB = 128;                        // bytes per tile row = 64 bf16
     constexpr int CH = 8, RPP = 8;                  // 16-byte chunks per row; rows per 1 KB DMA piece
     constexpr int NW = WGM * WGN, NT = NW * 64;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     const int wm = wave / WGN, wn = wave % WGN;
     constexpr bool LATE = false;             // (measured: issuing the ring refill behind the first half's MFMAs changes nothing)
 
-    int bid = blockIdx.x;
+    int bid = block_x;
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     {
         const int nblk = nbm * nbn, nx = 8;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
         tr = g * p.group_m + r % gm_eff; tc = r / gm_eff;
     }
     const int bm0 = tr * BM, bn0 = tc * BN;
-    const int bz = blockIdx.y;
+    const int bz = block_y;
     const uint16_t* Ab = p.Ab + bz * p.strideA;
     const uint16_t* Wb = p.Wb + bz * p.strideW;
     if (p.C) p.C += bz * p.strideC;                  // (C may be null: only the bf16 copy Cb is wanted)
@@ -332,6 +332,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
     }
 }
 
+template <int WGM, int WGN, int TM, int TN, int NS, bool RMS>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_kernel(GemmArgs p) {
+    gemm_bf16a_body<WGM, WGN, TM, TN, NS, RMS>(p, blockIdx.x, blockIdx.y);
+}
+
+// Two independent products of equal K in ONE grid (blocks [0, nblk_a) work on `a`, the rest on `b`; each keeps its own tile order and the bits of
+// the separate launches): the attention pool's query projection (a few dozen tiles) rides in the key projection's launch.
+template <int WGM, int WGN, int TM, int TN, int NS, bool RMS>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_pair_kernel(GemmArgs a, GemmArgs b, int nblk_a) {
+    const int bid = blockIdx.x;
+    if (bid < nblk_a) gemm_bf16a_body<WGM, WGN, TM, TN, NS, RMS>(a, bid, 0);
+    else gemm_bf16a_body<WGM, WGN, TM, TN, NS, RMS>(b, bid - nblk_a, 0);
+}
+
 // ---- configurations --------------------------------------------------------------------------------------------
 // name        waves   wave tile   block tile   ring            blocks / CU
 // 128x128     4 x 2    32 x 64    128 x 128    3 x 32 KB       1          SiLU-GLU capable
@@ -404,6 +418,54 @@ int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t e
         case VA_256x256: return launch_va<4, 4, 4, 4, 2>(p, stream, ea, eb);
     }
     return 2;
+}
+
+int gemm_bf16a_rule(const GemmArgs& p);
+static void bf16a_group(GemmArgs& q, int BM, int BN) {
+    const int nbm = cdiv(q.M, BM), nbn = cdiv(q.N, BN);
+    int best = 1; long best_cost = -1;
+    for (int gm = 1; gm <= 16 && gm <= nbm; ++gm) {
+        const int cols = (32 + gm - 1) / gm;
+        const long cost = (long)gm * BM + (long)(cols < nbn ? cols : nbn) * BN;
+        if (best_cost < 0 || cost < best_cost) { best = gm; best_cost = cost; }
+    }
+    q.group_m = best;
+}
+
+template <int WGM, int WGN, int TM, int TN, int NS>
+static int launch_va_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int BM = WGM * TM * 16, BN = WGN * TN * 16;
+    const size_t lds = (size_t)NS * (BM + BN) * 128 + BM * sizeof(float);
+    auto k = gemm_bf16a_pair_kernel<WGM, WGN, TM, TN, NS, true>;
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.done();
+    }
+    GemmArgs qa = a, qb = b;
+    bf16a_group(qa, BM, BN); bf16a_group(qb, BM, BN);
+    const int na = cdiv(a.M, BM) * cdiv(a.N, BN), nb = cdiv(b.M, BM) * cdiv(b.N, BN);
+    const dim3 grid(na + nb), block(WGM * WGN * 64);
+    if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, qa, qb, na);
+    else hipLaunchKernelGGL(k, grid, block, lds, stream, qa, qb, na);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
+// both: bf16 activations + weights, the folded RMSNorm, no batch, equal K; the tile is the LARGER problem's (by the shape rule), restricted to the
+// two 8-wave forms that carry the pool projections
+bool gemm_bf16a_pair_applicable(const GemmArgs& a, const GemmArgs& b) {
+    auto ok = [](const GemmArgs& p) { return gemm_bf16a_applicable(p) && (p.flags == GEMM_RMS_ROWSCALE) && p.batch <= 1 && !p.C2 && !p.R && !p.bias && p.M > 0; };
+    if (!ok(a) || !ok(b) || a.K != b.K) return false;
+    const GemmArgs& big = (double)a.M * a.N >= (double)b.M * b.N ? a : b;
+    const int c = gemm_bf16a_rule(big);
+    return c == VA_128x64 || c == VA_64x64;
+}
+int gemm_bf16a_pair_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    D4_REQUIRE(gemm_bf16a_pair_applicable(a, b), "gemm_bf16a_pair: call not supported");
+    const GemmArgs& big = (double)a.M * a.N >= (double)b.M * b.N ? a : b;
+    if (gemm_bf16a_rule(big) == VA_128x64) return launch_va_pair<4, 2, 2, 2, 3>(a, b, stream, ea, eb);
+    return launch_va_pair<2, 2, 2, 2, 4>(a, b, stream, ea, eb);
 }
 
 // tile by shape (a rule, never a timing)

@@ -55,6 +55,9 @@ bool gemm_bf16a_config_valid(int c, const GemmArgs& p);
 int gemm_bf16a_configs();
 int gemm_bf16a_rule(const GemmArgs& p);
 int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+bool gemm_bf16a_pair_applicable(const GemmArgs& a, const GemmArgs& b);      // two RMS-folded products of equal K in one grid
+int gemm_bf16a_pair_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+int gemm_bf16a_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream);      // ... with gemm_bf16.hip's optional event pair
 void gemm_bf16_profile_enable(int stride);
 int gemm_bf16_profile_read(double* ms, double* flops, int64_t* count);
 // third fp32 family (gemm_x3.hip): fp32 operands split into three bf16 numbers, six bf16 MFMA products, fp32 accumulate (fp32 accuracy)

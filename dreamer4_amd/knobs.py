@@ -14,6 +14,7 @@ KNOBS = {
     'D4_FRAME_FUSED': ('1', 'experiment', 'per-frame fused block tails (frame_fused.hip): 0 off, 1 on where the rule applies, 2 tails only'),
     'D4_ATTN_OUT_COLS': ('1', 'experiment', 'few frames (decode): within-frame attention recomputed inside the column-split output projection, one launch (0: two)'),
     'D4_BF16_ACT': ('1', 'experiment', 'bf16 engine: bf16 activation images between producer and consumer (0: fp32 activations into every bf16 GEMM, the round-2 form)'),
+    'D4_BF16A_PAIR': ('1', 'experiment', 'bf16 engine: the attention pool query and key projections in one grid (gemm_bf16a_pair_kernel)'),
     'D4_BF16A_GROUPED': ('1', 'experiment', 'gemm_bf16a: grouped (L2-friendly) tile order (0: row-major)'),
     # --- fp32 GEMM dispatch
     'D4_GEMM_V2': ('1', 'experiment', 'LDS-DMA fp32 family gemm2.hip for K % 32 == 0 (0: register-staged family only)'),
