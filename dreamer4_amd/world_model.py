@@ -719,7 +719,11 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
     def _shortcut_coin(self, generator, prob):
         """The shortcut / plain-flow coin of a training step (dreamer4.py:345-346, 6965: `rand(1).item() < prob`, a HOST draw in the reference).
         Drawn on the host here too — a device draw would make every training step wait for the device — from the global CPU generator, or,
-        when the caller passes a (device) generator, from a CPU companion seeded with its initial seed (deterministic per seed)."""
+        when the caller passes a (device) generator, from a CPU companion seeded with its initial seed (deterministic per seed).
+        Consequences worth knowing: the coin does NOT advance the passed generator (the randint / randn draws that follow are not shifted by
+        it), and the companion is re-created only when the generator object or its initial seed changes — to replay a run from the start,
+        re-seed with a different-then-same seed or pass a fresh generator object (re-seeding the same object with the same seed continues
+        the companion's sequence); `draws=dict(shortcut_train=...)` injects the coin outright."""
         if generator is None:
             return bool(torch.rand(1).item() < prob)
         pair = getattr(self, '_coin_generator', None)
