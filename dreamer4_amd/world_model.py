@@ -721,14 +721,17 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         Drawn on the host here too — a device draw would make every training step wait for the device — from the global CPU generator, or,
         when the caller passes a (device) generator, from a CPU companion seeded with its initial seed (deterministic per seed).
         Consequences worth knowing: the coin does NOT advance the passed generator (the randint / randn draws that follow are not shifted by
-        it), and the companion is re-created only when the generator object or its initial seed changes — to replay a run from the start,
-        re-seed with a different-then-same seed or pass a fresh generator object (re-seeding the same object with the same seed continues
-        the companion's sequence); `draws=dict(shortcut_train=...)` injects the coin outright."""
+        it); the companion restarts whenever the generator object or its seed changes, or the generator is found freshly (re-)seeded — so
+        re-seeding the same object with the same seed replays the same coin sequence; `draws=dict(shortcut_train=...)` injects the coin outright."""
         if generator is None:
             return bool(torch.rand(1).item() < prob)
         pair = getattr(self, '_coin_generator', None)
-        if pair is None or pair[0] is not generator or pair[2] != generator.initial_seed():
-            pair = (generator, torch.Generator().manual_seed(generator.initial_seed()), generator.initial_seed())
+        seed = generator.initial_seed()
+        fresh = pair is not None and pair[0] is generator and pair[2] == seed and torch.equal(generator.get_state(), pair[3])
+        if pair is None or pair[0] is not generator or pair[2] != seed or fresh:
+            # (a generator whose state equals the state right after manual_seed(seed) was just (re-)seeded: the replay starts the coin sequence over)
+            ref_state = torch.Generator(device=generator.device).manual_seed(seed).get_state()
+            pair = (generator, torch.Generator().manual_seed(seed), seed, ref_state)
             object.__setattr__(self, '_coin_generator', pair)
         return bool(torch.rand(1, generator=pair[1]).item() < prob)
 

@@ -323,3 +323,22 @@ def test_every_environment_switch_is_in_the_knob_table():
     assert set(KNOBS) - found == set(), f'stale entries in dreamer4_amd/knobs.py: {sorted(set(KNOBS) - found)}'
     assert all(kind in ('experiment', 'mode', 'io') and doc for _, kind, doc in KNOBS.values())
     assert experiment_overrides({'D4_GEMM_X3': '0', 'D4_FORCE_PG': '1'}) == {'D4_GEMM_X3': '0'}
+
+
+def test_shortcut_coin_replays_when_the_generator_is_reseeded():
+    """The training step's shortcut coin is a host draw from a CPU companion of the caller's generator (dreamer4.py:6965 draws it on the host):
+    re-seeding the same generator object with the same seed replays the same coin sequence, another seed gives another one."""
+    m = small_model()
+    g = torch.Generator().manual_seed(5)
+
+    def run(n=8):
+        out = []
+        for _ in range(n):
+            out.append(m._shortcut_coin(g, 0.5))
+            torch.rand(3, generator=g)                       # a step's other draws advance the caller's generator
+        return out
+    a = run()
+    g.manual_seed(5)
+    assert run() == a
+    g.manual_seed(6)
+    assert run(32) != (a * 4)
