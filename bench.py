@@ -34,6 +34,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes fails with hipIpcGetMemHandle otherwise (must precede HIP init)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -4,6 +4,8 @@ step with global statistics; rank 0 also runs the same global batch alone and co
 import os
 import sys
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 import torch.distributed as dist
 
