@@ -265,9 +265,11 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    parallel.init_from_env('nccl')                       # RCCL over xGMI
+    backend = os.environ.get('D4_BENCH_BACKEND', 'nccl')   # 'gloo': the N-rank code path on FEWER devices than ranks (tests/test_gpu_dp.py; RCCL wants a device per rank)
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
+    parallel.init_from_env(backend)                      # 'nccl' = RCCL over xGMI
     if world > 1 or os.environ.get('D4_BENCH_STRICT_TUNE') == '1':
         # N ranks must not each time GEMM tile configurations on their own clock (different choices per rank, first-step skew): every shape
         # of this workload has to come from the shipped table dreamer4_amd/gemm_tune_default.txt, else the first step fails with the shape named

@@ -32,3 +32,21 @@ def test_two_ranks_over_rccl_equal_one_process_at_the_global_batch():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count('DPGPU_OK_') == 2, out.stdout
+
+
+def test_bench_runs_its_multi_rank_path_with_two_ranks():
+    """bench.py launched as the driver launches it for N = 2 (torch.distributed.run, one rank per process): strict tile table (no rank times GEMM
+    tiles on its own clock), barrier + max-over-ranks timing, per-rank skew, value = the units ALL ranks processed / that time.  Two ranks share
+    the test box's one GPU over gloo (D4_BENCH_BACKEND; RCCL wants a device per rank) - the collective calls and the control flow are the N-rank ones."""
+    import json
+    env = dict(os.environ, D4_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', '29677',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, out.stdout                                # rank 0 prints ONE JSON line
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 512 and d['scaling'] == 'weak' and d['config']['parallelism'] == 'dp2'
+    assert abs(d['value'] - 2 * 256 * 16 / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
+    assert d['per_rank']['generate_ms_max'] >= d['per_rank']['generate_ms_min'] > 0 and 'cpu_baseline' not in d and 'cfg5_bf16' not in d
