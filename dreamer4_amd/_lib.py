@@ -139,6 +139,7 @@ SYMBOLS = {
     'd4_rmsnorm': (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
     'd4_rmsnorm_backward': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     'd4_hl_gauss_scalar': (_I, [_P, _I, _P, _P, _I, _I, _P]),
+    'd4_ppo_policy_loss': (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     'd4_gae': (_I, [_P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P]),
     'd4_categorical_sample_logp': (_I, [_P, _I, _P, _I, _P, _I, _I, _F, _P, _P, _P]),
     'd4_hl_gauss_ce': (_I, [_P, _I, _P, _P, _P, _I, _I, _F, _F, _F, _F, _I, _P, _P, _P, _P]),

@@ -718,6 +718,38 @@ int d4_hl_gauss_ce(const float* logits, int ld, const float* targets, const floa
     return 0;
 }
 
+// Stateless form of the policy branch's loss for discrete actions (D4:6077-6242: joint log-prob of the stored actions under MultiCategorical
+// logits, PPO clipped surrogate (objective 0, D4:6204-6212) or SPO (1, D4:6188-6198) against the behaviour log-probs, entropy bonus, masked mean
+// over the learnable steps), forward + backward in one call — the fused kernel d4_learn runs, with the advantages taken as given (normalise them
+// before):  loss[0] = sum_r mask[r] (pl_r - entropy_weight * H_r) / max(sum mask, 1),  dlogits [rows][ld] = d loss / d logits.
+// action_sizes: device int32 [na], total = their sum <= ld.  mask: [rows] or null.  scratch >= 5 * rows + 64 floats.
+int d4_ppo_policy_loss(const float* logits, int ld, const int64_t* actions, const float* old_log_probs, const float* advantages, const float* mask,
+                       const int32_t* action_sizes, int rows, int na, int total, int objective, float eps_clip, float entropy_weight, float* loss,
+                       float* dlogits, float* scratch, void* stream) {
+    D4_REQUIRE(logits && actions && old_log_probs && advantages && action_sizes && loss && dlogits && scratch && rows >= 1 && na >= 1 && total >= 1 && ld >= total,
+               "d4_ppo_policy_loss: bad arguments");
+    D4_REQUIRE(objective == 0 || objective == 1, "d4_ppo_policy_loss: objective 0 (ppo) or 1 (spo)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* scal = scratch;                     // [64]: [1] count, [4] sum pl, [5] sum -entropy
+    float* ones = scratch + 64;                // [rows]
+    float* row_pl = ones + rows, *row_ent = row_pl + rows, *row_aux = row_ent + rows;
+    D4_HIP(hipMemsetAsync(scal, 0, 64 * sizeof(float), s));
+    if (!mask) { if (int rc = d4::fill_f32(ones, 1.f, rows, s)) return rc; mask = ones; }
+    hipLaunchKernelGGL(d4::reduce1_kernel<d4::RED_SUM>, dim3(1), dim3(1024), 0, s, mask, (const float*)nullptr, scal, (int64_t)rows, scal + 1);
+    d4::PolicyLossArgs p{};
+    p.logits = logits; p.ld = ld; p.actions = actions; p.old_lp = old_log_probs; p.adv_raw = advantages; p.mask = mask; p.scal = scal;
+    p.action_sizes = action_sizes; p.dlogits = dlogits; p.row_pl = row_pl; p.row_ent = row_ent; p.row_aux = row_aux;
+    p.R = rows; p.na = na; p.A = total; p.objective = objective; p.normalize = 0; p.use_gate = 0; p.clip = eps_clip; p.ent_w = entropy_weight;
+    p.eps = 1e-6f; p.gate_temp = 1.f;
+    hipLaunchKernelGGL(d4::policy_loss_kernel, dim3(d4::cdiv(rows, 128)), dim3(128), 0, s, p);
+    hipLaunchKernelGGL(d4::reduce1_kernel<d4::RED_SUM>, dim3(1), dim3(1024), 0, s, row_pl, (const float*)nullptr, scal, (int64_t)rows, scal + 4);
+    hipLaunchKernelGGL(d4::reduce1_kernel<d4::RED_SUM>, dim3(1), dim3(1024), 0, s, row_ent, (const float*)nullptr, scal, (int64_t)rows, scal + 5);
+    hipLaunchKernelGGL(d4::finalize_losses_kernel, dim3(1), dim3(1), 0, s, scal, scratch + 32, objective, entropy_weight, 0.f);
+    D4_HIP(hipMemcpyAsync(loss, scratch + 32, sizeof(float), hipMemcpyDeviceToDevice, s));
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 // clip_grad_norm_(params, max_norm) followed by one AdamW step on a flat parameter group
 // (trainers.py:1436-1452; torch.optim.AdamW semantics).  scratch: >= 1025 floats.
 int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,

@@ -566,3 +566,57 @@ def _hl_ce_bwd(ctx, d_loss, _d_dl):
 
 
 hl_gauss_ce.register_autograd(_hl_ce_bwd, setup_context=_hl_ce_setup)
+
+
+@custom_op('d4hip::ppo_policy_loss', mutates_args=())
+def ppo_policy_loss(logits: torch.Tensor, actions: torch.Tensor, old_log_probs: torch.Tensor, advantages: torch.Tensor, mask: torch.Tensor | None,
+                    action_sizes: list[int], objective: int, eps_clip: float, entropy_weight: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """The policy branch's loss for discrete actions (D4:6077-6242), stateless: PPO clipped surrogate (objective 0) or SPO (1) of the stored actions'
+    joint log-prob against the behaviour log-probs, minus entropy_weight x entropy, mean over the masked rows; the advantages are taken as given.
+    logits (..., sum(action_sizes)), actions / old_log_probs (..., na), advantages / mask (...).  Returns (loss, d loss / d logits); differentiable
+    in `logits` through the second output (d4_ppo_policy_loss: the fused forward + backward kernel the learner runs)."""
+    _need_gpu(logits, actions, old_log_probs, advantages)
+    lib = _lib.load()
+    l2 = logits.float().contiguous().view(-1, logits.shape[-1])
+    na, total = len(action_sizes), sum(action_sizes)
+    rows = l2.shape[0]
+    a2 = actions.long().contiguous().view(rows, na)
+    o2 = old_log_probs.float().contiguous().view(rows, na)
+    adv = advantages.float().contiguous().view(rows)
+    m1 = mask.float().contiguous().view(rows) if mask is not None else None
+    assert total == l2.shape[1] and na >= 1
+    sizes = torch.tensor(action_sizes, dtype=torch.int32, device=logits.device)
+    loss = torch.empty(1, device=logits.device)
+    dl = torch.empty_like(l2)
+    scratch = torch.empty(5 * rows + 64, device=logits.device)
+    _lib.check(lib.d4_ppo_policy_loss(_lib.ptr(l2), total, _lib.ptr(a2), _lib.ptr(o2), _lib.ptr(adv), _lib.ptr(m1), _lib.ptr(sizes), rows, na, total, objective,
+                                      eps_clip, entropy_weight, _lib.ptr(loss), _lib.ptr(dl), _lib.ptr(scratch), _stream(logits)))
+    return loss.view(()), dl.view(logits.shape)
+
+
+@ppo_policy_loss.register_fake
+def _(logits, actions, old_log_probs, advantages, mask, action_sizes, objective, eps_clip, entropy_weight):
+    return logits.new_empty((), dtype=torch.float32), torch.empty_like(logits, dtype=torch.float32)
+
+
+def _ppo_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+
+
+def _ppo_bwd(ctx, d_loss, _d_dl):
+    (dl,) = ctx.saved_tensors
+    return dl * d_loss, None, None, None, None, None, None, None, None
+
+
+ppo_policy_loss.register_autograd(_ppo_bwd, setup_context=_ppo_setup)
+
+
+def attn_pool(x: torch.Tensor, hiddens: torch.Tensor, norm_w: torch.Tensor, norm_ctx_w: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor,
+              wo: torch.Tensor, wg: torch.Tensor, gamma: torch.Tensor) -> torch.Tensor:
+    """Residual(AttentionPool) (D4:2143-2177 + 1869) under its reference name: every token row of x (rows, dim) attends, as ONE query, over its own
+    row in each of the L layer hiddens (L, rows, dim) (4 pool heads x 64), and the result is added to x.  A thin composition of the dispatcher op
+    `torch.ops.d4hip.attn_block_cross` (context item-major; forward + registered backward: d4_cross_attn_forward / _backward) — differentiable in
+    x, the hiddens and every weight, traceable under torch.compile."""
+    assert x.ndim == 2 and hiddens.ndim == 3 and hiddens.shape[1:] == x.shape
+    out = torch.ops.d4hip.attn_block_cross(x[:, None, :], hiddens, norm_w, norm_ctx_w, wq, wk, wv, wo, wg, gamma, True, 0.)[0]
+    return x + out[:, 0, :]

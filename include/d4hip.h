@@ -399,6 +399,13 @@ int d4_categorical_sample_logp(const float* logits, int ld, const float* uniform
  * scratch >= 2 * rows + 64 floats. */
 int d4_hl_gauss_ce(const float* logits, int ld, const float* targets, const float* mask, const float* support, int rows, int bins, float vmin,
                    float vmax, float sigma, float eps, int two_hot, float* loss, float* dlogits, float* scratch, void* stream);
+/* The policy branch's loss for discrete actions, stateless (dreamer4.py:6077-6242: log-prob of the stored actions under the MultiCategorical
+ * logits, PPO clipped surrogate (objective 0, dreamer4.py:6204-6212) or SPO (1, dreamer4.py:6188-6198) against the behaviour log-probs
+ * [rows][na], entropy bonus, masked mean): loss[0] and dlogits [rows][ld] in one call — the fused kernel d4_learn runs, the advantages taken as
+ * given (normalise them before, dreamer4.py:5985-5999).  action_sizes: device int32 [na], `total` their sum.  scratch >= 5 * rows + 64 floats. */
+int d4_ppo_policy_loss(const float* logits, int ld, const int64_t* actions, const float* old_log_probs, const float* advantages, const float* mask,
+                       const int32_t* action_sizes, int rows, int na, int total, int objective, float eps_clip, float entropy_weight, float* loss,
+                       float* dlogits, float* scratch, void* stream);
 int d4_gae(const float* rewards, const float* values, const int64_t* lens, const uint8_t* is_truncated,
            const uint8_t* terminals, float gamma, float lam, int batch, int time, float* returns,
            void* stream);

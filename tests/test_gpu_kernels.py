@@ -511,3 +511,64 @@ def test_hl_gauss_ce_op_vs_oracle(lib, two_hot):
     loss_all, _ = torch.ops.d4hip.hl_gauss_ce(logits.cuda(), returns.cuda(), None, support.cuda(), vmin, vmax, sigma, cfg.hl_gauss_eps, two_hot)
     ref_all = (-(probs * logits.log_softmax(dim=-1)).sum(dim=-1)).mean()
     assert abs(loss_all.item() - ref_all.item()) < 1e-5 * max(1., abs(ref_all.item()))
+
+
+@pytest.mark.parametrize('objective,sizes', [(0, (4,)), (1, (4,)), (0, (3, 5, 2))])
+def test_ppo_policy_loss_op_vs_oracle(lib, objective, sizes):
+    """torch.ops.d4hip.ppo_policy_loss (d4_ppo_policy_loss): the policy branch's loss D4:6077-6242 for discrete actions — joint log-prob of the stored
+    actions, PPO clipped surrogate / SPO against the behaviour log-probs, entropy bonus, masked mean — and its gradient, against autograd of
+    oracle/restate.py's restatement (discrete_log_probs, masked_mean and the surrogate lines of learn_losses)."""
+    from oracle import restate
+    cfg = restate.Config(dim=64, dim_latent=8, num_latent_tokens=4, num_discrete_actions=tuple(sizes))
+    g = torch.Generator().manual_seed(31)
+    logits = torch.randn(5, 40, sum(sizes), generator=g) * 1.5
+    actions = torch.stack([torch.randint(0, n, (5, 40), generator=g) for n in sizes], dim=-1)
+    old_lp = restate.discrete_log_probs(cfg, logits + 0.3 * torch.randn(logits.shape, generator=g), actions)       # a nearby behaviour policy
+    adv = torch.randn(5, 40, generator=g)
+    mask = torch.rand(5, 40, generator=g) > 0.25
+    clip, ent_w = cfg.ppo_eps_clip, 0.02
+    lr = logits.clone().requires_grad_()
+    lps, ents = restate.discrete_log_probs(cfg, lr, actions, with_entropy=True)
+    lp, old = lps.sum(dim=-1), old_lp.sum(dim=-1)
+    ratio = (lp - old).exp()
+    if objective == 0:
+        pl = -torch.min(ratio * adv, ratio.clamp(1. - clip, 1. + clip) * adv)
+    else:
+        pl = -(ratio * adv - (adv.abs() * (ratio - 1.).square()) / (2 * clip))
+    ref = restate.masked_mean(pl, mask) + ent_w * restate.masked_mean(-ents.sum(dim=-1), mask)
+    ref.backward()
+    lg = logits.cuda().requires_grad_()
+    loss, _ = torch.ops.d4hip.ppo_policy_loss(lg, actions.cuda(), old_lp.cuda(), adv.cuda(), mask.cuda(), list(sizes), objective, clip, ent_w)
+    (3. * loss).backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1., abs(ref.item()))
+    assert torch.allclose(lg.grad.cpu(), 3. * lr.grad, atol=1e-6, rtol=1e-3)
+    compiled = torch.compile(lambda l: torch.ops.d4hip.ppo_policy_loss(l, actions.cuda(), old_lp.cuda(), adv.cuda(), None, list(sizes), objective, clip, ent_w)[0],
+                             backend='eager', fullgraph=True)
+    ref_all = pl.mean() + ent_w * (-ents.sum(dim=-1)).mean()
+    assert abs(compiled(logits.cuda()).item() - ref_all.item()) < 1e-5 * max(1., abs(ref_all.item()))
+
+
+def test_attn_pool_op_vs_oracle(lib):
+    """dreamer4_amd.ops.attn_pool — Residual(AttentionPool), D4:2143-2177 + 1869, as a composition of the dispatcher op attn_block_cross — against
+    oracle/restate.py's attention_pool on random weights, forward and the gradient with respect to the input tokens."""
+    from oracle import restate
+    from dreamer4_amd import ops
+    D, L, rows, hp = 64, 5, 33, 256
+    g = torch.Generator().manual_seed(41)
+    r = lambda *s, sc=1.: torch.randn(*s, generator=g) * sc
+    pre = 'p.'
+    W = {pre + 'fn.attn.norm.weight': 1. + r(D, sc=0.1), pre + 'fn.attn.norm_context.weight': 1. + r(D, sc=0.1), pre + 'fn.attn.to_q.weight': r(hp, D, sc=D ** -0.5),
+         pre + 'fn.attn.to_k.weight': r(hp, D, sc=D ** -0.5), pre + 'fn.attn.to_v.weight': r(hp, D, sc=D ** -0.5), pre + 'fn.attn.to_out.weight': r(D, hp, sc=hp ** -0.5),
+         pre + 'fn.attn.to_gates.0.weight': r(4, D, sc=D ** -0.5), pre + 'fn.attn.k_heads_rmsnorm.gamma': r(4, 64, sc=0.2)}
+    cfg = restate.Config(dim=D, dim_latent=8, num_latent_tokens=4)
+    hid = r(L, rows, D)
+    x = hid[-1].clone().requires_grad_()
+    ref = restate.attention_pool(cfg, W, pre, x[None], [h[None] for h in hid])[0]
+    ref.square().sum().backward()
+    xg = hid[-1].cuda().requires_grad_()
+    k = lambda n: W[pre + 'fn.attn.' + n].cuda()
+    out = ops.attn_pool(xg, hid.cuda(), k('norm.weight'), k('norm_context.weight'), k('to_q.weight'), k('to_k.weight'), k('to_v.weight'), k('to_out.weight'),
+                        k('to_gates.0.weight'), k('k_heads_rmsnorm.gamma'))
+    out.square().sum().backward()
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(xg.grad.cpu(), x.grad, atol=2e-4 * float(x.grad.abs().max()), rtol=1e-3)

@@ -125,7 +125,7 @@ def test_custom_ops_are_registered_with_the_dispatcher_and_traceable():
     import dreamer4_amd  # noqa: F401
     for name in ('rmsnorm', 'linear', 'hl_gauss_to_scalar', 'gae', 'rmsnorm_backward', 'linear_backward', 'swiglu_ff', 'swiglu_ff_backward',
                  'attn_block_space', 'attn_block_space_backward', 'attn_block_time', 'attn_block_time_backward', 'attn_block_cross',
-                 'attn_block_cross_backward', 'flow_euler_step'):
+                 'attn_block_cross_backward', 'flow_euler_step', 'ppo_policy_loss', 'hl_gauss_ce', 'categorical_sample_logp'):
         assert hasattr(torch.ops.d4hip, name), name
     from torch._subclasses.fake_tensor import FakeTensorMode
     with FakeTensorMode():
