@@ -148,6 +148,25 @@ def test_small_engine_bf16_tracks_fp32():
     assert (ea.values - eb.values).abs().max().item() < 0.2           # values live on [-20, 20]
 
 
+@pytest.mark.parametrize('kw,B', [(dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), 24),
+                                  (dict(dim=192, dim_latent=16, num_latent_tokens=8, depth=3, time_block_every=3, attn_heads=3, num_discrete_actions=(3, 2)), 5)])
+def test_bf16_engine_with_mixed_image_coverage_tracks_fp32(kw, B):
+    """bf16 engines whose shapes do NOT let every GEMM take the bf16-activation kernel: at dim 512 the SiLU-GLU hidden is 1376 wide (K % 64 = 32: its
+    consumer stays on the fp32-activation kernel, so the producer must keep writing the fp32 buffer next to the image), at dim 192 with 3 heads most
+    contractions are not multiples of 64 — producer -> consumer hand-offs through images, conversion passes and fp32 buffers all in one rollout.
+    Same bound against the fp32 engine as the small and the config-5 models."""
+    a, b = _pair(kw)
+    cfg = oracle_config(a)
+    nz = make_noise(cfg, 4, B, 7)
+    gk = dict(return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, return_terminals=False)
+    ea = a.generate(4, batch_size=B, noise=nz, **gk)
+    eb = b.generate(4, batch_size=B, noise=nz, **gk)
+    lat = (ea.latents - eb.latents).abs()
+    assert 0. < lat.max().item() < 3e-2 and lat.mean().item() < 3e-3, (lat.max().item(), lat.mean().item())
+    assert (ea.agent_embed - eb.agent_embed).abs().max().item() < 3e-2 * max(1., ea.agent_embed.abs().max().item())
+    assert (ea.values - eb.values).abs().max().item() < 0.2
+
+
 def test_config5_shape_bf16_vs_fp32_at_the_per_gpu_batch():
     """dim 1024, depth 12, 64 x 32 latents, 6 continuous (Beta) actions, B = 128 (= 1024 / 8 GPUs), 3 frames x (4 + 1) evaluations:
     the bf16 engine against the fp32 engine on identical weights and noise."""
