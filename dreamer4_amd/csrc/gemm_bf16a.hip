@@ -354,13 +354,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_pair_kernel(GemmArgs
 // 64x64/s     4 x 1    16 x 64     64 x 64     4 x 16 KB       2          SiLU-GLU capable
 // 32x64       2 x 2    16 x 32     32 x 64     4 x 12 KB       3
 // 256x128     4 x 2    64 x 64    256 x 128    3 x 48 KB       1          SiLU-GLU capable (large problems)
+// 256x192     4 x 3    64 x 64    256 x 192    2 x 56 KB       1          SiLU-GLU capable; 12 waves; where its tile count fits the machine's rounds better
 // 256x256     4 x 4    64 x 64    256 x 256    2 x 64 KB       1          SiLU-GLU capable; 16 waves; half the operand bytes per flop of 128 x 128 (these
 //                                                                        kernels are bound by what the L2s deliver: ~14 TB/s measured on the cfg-5 shapes)
 // Measured and retired (round 4, tools/bf16a_probe.py): rings of 4 - 8 stages at one workgroup per CU (the whole LDS in flight) are level or slower
 // than these — two co-resident workgroups hide more than a deeper ring; the k-loop step (~0.6 - 0.7 us for 128 x 128 x 64 even on a quarter of
 // the CUs) is bound inside the workgroup (barrier / DMA issue / fragment reads per k-tile), not by bytes in flight.
-enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_256x256, VA_N };
-static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256, 256}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128, 256};
+enum { VA_128x128 = 0, VA_128x64, VA_64x64, VA_64x64_s, VA_32x64, VA_256x128, VA_256x256, VA_256x192, VA_N };
+static const int kVaBM[VA_N] = {128, 128, 64, 64, 32, 256, 256, 256}, kVaBN[VA_N] = {128, 64, 64, 64, 64, 128, 256, 192};
 
 int gemm_bf16a_configs() { return VA_N; }
 
@@ -371,7 +372,7 @@ bool gemm_bf16a_applicable(const GemmArgs& p) {
 
 bool gemm_bf16a_config_valid(int c, const GemmArgs& p) {
     if (c < 0 || c >= VA_N || !gemm_bf16a_applicable(p)) return false;
-    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128 || c == VA_256x256;
+    if (p.flags & GEMM_SWIGLU) return c == VA_128x128 || c == VA_64x64_s || c == VA_256x128 || c == VA_256x256 || c == VA_256x192;
     return true;
 }
 
@@ -416,6 +417,7 @@ int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t e
         case VA_32x64: return launch_va<2, 2, 1, 2, 4>(p, stream, ea, eb);
         case VA_256x128: return launch_va<4, 2, 4, 4, 3>(p, stream, ea, eb);
         case VA_256x256: return launch_va<4, 4, 4, 4, 2>(p, stream, ea, eb);
+        case VA_256x192: return launch_va<4, 3, 4, 4, 2>(p, stream, ea, eb);
     }
     return 2;
 }
@@ -479,7 +481,15 @@ int gemm_bf16a_rule(const GemmArgs& p) {
     // input projection at 1792 rows (154 tiles) 46.6 -> 36.8 us, at 14336 rows 290 -> 202 us; the SiLU-GLU output projection at 14336 rows 131 -> 80 us;
     // the pool key projection at 114688 rows 143 -> 91 us.  Below that it leaves CUs idle and loses (28 tiles: 65 vs 25 us).
     const int64_t t256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) * nb;
-    if (t256 >= 140 && p.N >= 256) return VA_256x256;
+    const int64_t t192 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 192) * nb;
+    if ((t256 >= 140 || t192 >= 140) && p.N >= 256) {
+        // 256 x 192 (12 waves) when its rounds of the machine cost less tile area than the 256 x 256 form's: the SiLU-GLU input projection at 1792 rows
+        // (203 tiles in one round against 154: 36.5 -> 31.8 us), the fused q/k/v projection at 14336 rows (N = 1552: 73.6 -> 62.4 us); at 14336 x 5504
+        // the square tile stays (193 vs 216 us)
+        const int64_t c256 = t256 >= 140 ? (int64_t)cdiv(t256, 256) * 256 * 256 : INT64_MAX;
+        const int64_t c192 = t192 >= 140 ? (int64_t)cdiv(t192, 256) * 256 * 192 : INT64_MAX;
+        return c192 < c256 ? VA_256x192 : VA_256x256;
+    }
     if (swiglu) return t128 >= 200 ? VA_128x128 : VA_64x64_s;
     if (t128 >= 400 && p.N >= 128) return VA_128x128;
     if (t128x64 >= 300) return VA_128x64;

@@ -26,7 +26,7 @@ for M, N, K, name in shapes:
         Nout = N // 2 if flags & SWIGLU else N
         for cb in (True,):
             ts = []
-            for c in range(7):
+            for c in range(8):
                 call = lambda: lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(outb) if cb else None, None, None, 0, M, N, K, flags, 1e-6, c, s)
                 ts.append(timeit(call) if call() == 0 else float('nan'))
             print(f'{name:8s} M{M:6d} N{N:5d} K{K:5d} flags {flags} Cb {int(cb)}: ' + ' '.join(f'{t:7.1f}' for t in ts) + f' | best {2.0 * M * N * K / min(t for t in ts if t == t) / 1e6:6.0f} TF/s')
