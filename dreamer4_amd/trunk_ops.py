@@ -3,9 +3,11 @@
 `feedforward`, `space_attention`, `time_attention` and `cross_attention` are the reference FeedForward (dreamer4/dreamer4.py:2079-2116)
 and Attention (dreamer4.py:1968-2075: within a frame, along time with rotary + causal mask, over a context) as
 `torch.autograd.Function`s over the C-ABI operators `d4_ff_* / d4_space_attn_* / d4_time_attn_* / d4_cross_attn_*` (include/d4hip.h).
-Parameters are passed in the reference's own layout (the tensors of its state_dict), gradients come back in the same layout.  The blocks are the
-dispatcher-visible `torch.ops.d4hip.{swiglu_ff, attn_block_space, attn_block_time, attn_block_cross}` (dreamer4_amd/ops.py, autograd registered);
-the bare RMSNorm + Linear pieces of the trunk run on `torch.ops.d4hip.{rmsnorm, linear}`.  By default a
+Parameters are passed in the reference's own layout (the tensors of its state_dict), gradients come back in the same layout.  BY DEFAULT the blocks
+run as these plain `autograd.Function`s (less host dispatch time; not traceable by torch.compile); with D4_TRUNK_DISPATCHER=1 they go through
+their dispatcher registrations `torch.ops.d4hip.{swiglu_ff, attn_block_space, attn_block_time, attn_block_cross}` (dreamer4_amd/ops.py: fake
+implementations + registered autograd, same C-ABI operators, same results).  The bare RMSNorm + Linear pieces of the trunk always run on
+`torch.ops.d4hip.{rmsnorm, linear}`.  By default a
 block keeps the workspace its forward ran in and the backward (`*_backward_saved`) recomputes nothing; with D4_TRUNK_SAVE_FORWARD=0 the
 backward recomputes the forward intermediates and nothing but the inputs is kept alive between the two passes.  `transformer` composes
 the AxialSpaceTimeTransformer (dreamer4.py:2927-3267), `world_model_prediction` the dynamics model's `get_prediction`
@@ -236,7 +238,7 @@ def _dev(*ts):
 
 def feedforward(x, norm_weight, proj_in_weight, proj_in_bias, proj_out_weight, proj_out_bias):
     """FeedForward.forward (dreamer4.py:2105-2116): proj_out(a * silu(g)), [a | g] = proj_in(RMSNorm(x)).  x (..., dim).
-    = torch.ops.d4hip.swiglu_ff (dreamer4_amd/ops.py: dispatcher-visible, autograd registered)."""
+    With D4_TRUNK_DISPATCHER=1: torch.ops.d4hip.swiglu_ff (dreamer4_amd/ops.py: dispatcher-visible, autograd registered); default: the autograd.Function above."""
     _dev(x)
     if not via_dispatcher():
         return _FeedForward.apply(x, norm_weight, proj_in_weight, proj_in_bias, proj_out_weight, proj_out_bias)
@@ -247,7 +249,7 @@ def space_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma,
                     softclamp_value=50., num_special=1, belief=True):
     """Attention.forward (dreamer4.py:1968-2075), self attention within each frame: x (frames, tokens, dim) -> (frames, tokens, dim).
     `residual_values` (frames, tokens, heads, dim_head) with `mix_weight` / `mix_bias` = to_learned_value_residual_mix.0 (every layer
-    but the first); `num_special` trailing tokens are hidden from ordinary queries (dreamer4.py:1769-1783).  = torch.ops.d4hip.attn_block_space."""
+    but the first); `num_special` trailing tokens are hidden from ordinary queries (dreamer4.py:1769-1783).  (D4_TRUNK_DISPATCHER=1: torch.ops.d4hip.attn_block_space.)"""
     _dev(x)
     assert x.ndim == 3, 'x must be (frames, tokens, dim)'
     if not via_dispatcher():
@@ -261,7 +263,7 @@ def time_attention(x, norm_weight, to_q, to_k, to_v, to_out, to_gates, k_gamma, 
                    mix_bias=None, softclamp_value=50., belief=True):
     """The trunk's time layers (dreamer4.py:3176-3215): causal attention along time for every token column, rotary positions
     (`inv_freq` = time_rotary.inv_freq), no KV cache (the training form).  x (batch, frames, tokens, dim), frames <= 64;
-    `residual_values` (batch, frames, tokens, heads, dim_head).  = torch.ops.d4hip.attn_block_time."""
+    `residual_values` (batch, frames, tokens, heads, dim_head).  (D4_TRUNK_DISPATCHER=1: torch.ops.d4hip.attn_block_time.)"""
     _dev(x)
     assert x.ndim == 4, 'x must be (batch, frames, tokens, dim)'
     if not via_dispatcher():
@@ -275,7 +277,7 @@ def cross_attention(q_tokens, context, norm_weight, norm_context_weight, to_q, t
                     context_item_major=False, softclamp_value=None):
     """Attention.forward with a context (dreamer4.py:1968-2075): q_tokens (groups, nq, dim); context (groups, nk, dim_ctx), or
     (nk, groups, dim_ctx) with `context_item_major` (the stack of layer hiddens of the AttentionPool).  nq, nk <= 64.
-    = torch.ops.d4hip.attn_block_cross."""
+    (D4_TRUNK_DISPATCHER=1: torch.ops.d4hip.attn_block_cross.)"""
     _dev(q_tokens)
     assert q_tokens.ndim == 3 and context.ndim == 3
     if not via_dispatcher():
