@@ -58,7 +58,7 @@ def build_model(device):
     return m.to(device)
 
 
-def cpu_baseline(max_threads=16, full_budget_s=150.0):
+def cpu_baseline(max_threads=16, full_budget_s=150.0, keep=None):
     """The CPU oracle (oracle/restate.py, torch fp32) on the host cores, rank 0 at N = 1 only: the SAME workload as the GPU step
     (B = 256 trajectories, H + 1 = 16 frames, 4 + 1 evaluations per frame, + learn_from_experience(ppo) with its backward) run
     ONCE in full when a short probe projects it to fit `full_budget_s`; otherwise a bounded sample of the same architecture /
@@ -78,14 +78,18 @@ def cpu_baseline(max_threads=16, full_budget_s=150.0):
     cfg, W = oracle_config(m), oracle_weights(m)
     heads = ('policy_head', 'value_head', 'action_embedder.discrete_action_unembed')
 
+    nz_full = make_noise(cfg, HORIZON + 1, B_LOCAL, 1234)         # the draws the GPU rollout of `parity_at_headline` was given (trajectory-major slices)
+
     def run(batch, frames):
-        nz = make_noise(cfg, frames, batch, 1234)
+        nz = {k: v[:frames, :batch].contiguous() for k, v in nz_full.items()}
         t0 = time.perf_counter()
         with torch.no_grad():
             exp = restate.generate(cfg, W, frames, batch_size=batch, noise=nz, num_steps=NUM_STEPS)
         Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
         pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
         pl.backward(); vl.backward()
+        if keep is not None and frames == HORIZON + 1:
+            keep.update(exp=exp, noise=nz, cfg=cfg, batch=batch)
         return batch * exp['latents'].shape[1], time.perf_counter() - t0
 
     run(1, 1)                                           # warm-up (thread pool, allocator)
@@ -217,8 +221,9 @@ def train_flow_step(device, B=16, T=16, reps=4):
 
 def cfg5_bf16(device, lib, B=128, frames=16, reps=2):
     """BASELINE config 5, secondary numbers: dim 1024 depth 12, 64 x 32 latents, 6 continuous (Beta) actions, B = 128 per GPU
-    (1024 / 8), H = 15, trunk GEMMs on the bf16 MFMA path.  Rollout only (the learner is the same fp32 code as config 2)."""
-    from dreamer4_amd import DynamicsWorldModel, _lib
+    (1024 / 8), H = 15, trunk GEMMs on the bf16 MFMA path.  Both halves of BASELINE.json's metric: the rollout (imagined steps/s) and the
+    actor/critic step (learn_from_experience(ppo) on the Beta head + both backward passes + clip/AdamW on both heads; fp32, as at config 2)."""
+    from dreamer4_amd import DreamTrainer, DynamicsWorldModel, _lib
     from dreamer4_amd.synthetic import randomize_weights
     torch.manual_seed(0)
     m = randomize_weights(DynamicsWorldModel(**CFG5, matmul_dtype='bf16'), terminal_bias=-10.).to(device)
@@ -237,12 +242,58 @@ def cfg5_bf16(device, lib, B=128, frames=16, reps=2):
     _lib.check(lib.d4_profile_bf16_read(C.byref(ms), C.byref(fl), C.byref(cnt)))
     steps = B * e.latents.shape[1]
     ach = fl.value / max(ms.value, 1e-9) / 1e9
-    return dict(value=round(steps / dt, 1), unit='imagined steps/s', ms_per_rollout=round(1e3 * dt, 2), dtype='bf16 MFMA (fp32 accumulate / norms / softmax)',
-                workload=f'cfg5: dim=1024 depth=12 latents=64x32, 6 continuous actions, B={B}, H={frames - 1}, num_steps={NUM_STEPS}; rollout only',
+    # the second half of the metric: actor/critic step on this rollout (trainers.py:1430-1452)
+    tr = DreamTrainer(m, batch_size=B, generate_timesteps=frames - 1, objective='ppo')
+    tr.learn(e)                                            # warm-up: learner workspace, tile choices of the 2048-row head GEMMs
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(3):
+        tr.learn(e)
+    torch.cuda.synchronize()
+    learn_ms = 1e3 * (time.perf_counter() - t1) / 3
+    return dict(value=round(steps / dt, 1), unit='imagined steps/s', ms_per_rollout=round(1e3 * dt, 2), actor_critic_step_ms=round(learn_ms, 2),
+                whole_step_steps_per_sec=round(steps / (dt + 1e-3 * learn_ms), 1),
+                dtype='bf16 MFMA (fp32 accumulate / norms / softmax); learner fp32',
+                workload=f'cfg5: dim=1024 depth=12 latents=64x32, 6 continuous actions, B={B}, H={frames - 1}, num_steps={NUM_STEPS}; rollout, then learn_from_experience(ppo) + clip/AdamW both heads',
                 rollout_algorithmic_tflops=round(FLOP_PER_IMAGINED_STEP_CFG5 * steps / dt / 1e12, 1),
                 roofline=dict(bound='mfma', kernel='gemm_bf16a_kernel / gemm_bf16_kernel (all bf16 trunk GEMMs: bf16 activation images by LDS-DMA where the activation has one)', achieved=round(ach, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit='TFLOP/s',
                               frac=round(ach / PEAK_BF16_MFMA_TFLOPS, 4), launches_timed=int(cnt.value), event_stride=5,
                               avg_launch_us=round(1e3 * ms.value / max(cnt.value, 1), 2)))
+
+
+def cfg5_cpu_baseline(max_threads=16, budget_s=25.):
+    """The CPU oracle at config 5's architecture (dim 1024, depth 12, 6 Beta actions; torch fp32 on the host), rank 0 at N = 1 only: a BOUNDED
+    SAMPLE of the workload — the full one (B = 128, 16 frames: 69 TFLOP) would take minutes on the host — sized by a short probe to about `budget_s`."""
+    from dreamer4_amd import DynamicsWorldModel
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import make_noise, oracle_config, oracle_weights
+    from dreamer4_amd.synthetic import randomize_weights
+    from oracle import restate
+    host = os.cpu_count() or 1
+    cores = min(host, max_threads)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG5), terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    heads = ('policy_head', 'value_head', 'action_embedder.continuous_action_unembed')
+
+    def run(batch, frames):
+        nz = make_noise(cfg, frames, batch, 1234)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            exp = restate.generate(cfg, W, frames, batch_size=batch, noise=nz, num_steps=NUM_STEPS)
+        Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
+        pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
+        pl.backward(); vl.backward()
+        return batch * exp['latents'].shape[1], time.perf_counter() - t0
+
+    run(1, 1)
+    steps, dt = run(4, 2)
+    batch = int(max(2, min(128, budget_s / max(dt / steps, 1e-6) / (HORIZON + 1))))
+    steps, dt = run(batch, HORIZON + 1)
+    return dict(value=round(steps / dt, 2), unit='imagined steps/s', cores=cores, host_cores=host, kind='port',
+                sample=f'BOUNDED SAMPLE: oracle/restate.py at cfg5 (dim=1024 depth=12, 6 continuous actions), generate(B={batch}, frames={HORIZON + 1}, '
+                       f'num_steps={NUM_STEPS}) + learn(ppo): {steps} imagined steps in {dt:.1f} s, torch fp32, {cores} of {host} host threads')
 
 
 def main():
@@ -261,6 +312,16 @@ def main():
     env_over = experiment_overrides()
     assert not env_over or args.allow_experiment_env, (f'experiment switches set: {env_over} - the bench measures the product defaults (the ones the GPU tests '
                                                       'run under); unset them or pass --allow-experiment-env')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher — one process per GPU under torch.distributed.run (trainers.py:1388-1396 leaves
+        # this to `accelerate launch`); rank 0 of the children prints the one JSON line on this process's stdout
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+                                  '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -282,6 +343,15 @@ def main():
                            generate_kwargs=dict(return_for_policy_optimization=True, num_steps=NUM_STEPS))
     lib = _lib.load()
 
+    gpu_headline = None
+    if world == 1 and not args.no_cpu_baseline:
+        # parity at the headline size: the SAME rollout (B = 256, 16 frames) under injected draws with the INITIAL weights (before any optimiser step
+        # moves the heads), compared at the end with the oracle run that `cpu_baseline` times anyway (outside the timed region; the oracle is the
+        # checker here, never the thing measured)
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from util import make_noise, oracle_config
+        nz = make_noise(oracle_config(model), HORIZON + 1, B_LOCAL, 1234)
+        gpu_headline = model.generate(HORIZON + 1, batch_size=B_LOCAL, return_for_policy_optimization=True, num_steps=NUM_STEPS, noise=nz).cpu()
     timing = not args.no_kernel_timing
     ncls = lib.d4_profile_classes()
     raw_names = [lib.d4_profile_class_name(i).decode() for i in range(ncls)]
@@ -442,12 +512,36 @@ def main():
     if world == 1 and not args.no_secondary:
         del trainer, model
         torch.cuda.empty_cache()
-        out['cfg4_env_step'] = cfg4_env_latency(device)
-        out['cfg5_bf16'] = cfg5_bf16(device, lib)
-        out['train_flow_step'] = train_flow_step(device)
+        for key, fn in (('cfg4_env_step', lambda: cfg4_env_latency(device)), ('cfg5_bf16', lambda: cfg5_bf16(device, lib)),
+                        ('train_flow_step', lambda: train_flow_step(device))):
+            try:                                      # a failing secondary measurement must not cost the headline line
+                out[key] = fn()
+            except Exception as exc:                  # noqa: BLE001
+                out[key + '_error'] = repr(exc)
     if world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline()
+        kept = {}
+        out['cpu_baseline'] = cpu_baseline(keep=kept)
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+        if 'cfg5_bf16' in out:
+            try:
+                out['cfg5_bf16']['cpu_baseline'] = cfg5_cpu_baseline()
+                out['cfg5_bf16']['speedup_vs_cpu_baseline'] = round(out['cfg5_bf16']['whole_step_steps_per_sec'] / out['cfg5_bf16']['cpu_baseline']['value'], 1)
+            except Exception as exc:                  # noqa: BLE001
+                out['cfg5_bf16']['cpu_baseline_error'] = repr(exc)
+        if kept and gpu_headline is not None:
+            from util import rollout_parity
+            b = kept['batch']
+            from dataclasses import fields, replace
+            from torch.utils._pytree import tree_map
+            first = lambda v: v[:b] if torch.is_tensor(v) and v.ndim >= 1 else v
+            sub = replace(gpu_headline, **{f.name: tree_map(first, getattr(gpu_headline, f.name)) for f in fields(gpu_headline)})
+            try:
+                rep = rollout_parity(sub, kept['exp'], kept['noise'], kept['cfg'])
+            except Exception as exc:                      # noqa: BLE001 - the headline line must still be printed
+                rep = dict(error=repr(exc))
+            rep['what'] = (f'the GPU rollout of the first {b} of the B={B_LOCAL} trajectories x {HORIZON + 1} frames vs oracle/restate.py under the same injected draws '
+                           '(max |difference| per tensor over the trajectories whose sampling margins are well posed; integers must be equal there)')
+            out['parity_at_headline'] = rep
         if (os.cpu_count() or 1) >= 64:
             out['cpu_baseline_sharded'] = cpu_baseline_sharded()
     print(json.dumps(out))

@@ -34,14 +34,22 @@ def test_two_ranks_over_rccl_equal_one_process_at_the_global_batch():
     assert out.stdout.count('DPGPU_OK_') == 2, out.stdout
 
 
-def test_bench_runs_its_multi_rank_path_with_two_ranks():
+@pytest.mark.parametrize('launch', ['torch.distributed.run', 'bare'])
+def test_bench_runs_its_multi_rank_path_with_two_ranks(launch):
     """bench.py launched as the driver launches it for N = 2 (torch.distributed.run, one rank per process): strict tile table (no rank times GEMM
     tiles on its own clock), barrier + max-over-ranks timing, per-rank skew, value = the units ALL ranks processed / that time.  Two ranks share
-    the test box's one GPU over gloo (D4_BENCH_BACKEND; RCCL wants a device per rank) - the collective calls and the control flow are the N-rank ones."""
+    the test box's one GPU over gloo (D4_BENCH_BACKEND; RCCL wants a device per rank) - the collective calls and the control flow are the N-rank ones.
+    'bare': `python bench.py --gpus 2` with no launcher and no WORLD_SIZE — bench.py re-executes itself under torch.distributed.run (one process per
+    GPU) and still prints exactly one JSON line."""
     import json
     env = dict(os.environ, D4_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', '29677',
-           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1']
+    tail = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1']
+    if launch == 'bare':
+        cmd = [sys.executable, *tail]
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1', '--master-port', '29677', *tail]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]

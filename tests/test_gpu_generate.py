@@ -421,6 +421,36 @@ def test_full_size_properties_at_baseline_batch():
     close(c.latents, a.latents[100:104], atol=1e-5); close(c.values, a.values[100:104], atol=1e-5)
 
 
+# HIP vs the oracle at the headline size (B = 256 x 16 frames), per tensor: SURVEY 8(c)'s atol 2e-4 holds for every one of them (measured on MI355X:
+# latents 9e-7, agent_embed 2.9e-6, values 2.4e-6, rewards 2.4e-5 at scale 5, log-probs 4.2e-5 at scale 7.5).  BASELINE.md section 2 carries this
+# table next to the looser bounds some OTHER full-size tests use (different architectures / sharper logits), each with the scale that justifies it.
+HEADLINE_ATOL = dict(latents=2e-4, agent_embed=2e-4, values=2e-4, rewards=2e-4, log_probs=2e-4)
+
+
+def test_full_rollout_at_baseline_batch_vs_oracle():
+    """The WHOLE headline rollout — BASELINE config 2, bench.py's model and call: B = 256 trajectories x 16 frames x (4 + 1) evaluations, time
+    cache, actions / log-probs / values / rewards — against the oracle under the same injected noise (about a minute of oracle on 16 host
+    threads).  Integers exact on every trajectory whose sampling margins are well posed (util.rollout_parity), floats within HEADLINE_ATOL."""
+    from dreamer4_amd import DynamicsWorldModel
+    from util import rollout_parity
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8, attn_dim_head=64, num_spatial_tokens=4,
+                                             num_register_tokens=8, max_steps=64, multi_token_pred_len=8, num_discrete_actions=4), seed=0, terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = 256, 16
+    nz = make_noise(cfg, T, B, 1234)
+    with torch.no_grad():
+        ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, num_steps=4)
+    e = m.cuda().generate(T, batch_size=B, return_for_policy_optimization=True, num_steps=4, noise=nz)
+    rep = rollout_parity(e, ref, nz, cfg)
+    print(f'\nheadline rollout vs oracle: {rep}')
+    assert rep['frames_equal'] and rep['well_posed_trajectories'] >= B - 8
+    assert rep['actions_equal'] and rep['lens_equal'] and rep['terminals_equal']
+    for k, tol in HEADLINE_ATOL.items():
+        assert rep[k + '_max_abs'] <= tol, (k, rep[k + '_max_abs'], rep[k + '_scale'])
+
+
 def test_per_frame_fused_block_tails_equal_the_separate_kernels():
     """frame_fused.hip (within-frame attention -> output projection, attention-pool mix -> value / output projections, one workgroup per frame) is
     taken by rule at >= 192 frames: the same rollout with the fused tails (mode 1), with the pool mix kept as its own kernel (2) and with the

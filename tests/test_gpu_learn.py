@@ -271,3 +271,99 @@ def test_optimizer_arguments_step_the_heads_like_the_reference():
     assert any(not torch.equal(a, b) for a, b in zip(after, before))
     e2 = m.generate(4, batch_size=3, return_for_policy_optimization=True, noise=nz)       # heads are read in place: no re-prepare needed
     assert not torch.equal(e2.values, e.values)
+
+
+CFG2_ARCH = dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, attn_heads=8, attn_dim_head=64, num_spatial_tokens=4,
+                 num_register_tokens=8, max_steps=64, multi_token_pred_len=8, num_discrete_actions=4)
+
+
+@pytest.mark.parametrize('terminal_bias', [-10., -3.])
+def test_learn_at_baseline_size_vs_oracle(terminal_bias):
+    """The actor/critic step of the headline (BASELINE config 2: dim 512, depth 6, B = 256 trajectories x T = 16 frames = 4096 learner rows —
+    bench.py's `actor_critic_step_ms`) against the oracle AT THAT SIZE: learn_from_experience(ppo) = GAE -> z-score -> PPO surrogate + entropy ->
+    HL-Gauss CE (D4:5893-6305), both backward passes, then clip_grad_norm_(0.5) + AdamW(3e-4) on each head (trainers.py:1430-1452).  At 4096
+    rows the learner's MLP GEMMs take other tile configurations than every dim <= 128 test (k-sliced weight gradients, input gradients
+    through a transposed weight image).  Checked, on ONE Experience fed to both sides (the GPU's own B = 256 rollout; terminal bias -10 is
+    bench.py's model — nothing terminates; -3 ends a share of the trajectories early so that lens / masks / the terminal bootstrap matter):
+      * both losses, every gradient of policy_head.* / value_head.* / discrete_action_unembed, both gradient norms vs restate.learn_losses + autograd;
+      * the head weights after ONE DreamTrainer.learn vs torch clip_grad_norm_ + torch.optim.AdamW — on the GPU's gradients elementwise (the
+        optimiser kernel at this size), on the oracle's gradients as a relative l2 distance of the update (AdamW's first step is
+        lr * g / (|g| + 1e-8): elementwise it amplifies a 1e-9 gradient difference without bound where |g| ~ 1e-8)."""
+    from dreamer4_amd import DynamicsWorldModel
+    from util import randomize_weights
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG2_ARCH), seed=0, terminal_bias=terminal_bias)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = 256, 16
+    m = m.cuda()
+    nz = make_noise(cfg, T, B, 1234)
+    e = m.generate(T, batch_size=B, return_for_policy_optimization=True, num_steps=4, noise=nz)
+    assert e.agent_embed.shape == (B, e.latents.shape[1], 512)
+    if terminal_bias <= -10.:
+        assert e.latents.shape[1] == T and int(e.lens.min()) == T
+    else:
+        assert 0 < int((e.lens < e.latents.shape[1]).sum()) < B, 'this case is meant to end some, not all, trajectories early'
+    cpu = lambda x: x.detach().cpu()
+    ref = dict(latents=cpu(e.latents), agent_embed=cpu(e.agent_embed), rewards=cpu(e.rewards), values=cpu(e.values), log_probs=cpu(e.log_probs.discrete),
+               actions=cpu(e.actions.discrete), lens=cpu(e.lens), terminals=cpu(e.terminals), is_truncated=cpu(e.is_truncated),
+               old_action_unembeds=cpu(e.old_action_unembeds.discrete), step_size=e.step_size)
+    Wg = {k: (v.clone().requires_grad_() if k.startswith(HEADS) else v) for k, v in W.items()}
+    pl_o, vl_o = restate.learn_losses(cfg, Wg, ref, 'ppo')
+    pl_o.backward(); vl_o.backward()
+    # the oracle once more on inputs moved by fp32 rounding: what that does to each quantity is the yardstick (as in the random-config sweep above)
+    gen = torch.Generator().manual_seed(7)
+    jig = lambda x, r: x * (1 + r * (2 * torch.rand(x.shape, generator=gen) - 1))
+    ref2 = dict(ref, values=jig(ref['values'], 2e-6), rewards=jig(ref['rewards'], 2e-6), agent_embed=jig(ref['agent_embed'], 2e-6),
+                log_probs=ref['log_probs'] + 1e-6 * ref['old_action_unembeds'].abs().max() * (2 * torch.rand(ref['log_probs'].shape, generator=gen) - 1))
+    Wp = {k: (v.clone().requires_grad_() if k.startswith(HEADS) else v) for k, v in W.items()}
+    pl_p, vl_p = restate.learn_losses(cfg, Wp, ref2, 'ppo')
+    pl_p.backward(); vl_p.backward()
+
+    before = {k: p.detach().cpu().clone() for k, p in m.named_parameters() if k.startswith(HEADS) and p.numel() > 0}
+    tr = DreamTrainer(m, batch_size=B, generate_timesteps=T - 1, objective='ppo')
+    losses = tr.learn(e)                                        # learn_from_experience + both backward passes + clip + AdamW on both heads
+    close(losses[0], pl_o, atol=2e-5 + 20 * abs(pl_p.item() - pl_o.item())); close(losses[1], vl_o, atol=2e-5 + 20 * abs(vl_p.item() - vl_o.item()))
+    names = {id(p): k for k, p in m.named_parameters()}
+    n_checked = 0
+    for head, prefix in (('policy', ('policy_head', 'action_embedder.discrete_action_unembed')), ('value', ('value_head',))):
+        grp = m._groups[head]
+        keys = [names[id(p)] for p in grp['params']]
+        assert keys and all(k.startswith(prefix) for k in keys)
+        g_gpu = grp['grad'].detach().cpu()
+        off, worst = 0, 0.
+        for k, p in zip(keys, grp['params']):
+            gg, go = g_gpu[off:off + p.numel()].view(p.shape), Wg[k].grad
+            sens = (Wp[k].grad - go).abs().max().item()
+            close(gg, go, atol=20 * sens + 1e-5 * go.abs().max().item() + 1e-9, rtol=1e-4)
+            off += p.numel(); n_checked += 1
+        g_or = torch.cat([Wg[k].grad.reshape(-1) for k in keys])
+        g_pp = torch.cat([Wp[k].grad.reshape(-1) for k in keys])
+        # norms in float64: torch's fp32 `.norm()` of 9.5 M elements on the CPU is itself off by 3e-4 ... 2e-3 relative (its accumulation order
+        # depends on the thread count) - more than the whole GPU-vs-oracle difference (measured 2.5e-6 relative on every tensor)
+        n_or, n_pp = g_or.double().norm().item(), g_pp.double().norm().item()
+        close(tr._state[head]['scratch'][0], n_or, atol=1e-6 + 20 * abs(n_pp - n_or), rtol=2e-5)
+        assert (g_gpu.double() - g_or.double()).norm().item() <= 20 * (g_pp.double() - g_or.double()).norm().item() + 1e-5 * n_or
+
+        def torch_step(grads):                                  # trainers.py:1436-1452 on plain torch
+            ps = [before[k].clone().requires_grad_() for k in keys]
+            opt = torch.optim.AdamW(ps, lr=3e-4, weight_decay=0.)
+            o = 0
+            for q in ps:
+                q.grad = grads[o:o + q.numel()].view(q.shape).clone(); o += q.numel()
+            torch.nn.utils.clip_grad_norm_(ps, 0.5)
+            opt.step()
+            return torch.cat([q.detach().reshape(-1) for q in ps])
+        w0 = torch.cat([before[k].reshape(-1) for k in keys])
+        w_gpu = grp['flat'].detach().cpu()
+        assert not torch.equal(w_gpu, w0)
+        w_t = torch_step(g_gpu)                                 # the optimiser kernel on ITS gradients: elementwise
+        tiny = g_gpu.abs() < 1e-6 * g_gpu.abs().max()           # (|g| within ~100 x eps of 0: the step there is ill-conditioned in g's last bits)
+        assert (w_gpu - w_t)[~tiny].abs().max().item() <= 2e-7 + 1e-6 * w0.abs().max().item()
+        assert (w_gpu - w_t).abs().max().item() <= 3.1e-4        # never more than one full step of lr
+        w_o = torch_step(g_or)                                  # ... and on the oracle's gradients: the update as a whole
+        d = lambda x: x.double()
+        rel = (d(w_gpu) - d(w_o)).norm().item() / (d(w_o) - d(w0)).norm().item()
+        rel_p = (d(torch_step(g_pp)) - d(w_o)).norm().item() / (d(w_o) - d(w0)).norm().item()
+        assert rel <= 20 * rel_p + 1e-3, (head, rel, rel_p)
+    assert n_checked >= 10

@@ -342,3 +342,18 @@ def test_shortcut_coin_replays_when_the_generator_is_reseeded():
     assert run() == a
     g.manual_seed(6)
     assert run(32) != (a * 4)
+
+
+def test_bench_launches_itself_for_several_gpus():
+    """`python bench.py --gpus 2` with no launcher around it must become the launcher (one process per GPU under torch.distributed.run) instead of
+    failing on WORLD_SIZE.  Without a GPU the ranks then stop at bench.py's "needs an MI355X" check - which proves they were started as ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip('covered on the GPU by tests/test_gpu_dp.py (bare launch)')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0
+    assert 'needs an MI355X' in out.stderr and 'WORLD_SIZE=1' not in out.stderr, out.stderr[-2000:]

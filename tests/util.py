@@ -123,3 +123,52 @@ def t(a):
 
 def golden_noise(g, prefix):
     return {k: t(g[prefix + 'noise_' + k]) for k in ('latent', 'context', 'gumbel_u', 'bern_u', 'beta') if prefix + 'noise_' + k in g}
+
+
+def rollout_parity(e, ref, nz, cfg, margin=1e-3):
+    """A product rollout `e` (Experience) against the oracle's `ref` (restate.generate) under the same injected noise `nz`, at any batch size.
+    Exact-index parity is well posed only where the oracle's own decision margins exceed fp32 noise: per trajectory, the smallest
+    top-2 gap of (logit + Gumbel) over its sampled actions is recovered from the oracle's outputs; a trajectory below `margin` is 'ill posed' and
+    reported, not compared (an index that flips there sends the whole trajectory down
+    another path).  Returns a dict of plain numbers: counts, integer equality on the well-posed trajectories, max |diff| of the float fields there."""
+    F_ = ref['latents'].shape[1]
+    B = ref['latents'].shape[0]
+    well = torch.ones(B, dtype=torch.bool)
+    lg = ref.get('old_action_unembeds')
+    if lg is not None and lg.numel() > 0:
+        Fa = lg.shape[1]
+        u = nz['gumbel_u'][:Fa].transpose(0, 1)[:B]
+        g = -torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+        z, o = lg + g, 0
+        for n in cfg.num_discrete_actions:
+            top = z[..., o:o + n].topk(2, dim=-1).values
+            gap = top[..., 0] - top[..., 1]                                            # (B, Fa)
+            valid = torch.arange(Fa)[None] < ref['lens'][:, None]
+            well &= (gap.masked_fill(~valid, float('inf')).min(dim=1).values >= margin)
+            o += n
+    out = dict(trajectories=B, frames=F_, well_posed_trajectories=int(well.sum()), margin=margin)
+    same_len = e.latents.shape[1] == F_
+    out['frames_equal'] = bool(same_len)
+    if not same_len or not well.any():
+        return out
+    c = lambda x: x.detach().cpu()
+    acts = c(e.actions.discrete) if e.actions is not None and e.actions.discrete is not None else None
+    if acts is not None and ref.get('actions') is not None:
+        eq = (acts == ref['actions']).flatten(1).all(dim=1)
+        out['actions_equal'] = bool(eq[well].all())
+        out['trajectories_with_identical_actions'] = int(eq.sum())
+        well = well & eq if not out['actions_equal'] else well
+        if not well.any():
+            return out
+    out['lens_equal'] = bool(torch.equal(c(e.lens)[well], ref['lens'][well]))
+    if 'terminals' in ref and e.terminals is not None:
+        out['terminals_equal'] = bool(torch.equal(c(e.terminals)[well], ref['terminals'][well]))
+    for name, a, b in (('latents', e.latents, ref['latents']), ('agent_embed', e.agent_embed, ref.get('agent_embed')),
+                       ('values', e.values, ref.get('values')), ('rewards', e.rewards, ref.get('rewards')),
+                       ('log_probs', e.log_probs.discrete if e.log_probs is not None else None, ref.get('log_probs'))):
+        if a is None or b is None:
+            continue
+        a, b = c(a).float()[well], b.float()[well]
+        out[name + '_max_abs'] = float((a - b).abs().max())
+        out[name + '_scale'] = float(b.abs().max())
+    return out
