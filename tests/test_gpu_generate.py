@@ -290,8 +290,8 @@ def test_full_size_config_vs_oracle(B):
     ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, return_terminals=False)
     e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
                           return_log_probs_and_values=True, noise=nz)
-    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed'], atol=5e-4)
-    close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'], atol=5e-4)
+    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed'])
+    close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'])
     assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
 
 
@@ -314,8 +314,8 @@ def test_short_history_time_attention_eager_and_graph_replay_vs_oracle(graph_row
     e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
                           return_log_probs_and_values=True, noise=nz)
     assert e.latents.shape[1] == T
-    close(e.latents, ref['latents'], atol=5e-4); close(e.agent_embed, ref['agent_embed'], atol=1e-3)
-    close(e.values, ref['values'], atol=5e-4); close(e.log_probs.discrete, ref['log_probs'], atol=1e-3)
+    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed'])
+    close(e.values, ref['values']); close(e.log_probs.discrete, ref['log_probs'])
     assert torch.equal(e.actions.discrete.cpu(), ref['actions'])
 
 
@@ -392,8 +392,8 @@ def test_config5_shape_vs_oracle():
             break
     e = m.cuda().generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
                           return_log_probs_and_values=True, noise=nz)
-    close(e.latents, ref['latents'], atol=5e-4); close(e.agent_embed, ref['agent_embed'], atol=1e-3)
-    close(e.values, ref['values'], atol=5e-4); close(e.log_probs.continuous, ref['log_probs_cont'], atol=2e-3)
+    close(e.latents, ref['latents']); close(e.agent_embed, ref['agent_embed'])
+    close(e.values, ref['values']); close(e.log_probs.continuous, ref['log_probs_cont'])
     close(e.actions.continuous, ref['actions_cont'], atol=1e-4)
 
 
@@ -663,7 +663,7 @@ def test_config4_env_wrapper_pattern_at_full_size_vs_oracle():
         lat_e, rew_e = e.latents, e.rewards
         assert tc.frames == i + 1 and e.latents.shape[1] == i + 1
         worst = max(worst, (e.latents[:, -1].cpu() - ref['latents'][:, -1]).abs().max().item())
-        close(e.latents[:, -1], ref['latents'][:, -1], atol=5e-4); close(e.rewards[:, -1], ref['rewards'][:, -1], atol=2e-3)
+        close(e.latents[:, -1], ref['latents'][:, -1]); close(e.rewards[:, -1], ref['rewards'][:, -1])
         assert not bool(e.terminals.any())
     print(f'\ncfg4 full size, 50 chained env steps: worst latent deviation from the oracle {worst:.2e}')
 
