@@ -136,6 +136,9 @@ SYMBOLS = {
     'd4_cvt_rows_bf16': (_I, [_P, _L, _P, _L, _I, _I, _P]),
     'd4_split_bf16x3': (_I, [_P, _P, _L, _L, _P]),
     'd4_gemm_split': (_I, [_P, _I, _P, _L, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    'd4_split_f16x2': (_I, [_P, _P, _I, _I, _I, _L, _P, _P]),
+    'd4_row_scale_exp': (_I, [_P, _L, _I, _I, _P, _P]),
+    'd4_gemm_split2': (_I, [_P, _I, _P, _L, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     'd4_rmsnorm': (_I, [_P, _I, _P, _P, _I, _I, _I, _F, _P]),
     'd4_rmsnorm_backward': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     'd4_hl_gauss_scalar': (_I, [_P, _I, _P, _P, _I, _I, _P]),

@@ -85,8 +85,17 @@ struct d4_engine {
     // ---- bf16 compute (opt-in): bf16 mirrors of every weight the trunk GEMMs read, carved from one arena of the workspace
     bool bf16 = false;                     // the trunk's GEMMs read mirrors of their weights (bf16 mode, or the three planes of the split-operand fp32 mode)
     bool split = false;                    // mirrors are three bf16 planes (plane stride = bf16_cap): fp32 GEMMs on the bf16 matrix cores (gemm_x3.hip)
+    bool h2 = false;                       // opt-in `fp32_fp16x2` mode: mirrors are two fp16 planes + an exact power-of-two scale per weight row (gemm_h2.hip:
+                                           // 23-bit operand images, three products, fp32 accumulate); activations stay fp32, their row exponents in `aexp`
+    bool fp32_planes() const { return split || h2; }      // an fp32-class engine whose GEMMs read plane mirrors of their weights
     uint16_t* bf16_arena = nullptr; size_t bf16_cap = 0, bf16_used = 0;
-    struct Mirror { const float* src; size_t n; uint16_t* dst; };
+    float* wscale_arena = nullptr; size_t wscale_cap = 0, wscale_used = 0;      // h2 mode: the inverse row scales, one float per mirrored weight row
+    // h2 mode: scale exponents of activation rows (GemmArgs::aexp).  The residual-stream slabs keep theirs for the whole evaluation (every later attention
+    // pool re-reads every earlier slab): aexp_slab [nslab][M] + one validity flag per slab, cleared when an evaluation starts; any other A gets its
+    // exponents into aexp_tmp right before the GEMM that reads it
+    int* aexp_slab = nullptr; int* aexp_tmp = nullptr; size_t aexp_tmp_rows = 0, aexp_M = 0;      // aexp_M: token rows per slab in the running evaluation
+    std::vector<char> aexp_valid;
+    struct Mirror { const float* src; size_t n; uint16_t* dst; int ld; float* scales; };
     std::vector<Mirror> mirrors;
     // bf16 mode (not split): bf16 IMAGES of the activation buffers the trunk GEMMs read (same element offsets / leading dimensions as the fp32
     // buffer).  Producers write them (GEMM epilogue `Cb`, attention / pool-mix `out_b`, a conversion pass elsewhere) and consumers read them

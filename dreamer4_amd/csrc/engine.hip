@@ -82,7 +82,11 @@ int engine_layout(d4_engine* e, bool assign) {
         const size_t per_pool = (size_t)(hp + e->php + 2 * hp) * D + (size_t)D * hp;
         const size_t extra = (size_t)(hd + c.attn_heads + 2 * hd + hd) * D + (size_t)2 * hd * dl + (size_t)2 * hd * D + (size_t)dl * (hd > D ? hd : D) + (size_t)D * hd + (size_t)D * dl;
         e->bf16_cap = ((size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096 + 7) / 8 * 8;
-        e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * (e->split ? 3 : 1) * sizeof(uint16_t)));     // split mode: three planes
+        e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * (e->split ? 3 : (e->h2 ? 2 : 1)) * sizeof(uint16_t)));     // split mode: three planes; fp16x2 mode: two
+        if (e->h2) {
+            e->wscale_cap = e->bf16_cap / 16 + 64;           // one float per weight row; the narrowest mirrored matrix has >= 16 columns
+            e->wscale_arena = reinterpret_cast<float*>(alloc_bytes(e->wscale_cap * sizeof(float)));
+        }
     }
     const size_t KR = e->decoder ? (size_t)e->P : (e->encoder ? (size_t)n : (size_t)ns + 1);        // token rows per frame the final stage keeps (compact copies)
     const size_t KQ = e->encoder ? (size_t)n : 1;                        // special tokens per frame that cross-attend (D4:3227-3238)
@@ -119,8 +123,14 @@ int engine_layout(d4_engine* e, bool assign) {
     e->pool_kv = fl((size_t)e->nslab * M * 2 * hp);
     e->pool_att = fl(M * hp);
     e->pool_u = fl(M * (size_t)e->php * D);
+    if (e->h2) {
+        e->aexp_slab = reinterpret_cast<int*>(alloc_bytes((size_t)e->nslab * M * sizeof(int)));
+        e->aexp_tmp_rows = (size_t)e->nslab * M;
+        e->aexp_tmp = reinterpret_cast<int*>(alloc_bytes(e->aexp_tmp_rows * sizeof(int)));
+        e->aexp_valid.assign(e->nslab, 0);
+    }
     e->shadows.clear();
-    if (e->bf16 && !e->split && !e->decoder && !e->encoder) {
+    if (e->bf16 && !e->fp32_planes() && !e->decoder && !e->encoder) {
         static const bool shadows_on = !(getenv("D4_BF16_ACT") && atoi(getenv("D4_BF16_ACT")) == 0);       // 0: fp32 activations into every bf16 GEMM (the round-2 form)
         auto sh = [&](const float* src, size_t n, bool only) {
             uint16_t* dst = reinterpret_cast<uint16_t*>(alloc_bytes(n * sizeof(uint16_t)));
@@ -369,19 +379,70 @@ static thread_local d4_engine* t_bf16 = nullptr;
 static thread_local int t_sig_uniform = -1;    // >= 0: every frame of the next engine_forward is at this signal level (decode loop: no fill kernel)
 static thread_local int t_keep_lo = 1;         // first token row of a frame the compacted copies keep (set by engine_forward)
 
-static int mirror_weight(d4_engine* e, const float* src, size_t n, hipStream_t s) {
+static int mirror_weight(d4_engine* e, const float* src, size_t rows, int ld, hipStream_t s) {
+    size_t n = rows * (size_t)ld;
     if (!e->bf16 || !src || n == 0) return 0;
     n = (n + 7) / 8 * 8;
     D4_REQUIRE(e->bf16_used + n <= e->bf16_cap, "bf16 weight arena exhausted (%zu + %zu > %zu)", e->bf16_used, n, e->bf16_cap);
     uint16_t* dst = e->bf16_arena + e->bf16_used;
+    if (e->h2) {
+        // two fp16 planes under one exact power-of-two scale per row (gemm_h2.hip); a matrix too narrow for that kernel's 16-byte plane rows
+        // (ld % 8) gets no mirror: its GEMMs stay on the f32-input kernels
+        if ((ld % 8) != 0) return 0;
+        D4_REQUIRE(e->wscale_used + rows <= e->wscale_cap, "weight scale arena exhausted");
+        float* sc = e->wscale_arena + e->wscale_used;
+        e->wscale_used += rows;
+        e->bf16_used += n;
+        e->mirrors.push_back({src, n, dst, ld, sc});
+        return split_f16x2_rows(src, dst, (int)rows, ld, ld, (int64_t)e->bf16_cap, sc, s);
+    }
     e->bf16_used += n;
-    e->mirrors.push_back({src, n, dst});
+    e->mirrors.push_back({src, n, dst, ld, nullptr});
     if (e->split) return split_bf16x3(src, dst, (int64_t)n, (int64_t)e->bf16_cap, s);
     return cvt_f32_to_bf16(src, dst, (int64_t)n, s);
 }
 
+// fp16x2 mode: attach the fp16 planes and row scales of g's weight view (whole rows of a mirrored matrix at its leading dimension) and — when the
+// dispatcher's rule sends the call to gemm_h2.hip — the scale exponents of A's rows: a residual-stream slab keeps them for the evaluation
+// (computed once, by the first GEMM that reads the slab), any other activation buffer gets them right here (row_scale_exp: one small launch)
+static int attach_h2(d4_engine* e, GemmArgs& g, hipStream_t s) {
+    g.Wb = nullptr; g.wplane = 0; g.wscale = nullptr; g.strideWs = 0; g.aexp = nullptr;
+    const int nb = g.batch > 1 ? g.batch : 1;
+    for (const auto& m : e->mirrors) {
+        if (g.W < m.src || g.W >= m.src + m.n) continue;
+        const size_t off = (size_t)(g.W - m.src);
+        if (g.ldw != m.ld || (off % (size_t)m.ld) != 0 || (nb > 1 && (g.strideW % m.ld) != 0)) return 0;     // not a row view: f32-input kernels
+        g.Wb = m.dst + off; g.wplane = (int64_t)e->bf16_cap; g.wscale = m.scales + off / (size_t)m.ld; g.strideWs = nb > 1 ? g.strideW / m.ld : 0;
+        break;
+    }
+    if (!g.Wb || !gemm_h2_takes(g)) { g.Wb = nullptr; g.wplane = 0; g.wscale = nullptr; g.strideWs = 0; return 0; }
+    if (nb > 1) return 0;                                   // batched views: the kernel finds the row exponents itself
+    const size_t M = e->aexp_M;
+    if (M > 0 && g.A >= e->slabs && g.A < e->slabs + (size_t)e->nslab * M * e->D && g.lda == e->D && g.K == e->D && ((size_t)(g.A - e->slabs) % (size_t)e->D) == 0) {
+        const size_t row0 = (size_t)(g.A - e->slabs) / e->D;
+        if (row0 + g.M <= (size_t)e->nslab * M) {
+            for (size_t sl = row0 / M; sl <= (row0 + g.M - 1) / M; ++sl) {
+                if (e->aexp_valid[sl]) continue;
+                if (int rc = row_scale_exp(e->slabs + sl * M * e->D, e->D, (int)M, e->D, e->aexp_slab + sl * M, s)) return rc;
+                e->aexp_valid[sl] = 1;
+            }
+            g.aexp = e->aexp_slab + row0;
+            return 0;
+        }
+    }
+    if ((size_t)g.M <= e->aexp_tmp_rows && (g.K % 4) == 0) {
+        if (int rc = row_scale_exp(g.A, g.lda, g.M, g.K, e->aexp_tmp, s)) return rc;
+        g.aexp = e->aexp_tmp;
+    }
+    return 0;
+}
+
 static int engine_gemm(GemmArgs& g, hipStream_t s) {
     if (d4_engine* e = t_bf16) {
+        if (e->h2) {
+            if (int rc = attach_h2(e, g, s)) return rc;
+            return gemm(g, s);
+        }
         g.Wb = nullptr;
         for (const auto& m : e->mirrors)
             if (g.W >= m.src && g.W < m.src + m.n) { g.Wb = m.dst + (g.W - m.src); break; }
@@ -391,7 +452,7 @@ static int engine_gemm(GemmArgs& g, hipStream_t s) {
             if (!gemm_x3_applicable(g)) { g.Wb = nullptr; g.wplane = 0; }
         } else
         if (!gemm_bf16_applicable(g)) g.Wb = nullptr;       // e.g. K not a multiple of 32: this call stays on the fp32 kernel
-        if (!e->split && !e->shadows.empty()) {
+        if (!e->fp32_planes() && !e->shadows.empty()) {
             // bf16 activation images: read A's when it has one (and the bf16-activation kernel takes the call), refresh C's either in the
             // epilogue of that kernel or by a conversion pass after any other kernel
             uint16_t* cb = e->shadow_of(g.C);
@@ -435,7 +496,13 @@ static int gemm_simple(const float* A, int lda, const float* W, int ldw, float* 
 
 // Two independent projections of equal K: one launch when both are few-row problems (fp32 engine), else one after the other.
 static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
-    if ((!t_bf16 || t_bf16->split) && gemm_skinny_pair_applicable(a, b)) return gemm_skinny_pair(a, b, s);
+    if ((!t_bf16 || t_bf16->fp32_planes()) && gemm_skinny_pair_applicable(a, b)) return gemm_skinny_pair(a, b, s);
+    if (t_bf16 && t_bf16->h2) {
+        // fp16x2 mode: each call by the rule (the key projection of many rows on gemm_h2.hip, the small query projection on the f32-input kernels)
+        int rc;
+        if ((rc = engine_gemm(a, s))) return rc;
+        return engine_gemm(b, s);
+    }
     if (!t_bf16 || t_bf16->split) {
         // fp32 engine: one grid for both when the dispatcher's pair form applies (gemm_pair falls back to two launches itself)
         if (d4_engine* e = t_bf16) {
@@ -452,7 +519,7 @@ static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
     // bf16 engine: both activations have bf16 images and neither output has one -> one grid on the bf16-activation kernel (the pool's query
     // projection rides in the key projection's launch)
     if (d4_engine* e = t_bf16) {
-        if (!e->split && !e->shadows.empty() && !e->shadow_of(a.C) && !e->shadow_of(b.C)) {
+        if (!e->fp32_planes() && !e->shadows.empty() && !e->shadow_of(a.C) && !e->shadow_of(b.C)) {
             GemmArgs pa = a, pb = b;
             bool ok = true;
             for (GemmArgs* g : {&pa, &pb}) {
@@ -582,31 +649,32 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
     // ---- bf16 mirrors of everything the trunk's GEMMs read (prepared images above + the raw output projections)
     if (e->bf16) {
         e->mirrors.clear(); e->bf16_used = 0;
-        auto mir = [&](const float* w, size_t n) { return mirror_weight(e, w, n, s); };
+        e->wscale_used = 0;
+        auto mir = [&](const float* w, size_t rows, int ld) { return mirror_weight(e, w, rows, ld, s); };
         for (int l = 0; l < c.depth; ++l) {
-            if ((rc = mir(e->proj_w[l], (size_t)(l == 0 ? e->Nproj0 : e->Nproj) * D))) return rc;
-            if ((rc = mir(e->layer_attn[l].to_out, (size_t)D * hd))) return rc;
+            if ((rc = mir(e->proj_w[l], (size_t)(l == 0 ? e->Nproj0 : e->Nproj), D))) return rc;
+            if ((rc = mir(e->layer_attn[l].to_out, (size_t)D, hd))) return rc;
         }
         for (int l = 0; l <= c.depth; ++l) {
-            if ((rc = mir(e->ffp[l].w1, (size_t)2 * e->inner_pad * D))) return rc;
-            if ((rc = mir(e->ffp[l].w2, (size_t)D * e->inner_pad))) return rc;
+            if ((rc = mir(e->ffp[l].w1, (size_t)2 * e->inner_pad, D))) return rc;
+            if ((rc = mir(e->ffp[l].w2, (size_t)D, e->inner_pad))) return rc;
         }
         for (int p = 0; p < c.depth; ++p) {
-            if ((rc = mir(e->pq_w[p], (size_t)(hp + e->php) * D))) return rc;
-            if ((rc = mir(e->pkv_w[p], (size_t)2 * hp * D))) return rc;
-            if ((rc = mir(e->pools[p].to_out, (size_t)D * hp))) return rc;
+            if ((rc = mir(e->pq_w[p], (size_t)(hp + e->php), D))) return rc;
+            if ((rc = mir(e->pkv_w[p], (size_t)2 * hp, D))) return rc;
+            if ((rc = mir(e->pools[p].to_out, (size_t)D, hp))) return rc;
         }
-        if ((rc = mir(e->cq_w, (size_t)(hd + h) * D))) return rc;
-        if ((rc = mir(e->ckv_w, (size_t)2 * hd * D))) return rc;
-        if ((rc = mir(e->cross.to_out, (size_t)D * hd))) return rc;
+        if ((rc = mir(e->cq_w, (size_t)(hd + h), D))) return rc;
+        if ((rc = mir(e->ckv_w, (size_t)2 * hd, D))) return rc;
+        if ((rc = mir(e->cross.to_out, (size_t)D, hd))) return rc;
         if (ns == n) {
-            if ((rc = mir(e->lin_w, (size_t)D * dl))) return rc;
-            if ((rc = mir(e->lout_w, (size_t)dl * D))) return rc;
+            if ((rc = mir(e->lin_w, (size_t)D, dl))) return rc;
+            if ((rc = mir(e->lout_w, (size_t)dl, D))) return rc;
         } else {
-            if ((rc = mir(e->lin_kv_w, (size_t)2 * hd * dl))) return rc;
-            if ((rc = mir(e->lq_in.to_out, (size_t)D * hd))) return rc;
-            if ((rc = mir(e->lout_kv_w, (size_t)2 * hd * D))) return rc;
-            if ((rc = mir(e->lout_w, (size_t)dl * hd))) return rc;
+            if ((rc = mir(e->lin_kv_w, (size_t)2 * hd, dl))) return rc;
+            if ((rc = mir(e->lq_in.to_out, (size_t)D, hd))) return rc;
+            if ((rc = mir(e->lout_kv_w, (size_t)2 * hd, D))) return rc;
+            if ((rc = mir(e->lout_w, (size_t)dl, hd))) return rc;
         }
     }
 
@@ -654,7 +722,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         if (t_bf16) if (uint16_t* ub = t_bf16->shadow_of(e->pool_u)) { pm.u_b = ub; if (t_bf16->shadow_only(e->pool_u)) pm.u = nullptr; }   // only the value GEMM reads the mixes
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
         // D4_FRAME_FUSED=2: the mix stays its own kernel and only the tail is fused
-        if (S > 0 && M % S == 0 && !e->pv_t.empty() && (!t_bf16 || t_bf16->split) && frame_pool_tail_applicable(M / S, S, D, c.pool_heads)) {
+        if (S > 0 && M % S == 0 && !e->pv_t.empty() && (!t_bf16 || t_bf16->fp32_planes()) && frame_pool_tail_applicable(M / S, S, D, c.pool_heads)) {
             const bool tail_only = frame_fused_mode() == 2;
             if (!tail_only) return frame_pool(pm, e->pv_t[p], e->po_t[p], M / S, S, x, D, y, D, y_compact, D, e->keep_lo, e->keep_hi, has_agent, s);
             if ((rc = pool_mix(pm, s))) return rc;
@@ -717,6 +785,10 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
     const int Fr = B * Tq, M = Fr * S;
     const bool denoise_only = !need_agent && !e->encoder && !e->decoder;        // dynamics evaluation whose last layer only feeds the spatial rows
     int rc;
+    if (e->h2) {                              // fp16x2 mode: every slab is rewritten by this evaluation -> no row exponent of the last one is valid
+        e->aexp_M = (size_t)M;
+        std::fill(e->aexp_valid.begin(), e->aexp_valid.end(), 0);
+    }
 
     float* slab0 = e->slabs;
     auto slab = [&](int j) { return e->slabs + (size_t)j * M * D; };
@@ -816,10 +888,10 @@ static int engine_forward_impl(d4_engine* e, const float* latents, int B, int Tq
             }
             // per-frame fused form: attention of all heads of a frame, then its output projection + residual, in one kernel
             const bool tail_compact = denoise_only && l == c.depth - 1 && c.depth >= 2 && S <= 16 && S >= 8;
-            if (!tail_compact && !e->wo_t.empty() && (!t_bf16 || t_bf16->split) && frame_attn_out_applicable(sa, D)) {
+            if (!tail_compact && !e->wo_t.empty() && (!t_bf16 || t_bf16->fp32_planes()) && frame_attn_out_applicable(sa, D)) {
                 if ((rc = frame_attn_out(sa, e->wo_t[l], D, x_in, D, slab(2 * l + 1), D, cslab(2 * l + 1), D, e->keep_lo, e->keep_hi, has_agent, s))) return rc;
                 fused_out = true;
-            } else if (!tail_compact && hd == 512 && (!t_bf16 || t_bf16->split) && attn_out_cols_applicable(sa, D)) {
+            } else if (!tail_compact && hd == 512 && (!t_bf16 || t_bf16->fp32_planes()) && attn_out_cols_applicable(sa, D)) {
                 // few frames (launch-bound decode): attention recomputed inside every column workgroup of the output projection, one launch for two
                 if ((rc = attn_out_cols(sa, a.to_out, hd, D, x_in, D, slab(2 * l + 1), D, cslab(2 * l + 1), D, e->keep_lo, e->keep_hi, has_agent, s))) return rc;
                 fused_out = true;
@@ -1060,6 +1132,7 @@ int d4_engine_create(const d4_config* cfg, d4_engine** out) {
     e->nc = c.num_continuous_actions;
     e->bf16 = c.matmul_bf16 != 0;
     e->split = c.matmul_bf16 == 2;
+    e->h2 = c.matmul_bf16 == 3;
     D4_REQUIRE(e->nc >= 0 && e->nc <= 64, "num_continuous_actions out of range");
     e->A = 0;
     for (int a = 0; a < e->na; ++a) e->A += c.num_discrete_actions[a];
@@ -1415,7 +1488,9 @@ const char* d4_profile_glue_class_name(int c) { return d4::glue_class_name(c); }
 int d4_frame_fused_set(int mode) { return d4::frame_fused_set(mode); }
 
 int d4_gemm_force_config(int id) {
-    if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile configuration c of the split-operand fp32 family (gemm_x3.hip)
+    if (id >= 500 || id == -1) d4::gemm_bf16a_force_config(id >= 500 ? id - 500 : -1);    // 500 + c: tile configuration c of the bf16-activation kernel (gemm_bf16a.hip)
+    if (id >= 500) return d4::gemm_force_config(-1);
+    if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile c of the split-operand fp32 family (gemm_x3.hip); 400 + c: of the fp16x2 family (gemm_h2.hip)
     if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1);
     return d4::gemm_force_config(id >= 200 ? -1 : id);
 }
@@ -1480,6 +1555,23 @@ int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_str
         return d4::gemm_x3sk_launch(g, static_cast<hipStream_t>(stream), nullptr, nullptr, config == d4::gemm_x3_configs() ? 1 : 0);
     if (config >= 0) return d4::gemm_x3_launch(config, g, static_cast<hipStream_t>(stream));
     return d4::gemm_x3_launch(d4::gemm_x3_heuristic(g), g, static_cast<hipStream_t>(stream));
+}
+int d4_split_f16x2(const float* src, uint16_t* dst, int rows, int cols, int ld, int64_t plane_stride, float* inv_scale, void* stream) {
+    D4_REQUIRE(src && dst && inv_scale && rows >= 0 && cols >= 1 && ld >= cols && (ld % 8) == 0 && plane_stride >= (int64_t)rows * ld && (plane_stride % 8) == 0,
+               "d4_split_f16x2: bad arguments");
+    return d4::split_f16x2_rows(src, dst, rows, cols, ld, plane_stride, inv_scale, static_cast<hipStream_t>(stream));
+}
+int d4_row_scale_exp(const float* A, int64_t lda, int rows, int K, int32_t* exp_out, void* stream) {
+    D4_REQUIRE(A && exp_out && rows >= 0 && K >= 4 && lda >= K, "d4_row_scale_exp: bad arguments");
+    return d4::row_scale_exp(A, lda, rows, K, exp_out, static_cast<hipStream_t>(stream));
+}
+int d4_gemm_split2(const float* A, int lda, const uint16_t* W2, int64_t plane_stride, int ldw, const float* w_inv_scale, float* C, int ldc, const float* bias,
+                   const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, const int32_t* a_exp, void* stream) {
+    d4::GemmArgs g{A, lda, reinterpret_cast<const float*>(W2), ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.Wb = W2; g.wplane = plane_stride; g.wscale = w_inv_scale; g.aexp = a_exp;
+    D4_REQUIRE(d4::gemm_h2_applicable(g), "d4_gemm_split2: call not supported (M=%d N=%d K=%d flags=%d: K %% 32, lda %% 4, ldw %% 8, plane_stride %% 8, 16-byte alignment)", M, N, K, flags);
+    if (M == 0) return 0;
+    return d4::gemm_h2_launch(config >= 0 ? config : d4::gemm_h2_heuristic(g), g, static_cast<hipStream_t>(stream));
 }
 int d4_gemm_bf16(const float* A, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, const float* bias,
                  const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, void* stream) {

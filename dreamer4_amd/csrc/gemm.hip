@@ -442,8 +442,9 @@ static const char* const kTileKernel[N_TILE_CFG] = {
     "gemm_kernel<128, 128, 2, 4, 32, 1", "gemm_kernel<128, 128, 4, 2, 32, 1", "gemm_kernel<128, 96, 4, 1, 32, 1", "gemm_kernel<64, 128, 2, 2, 32, 1",
     "gemm_kernel<64, 64, 2, 2, 32, 1", "gemm_kernel<256, 128, 4, 4, 32, 1", "gemm_kernel<64, 128, 2, 2, 16, 1", "gemm_kernel<64, 64, 2, 2, 16, 1"};
 // profile classes: the N_TILE_CFG configurations of this family, then the configurations of the second family (gemm2.hip)
-int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 1; }     // + the persistent split-operand form (gemm_x3sk.hip)
+int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 2; }     // + the persistent split-operand form (gemm_x3sk.hip) + the fp16x2 family (gemm_h2.hip, one class)
 const char* gemm_profile_class_name(int c) {
+    if (c == N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 1) return "gemm_h2_kernel";
     if (c == N_TILE_CFG + gemm2_configs() + gemm_x3_configs()) return gemm_x3sk_name();
     if (c >= N_TILE_CFG + gemm2_configs()) return gemm_x3_config_name(c - N_TILE_CFG - gemm2_configs());
     if (c >= N_TILE_CFG) return gemm2_config_name(c - N_TILE_CFG);
@@ -516,7 +517,7 @@ struct TuneKey {
     int M, N, K, flags, batch;
     bool operator<(const TuneKey& o) const { return std::tie(M, N, K, flags, batch) < std::tie(o.M, o.N, o.K, o.flags, o.batch); }
 };
-static std::map<TuneKey, int> g_tuned, g_tuned2, g_tuned3;
+static std::map<TuneKey, int> g_tuned, g_tuned2, g_tuned3, g_tuned4;
 static int g_forced_cfg = -1;          // test hook (d4_gemm_force_config): run this configuration wherever it is valid;
                                        // 100 + c: configuration c of the second family (gemm2.hip)
 int gemm_force_config(int id) { g_forced_cfg = id; return N_TILE_CFG; }
@@ -537,6 +538,7 @@ static void tune_cache_read(const char* path) {
             if (id >= 0 && id < N_TILE_CFG) g_tuned[k] = id;
             else if (id >= 100 && id < 100 + gemm2_configs()) g_tuned2[k] = id - 100;      // second family (gemm2.hip)
             else if (id >= 300 && id < 300 + gemm_x3_configs()) g_tuned3[k] = id - 300;    // split-operand family (gemm_x3.hip)
+            else if (id >= 400 && id < 400 + gemm_h2_configs()) g_tuned4[k] = id - 400;    // fp16x2 split-operand family (gemm_h2.hip)
         }
         fclose(f);
     }
@@ -799,6 +801,87 @@ static int gemm_v3(const GemmArgs& p, hipStream_t stream) {
     return launch_v3(best, p, stream);
 }
 
+// ---- fp16x2 split-operand family (gemm_h2.hip; the opt-in `fp32_fp16x2` engine mode): launch with the optional event pair (ONE profile class for
+// all its tiles), timed choice among its tiles (every tile gives the same bits) ----
+static int launch_v4(int c, const GemmArgs& p, hipStream_t stream) {
+    const int cls = N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 1;
+    const bool timed = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
+    if (!timed) return gemm_h2_launch(c, p, stream);
+    ProfRec rec{};
+    rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.flags = p.flags; rec.batch = p.batch;
+    gemm_h2_config_tile(c, &rec.bm, &rec.bn);
+    rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
+    if (int rc = gemm_h2_launch(c, p, stream, rec.a, rec.b)) return rc;
+    g_prof.push_back(rec);
+    return 0;
+}
+
+static int autotune_v4(const GemmArgs& p, hipStream_t stream, int* best_out) {
+    hipEvent_t e0 = prof_event(), e1 = prof_event();
+    const int saved_mask = g_prof_mask;
+    g_prof_mask = 0;
+    int best = -1, rc = 0;
+    float best_ms = 0.f;
+    for (int c = 0; c < gemm_h2_configs() && !rc; ++c) {
+        if (!gemm_h2_config_valid(c, p)) continue;
+        if ((rc = gemm_h2_launch(c, p, stream))) break;
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2 && !rc; ++rep) {
+            (void)hipEventRecord(e0, stream);
+            if ((rc = gemm_h2_launch(c, p, stream))) break;
+            if ((rc = gemm_h2_launch(c, p, stream))) break;
+            (void)hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = 1; break; }
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            ms = t < ms ? t : ms;
+        }
+        if (!rc && (best < 0 || ms < best_ms)) { best = c; best_ms = ms; }
+    }
+    g_prof_mask = saved_mask;
+    g_event_pool.push_back(e0);
+    g_event_pool.push_back(e1);
+    if (rc) return rc;
+    D4_REQUIRE(best >= 0, "gemm_h2: no configuration for M=%d N=%d K=%d flags=%d", p.M, p.N, p.K, p.flags);
+    if (getenv("D4_GEMM_LOG"))
+        fprintf(stderr, "[d4 gemm_h2] tuned M %6d N %5d K %5d batch %2d flags %3d -> %s (%.1f us)\n", p.M, p.N, p.K, p.batch, p.flags, gemm_h2_config_name(best), 500.f * best_ms);
+    *best_out = best;
+    return 0;
+}
+
+static int gemm_v4(const GemmArgs& p, hipStream_t stream) {
+    const bool tune_on = tune_mode() != 0;
+    const int nb = p.batch > 0 ? p.batch : 1;
+    if (g_forced_cfg >= 400 && gemm_h2_config_valid(g_forced_cfg - 400, p)) return launch_v4(g_forced_cfg - 400, p, stream);
+    const TuneKey key{p.M, p.N, p.K, p.flags, p.batch};
+    tune_cache_load();
+    auto it = g_tuned4.find(key);
+    if (it != g_tuned4.end() && gemm_h2_config_valid(it->second, p)) return launch_v4(it->second, p, stream);
+    const bool idempotent = !(p.flags & GEMM_ACCUMULATE) && p.R != p.C && p.A != p.C;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
+        return launch_v4(gemm_h2_heuristic(p), p, stream);
+    D4_TUNE_STRICT_CHECK(p, nb);
+    int best = 0;
+    if (int rc = autotune_v4(p, stream, &best)) return rc;
+    g_tuned4[key] = best;
+    tune_cache_append(key, 400 + best);
+    return launch_v4(best, p, stream);
+}
+
+// Which calls of an fp16x2 engine the family takes is a RULE on the call's shape (never a timing): the families differ in their bits.  Measured on
+// MI355X (tools/gemm_h2_bench.py, profiles/r05c_*): x1.2-2.0 the f32-input MFMA kernels wherever a launch has a few hundred rows, N >= 256 and a k
+// loop of some length; level or behind on launches of under ~1.2 G multiply-adds (the 512 x 512 / 256 x 512 projections at 3584 rows) and at
+// K < 128; few-row calls stay on the few-row kernel.
+bool gemm_h2_takes(const GemmArgs& p) {
+    if (!p.Wb || p.wplane <= 0 || !p.wscale || !gemm_h2_applicable(p) || gemm_skinny_applicable(p)) return false;
+    if (g_forced_cfg >= 0 && g_forced_cfg < 400) return false;       // a forced tile of another family
+    if (g_forced_cfg >= 400) return true;
+    return p.M >= 256 && p.K >= 128 && p.N >= 64 && (double)p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1) >= 1.2e9;
+}
+
 // Two independent non-transposed fp32 GEMMs (the attention pool's query and key projections): ONE grid on the LDS-DMA family when both calls
 // would have run there anyway (same family, same k order, same bits as the two separate launches), else one after the other.  The tile
 // configuration is the one chosen for the larger problem.  D4_GEMM_PAIR=0 disables the grouping.
@@ -806,10 +889,11 @@ int gemm_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
     std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
     static const bool on = !(getenv("D4_GEMM_PAIR") && atoi(getenv("D4_GEMM_PAIR")) == 0);
     GemmArgs a = a_in, b = b_in;
-    const bool fp32_rule = (!a.Wb || (a.wplane > 0 && a.N < 2048)) && (!b.Wb || (b.wplane > 0 && b.N < 2048));     // neither goes to a bf16 / split-operand kernel
+    const bool fp32_rule = (!a.Wb || (a.wplane > 0 && a.N < 2048)) && (!b.Wb || (b.wplane > 0 && b.N < 2048)) &&     // neither goes to a bf16 / split-operand kernel
+                           !gemm_h2_takes(a) && !gemm_h2_takes(b);
     if (on && fp32_rule && g_forced_cfg < 0 && a.M > 0 && b.M > 0 && a.K == b.K && use_v2(a) && use_v2(b) && !gemm_skinny_applicable(a) &&
         !gemm_skinny_applicable(b) && gemm2_pair_applicable(a, b)) {
-        a.Wb = nullptr; a.wplane = 0; b.Wb = nullptr; b.wplane = 0;
+        a.Wb = nullptr; a.wplane = 0; a.wscale = nullptr; b.Wb = nullptr; b.wplane = 0; b.wscale = nullptr;
         const GemmArgs& big = (double)a.M * a.N >= (double)b.M * b.N ? a : b;
         tune_cache_load();
         auto it = g_tuned2.find(TuneKey{big.M, big.N, big.K, big.flags, big.batch});
@@ -849,6 +933,14 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(!((p.flags & GEMM_RMS_ROWSCALE) && ta), "gemm: rms rowscale needs a non-transposed A");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (p.N % 64) != 0), "gemm: swiglu needs N %% 64 == 0 (packed pairs)");
     D4_REQUIRE(!((p.flags & GEMM_SWIGLU) && (ta || tb)), "gemm: swiglu epilogue is forward-only");
+    // fp16x2 engine mode (two fp16 planes of W + row scales, gemm_h2.hip): the rule gemm_h2_takes names the calls; every other call drops the
+    // planes and runs on the f32-input kernels
+    if (p.Wb && p.wplane > 0 && p.wscale) {
+        if (gemm_h2_takes(p)) return gemm_v4(p, stream);
+        GemmArgs q = p;
+        q.Wb = nullptr; q.wplane = 0; q.wscale = nullptr; q.aexp = nullptr;
+        return gemm(q, stream);
+    }
     // split-operand fp32 (three bf16 planes of W): few-row calls stay on the few-row kernel (a rule on the shape, like every family choice)
     if (p.Wb && p.wplane > 0) {
         // Which calls take it is a RULE on the call's shape (never a timing).  Measured on MI355X (tools/gemm_x3_bench.py,

@@ -298,7 +298,7 @@ static int launch_bf16(const GemmArgs& p, hipStream_t stream) {
 }
 
 // bf16 activations + bf16 weights (gemm_bf16a.hip): tile by shape rule, with this file's optional per-launch event pair
-static int g_bf16a_forced = -1;          // test / microbenchmark hook (d4_gemm_force_config(400 + c))
+static int g_bf16a_forced = -1;          // test / microbenchmark hook (d4_gemm_force_config(500 + c); -1 resets)
 void gemm_bf16a_force_config(int id) { g_bf16a_forced = id; }
 int gemm_bf16a(const GemmArgs& p, hipStream_t stream) {
     D4_REQUIRE(gemm_bf16a_applicable(p), "gemm_bf16a: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);

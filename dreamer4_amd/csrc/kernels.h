@@ -39,6 +39,10 @@ struct GemmArgs {
                                        // ~32 tiles an XCD runs at a time share few operand panels (its 4 MB L2 then holds them); 0: row-major
     int64_t wplane = 0;                // > 0: Wb holds THREE bf16 planes (W = W1 + W2 + W3, plane stride in elements) and the call runs as
                                        // an fp32 GEMM on the bf16 matrix cores (split operands, six products: gemm_x3.hip)
+    const float* wscale = nullptr;     // set (with wplane > 0): Wb holds TWO fp16 planes of W scaled row by row (hi, lo 2^11) and wscale[n] = the exact
+                                       // power of two that undoes row n's scale -> fp32 GEMM on the fp16 matrix cores, three products (gemm_h2.hip)
+    int64_t strideWs = 0;              // ... batch stride of wscale (elements)
+    const int* aexp = nullptr;         // optional (gemm_h2.hip): scale exponent of every A row ([batch][M]) from a producer that knows it; null: the kernel finds it
 };
 
 int gemm(const GemmArgs& p, hipStream_t stream);
@@ -46,6 +50,7 @@ int gemm(const GemmArgs& p, hipStream_t stream);
 bool gemm_bf16_applicable(const GemmArgs& p);
 int gemm_bf16(const GemmArgs& p, hipStream_t stream);
 int gemm_bf16_force_config(int id);                          // test / microbenchmark hook; returns the number of configurations
+void gemm_bf16a_force_config(int id);                        // ... of the bf16-activation kernel (-1: by rule)
 int cvt_f32_to_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s);
 int cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, hipStream_t s);      // strided rows -> bf16
 int gemm_bf16a(const GemmArgs& p, hipStream_t stream);        // bf16 activations + bf16 weights: tile by rule, optional event pair (gemm_bf16.hip)
@@ -69,6 +74,17 @@ void gemm_x3_config_tile(int c, int* bm, int* bn);
 int gemm_x3_heuristic(const GemmArgs& p);
 int gemm_x3_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 int split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane, hipStream_t s);
+// fourth fp32 family (gemm_h2.hip): fp32 operands as two fp16 planes under exact power-of-two row scales, three fp16 MFMA products, fp32 accumulate
+bool gemm_h2_applicable(const GemmArgs& p);
+bool gemm_h2_config_valid(int c, const GemmArgs& p);
+int gemm_h2_configs();
+const char* gemm_h2_config_name(int c);
+void gemm_h2_config_tile(int c, int* bm, int* bn);
+int gemm_h2_heuristic(const GemmArgs& p);
+bool gemm_h2_takes(const GemmArgs& p);                     // the dispatcher's rule (gemm.hip): the calls of an fp16x2 engine that run on this family
+int gemm_h2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+int split_f16x2_rows(const float* src, uint16_t* dst, int rows, int cols, int ld, int64_t plane, float* inv_scale, hipStream_t s);
+int row_scale_exp(const float* A, int64_t lda, int rows, int K, int* out, hipStream_t s);      // GemmArgs::aexp of an activation matrix
 // persistent form of the 128 x 128 split-operand kernel (gemm_x3sk.hip): one workgroup per CU, the tiles of the last partial round cut along k
 bool gemm_x3sk_applicable(const GemmArgs& p);
 bool gemm_x3sk_rule(const GemmArgs& p);                    // the calls that take it (a rule on the shape and the CU count)

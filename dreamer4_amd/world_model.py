@@ -199,10 +199,15 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         #                     (csrc/gemm_x3.hip: fp32 accuracy — measured error against float64 below the f32-input MFMA kernels'),
         #                     everything else on the f32-input MFMA
         #   'fp32_mfma'       every GEMM on the f32-input MFMA (the round-1 arithmetic)
+        #   'fp32_fp16x2'     OPT-IN fast fp32-class mode (round 5, csrc/gemm_h2.hip): every operand row under an exact power-of-two scale as two
+        #                     fp16 planes (a 23-bit image), three fp16 MFMA products per fp32 product, fp32 accumulate.  On this model's dot products
+        #                     its error against float64 is BELOW the f32-input MFMA's (0.45x at K = 512) and the rollout is ~1.15x faster, but one
+        #                     product carries up to 2^-21 relative error where fp32 has 2^-24 — it fails the sharpest of the three criteria the
+        #                     default path is held to (profiles/r05_x3_products.txt), hence not the default
         #   'bf16'            bf16-rounded weights and activations on the bf16 MFMA, fp32 accumulation / norms / softmax / residual
         #                     stream (BASELINE config 5)
-        if matmul_dtype not in ('fp32', 'fp32_mfma', 'bf16'):
-            raise ValueError("matmul_dtype must be 'fp32', 'fp32_mfma' or 'bf16'")
+        if matmul_dtype not in ('fp32', 'fp32_mfma', 'fp32_fp16x2', 'bf16'):
+            raise ValueError("matmul_dtype must be 'fp32', 'fp32_mfma', 'fp32_fp16x2' or 'bf16'")
         self.matmul_dtype = matmul_dtype
         self.use_loss_normalization = bool(use_loss_normalization)
         # loss weights of the training forward's total (dreamer4.py:4719-4725, 5257-5267, 7708-7723): two plain floats and four persistent
@@ -481,7 +486,7 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
         c.head_mlp_recipe = MLP_RECIPES[self.head_mlp_recipe]
         c.continuous_beta_param = BETA_PARAMS[self.continuous_beta_param]
         c.reward_encoder_type = int(self.reward_encoder_type == 'symexp_two_hot')
-        c.matmul_bf16 = {'fp32': 2, 'fp32_mfma': 0, 'bf16': 1}[self.matmul_dtype]
+        c.matmul_bf16 = {'fp32': 2, 'fp32_mfma': 0, 'bf16': 1, 'fp32_fp16x2': 3}[self.matmul_dtype]
         c.pool_heads, c.pool_dim_head = self.pool_heads, self.pool_dim_head
         c.gae_discount_factor, c.gae_lambda, c.ppo_eps_clip = self.gae_discount_factor, self.gae_lambda, self.ppo_eps_clip
         c.policy_entropy_weight = self.policy_entropy_weight

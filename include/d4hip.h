@@ -58,7 +58,9 @@ typedef struct d4_config {
     int32_t matmul_bf16;                        /* trunk GEMM arithmetic.  0: fp32 on the f32-input MFMA; 2: fp32 on the bf16 matrix cores by operand
                                                    splitting (three bf16 planes per operand, six products, fp32 accumulate: fp32 accuracy,
                                                    csrc/gemm_x3.hip) — the Python mirror's default; 1: bf16 MFMA (bf16-rounded weights +
-                                                   activations, fp32 accumulate, fp32 norms / softmax / residual stream) */
+                                                   activations, fp32 accumulate, fp32 norms / softmax / residual stream); 3: opt-in fp32-class mode on
+                                                   the fp16 matrix cores (two fp16 planes per operand under exact row scales, three products:
+                                                   csrc/gemm_h2.hip, see d4_gemm_split2) */
     int32_t head_mlp_recipe;                    /* D4_MLP_PRE_RMS / D4_MLP_POST_LAYER: layer recipe of the policy / value / terminal MLPs (engine.h) */
     int32_t continuous_beta_param;              /* D4_BETA_SOFTPLUS_P1 / D4_BETA_EXP_P1: link of the Beta head's raw parameters (csrc/beta.h) */
     int32_t pool_heads, pool_dim_head;          /* AttentionPool defaults 4 x 64 (D4:2147-2148) */
@@ -252,7 +254,7 @@ const char* d4_profile_glue_class_name(int c);
 
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
- * split-operand fp32 family (gemm_x3.hip).
+ * split-operand fp32 family (gemm_x3.hip); 400 + c: tile c of the fp16x2 family (gemm_h2.hip); 500 + c: tile c of the bf16-activation kernel (gemm_bf16a.hip).
  * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
 /* Test hook for the per-frame fused block tails (csrc/frame_fused.hip; default from D4_FRAME_FUSED, 1): 0 separate kernels, 1 fused, 2 fused tails with the
  * pool mix as its own kernel.  Returns the previous mode.  Which path runs is otherwise a rule on the call's shape. */
@@ -306,6 +308,20 @@ int d4_cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, 
 int d4_split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane_stride, void* stream);
 int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_stride, int ldw, float* C, int ldc, const float* bias,
                   const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, void* stream);
+/* fp32-class GEMM on the fp16 matrix cores (csrc/gemm_h2.hip; round 5; the engine's OPT-IN `matmul_bf16 = 3` arithmetic for every nn.Linear of
+ * D4:1983-2068, 2105-2116, 2143-2210): each operand row is scaled by an exact power of two into fp16's range and written as two fp16 planes
+ * (hi, lo 2^11: a 23-bit image of the operand), a product is accumulated from its three leading fp16 x fp16 terms in fp32 and the scales are undone
+ * by one exponent shift.  Against float64 its error on dot products of >= 16 terms is BELOW the f32-input MFMA kernels' (0.45x at K = 512) at
+ * x1.2-2.0 their speed, but a single product carries a relative error of up to 2^-21 where fp32 has 2^-24: on operands spanning 2^120 inside a
+ * row (every output one product) it reads 5.5e-7 of sum |a w| against the f32-input MFMA's 3.1e-7 — which is why it is NOT the default fp32 path
+ * (profiles/r05_x3_products.txt).  d4_split_f16x2 writes the two planes of a weight matrix W [rows][ld] (dst[p * plane_stride + r * ld + c], p = 0..1;
+ * ld % 8 == 0, plane_stride % 8 == 0) and inv_scale[r] = the power of two that undoes row r's scale; d4_row_scale_exp the scale exponents of an
+ * activation matrix's rows (once for every GEMM that reads it); d4_gemm_split2 takes A in fp32 and splits it on the fly (a_exp null: the kernel
+ * finds the exponents itself, a pass over A per column tile).  `config` = -1: the family's static choice, 0..6 one tile (all give the same bits). */
+int d4_split_f16x2(const float* src, uint16_t* dst, int rows, int cols, int ld, int64_t plane_stride, float* inv_scale, void* stream);
+int d4_row_scale_exp(const float* A, int64_t lda, int rows, int K, int32_t* exp_out, void* stream);
+int d4_gemm_split2(const float* A, int lda, const uint16_t* W2, int64_t plane_stride, int ldw, const float* w_inv_scale, float* C, int ldc, const float* bias,
+                   const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, const int32_t* a_exp, void* stream);
 /* ---- trunk backward, first slice (SURVEY.md 8f-3 groundwork; not on the imagination path) ----
  * FeedForward block (dreamer4.py:2079-2116) on the reference parameter layout: y = proj_out(a * silu(g)) with [a | g] = proj_in(RMSNorm(x));
  * x / y / dy / dx [rows][dim], norm_w [dim], w_in [2*inner][dim], b_in [2*inner], w_out [dim][inner], b_out [dim].  The backward
