@@ -261,6 +261,31 @@ def cfg5_bf16(device, lib, B=128, frames=16, reps=2):
                               avg_launch_us=round(1e3 * ms.value / max(cnt.value, 1), 2)))
 
 
+def cfg2_fp16x2_mode(device, reps=3):
+    """Secondary: the headline rollout (cfg 2, B = 256, 16 frames) in the OPT-IN matmul_dtype='fp32_fp16x2' mode (csrc/gemm_h2.hip: trunk GEMMs of >= 1.2 G
+    multiply-adds on the fp16 matrix cores — two fp16 planes per operand under exact row scales, three products, fp32 accumulate).  NOT what `value` is
+    measured on: the scheme fails the sharpest of the three fp32 criteria the default path is held to (profiles/r05_x3_products.txt)."""
+    from dreamer4_amd import DynamicsWorldModel
+    from dreamer4_amd.synthetic import randomize_weights
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG2, matmul_dtype='fp32_fp16x2'), seed=0, terminal_bias=-10.).to(device)
+    g = torch.Generator(device=device).manual_seed(1234)
+    gk = dict(return_for_policy_optimization=True, num_steps=NUM_STEPS, generator=g)
+    for _ in range(2):
+        m.generate(HORIZON + 1, batch_size=B_LOCAL, **gk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e = m.generate(HORIZON + 1, batch_size=B_LOCAL, **gk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(rollout_steps_per_sec=round(B_LOCAL * e.latents.shape[1] / dt, 1), generate_ms=round(1e3 * dt, 2),
+                dtype='fp32-class on the fp16 MFMA: 23-bit operand images (two fp16 planes, exact power-of-two row scales), three products, fp32 accumulate',
+                note='opt-in mode, not the default and not `value`: error vs float64 0.45x the f32-input MFMA on this model\'s dot products, but single products carry up '
+                     'to 2^-21 relative error (fp32: 2^-24) - it fails the wide-exponent criterion of tests/test_gpu_kernels.py (profiles/r05_x3_products.txt)',
+                workload=f'cfg2 rollout only: B={B_LOCAL}, H={HORIZON}, num_steps={NUM_STEPS}')
+
+
 def cfg5_cpu_baseline(max_threads=16, budget_s=25.):
     """The CPU oracle at config 5's architecture (dim 1024, depth 12, 6 Beta actions; torch fp32 on the host), rank 0 at N = 1 only: a BOUNDED
     SAMPLE of the workload — the full one (B = 128, 16 frames: 69 TFLOP) would take minutes on the host — sized by a short probe to about `budget_s`."""
@@ -513,7 +538,7 @@ def main():
         del trainer, model
         torch.cuda.empty_cache()
         for key, fn in (('cfg4_env_step', lambda: cfg4_env_latency(device)), ('cfg5_bf16', lambda: cfg5_bf16(device, lib)),
-                        ('train_flow_step', lambda: train_flow_step(device))):
+                        ('train_flow_step', lambda: train_flow_step(device)), ('cfg2_fp16x2_mode', lambda: cfg2_fp16x2_mode(device))):
             try:                                      # a failing secondary measurement must not cost the headline line
                 out[key] = fn()
             except Exception as exc:                  # noqa: BLE001
