@@ -117,6 +117,7 @@ SYMBOLS = {
     'd4_profile_read': (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
     'd4_profile_classes': (_I, []),
     'd4_gemm_force_config': (_I, [_I]),
+    'd4_debug_switch': (_I, [C.c_char_p, _I]),
     'd4_frame_fused_set': (_I, [_I]),
     'd4_profile_class_name': (C.c_char_p, [_I]),
     'd4_profile_glue_enable': (_I, [_I]),

@@ -385,10 +385,9 @@ static int small_attn_impl(const SmallAttnArgs& p, hipStream_t stream, bool* wro
         // algorithmic bytes: q, k, v (+ value residual) rows of every (frame, head) read once, the kept query rows written once
         const int nq_out = p.q_hi > 0 ? (p.q_hi - p.q_lo + p.q_last) : p.nq;
         const double sp_bytes = 4.0 * p.groups * p.heads * (p.dh * ((double)p.nk * (p.vres ? 4 : 3) + nq_out) + 2.0 * p.nk);
-        // head dim 64 with 16-byte aligned rows: one wave per (frame, head) on the matrix pipe (D4_SPACE_ATTN_MFMA=0: the LDS-staged VALU form)
-        static const bool mfma_on = !(getenv("D4_SPACE_ATTN_MFMA") && atoi(getenv("D4_SPACE_ATTN_MFMA")) == 0);
+        // head dim 64 with 16-byte aligned rows: one wave per (frame, head) on the matrix pipe (else the LDS-staged VALU form)
         auto al4 = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
-        const bool mfma_ok = mfma_on && p.dh == 64 && al4(p.q, p.q_group_stride, p.q_item_stride) && al4(p.k, p.k_group_stride, p.k_item_stride) &&
+        const bool mfma_ok = p.dh == 64 && al4(p.q, p.q_group_stride, p.q_item_stride) && al4(p.k, p.k_group_stride, p.k_item_stride) &&
                              al4(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4(p.vres, p.r_group_stride, p.r_item_stride)) &&
                              ((uintptr_t)p.k_gamma % 16) == 0;
         *wrote_b = mfma_ok;
@@ -400,9 +399,8 @@ static int small_attn_impl(const SmallAttnArgs& p, hipStream_t stream, bool* wro
         return 0;
     }
     // algorithmic bytes: a batch-independent operand (group stride 0) is counted once
-    static const bool mfma_small_on = !(getenv("D4_SPACE_ATTN_MFMA") && atoi(getenv("D4_SPACE_ATTN_MFMA")) == 0);
     auto al4s = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
-    const bool mfma_small = mfma_small_on && p.dh == 64 && p.nq <= 64 && p.nk <= 64 && (p.nq <= 16 || p.nk <= 16) && p.q_hi == 0 &&
+    const bool mfma_small = p.dh == 64 && p.nq <= 64 && p.nk <= 64 && (p.nq <= 16 || p.nk <= 16) && p.q_hi == 0 &&
                             al4s(p.q, p.q_group_stride, p.q_item_stride) && al4s(p.k, p.k_group_stride, p.k_item_stride) &&
                             al4s(p.v, p.v_group_stride, p.v_item_stride) && (!p.vres || al4s(p.vres, p.r_group_stride, p.r_item_stride)) &&
                             ((uintptr_t)p.k_gamma % 16) == 0;
@@ -622,11 +620,10 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.L >= 1 && p.L <= 64 && p.D % 4 == 0 && p.D <= 1024, "pool_mix: L=%d D=%d out of range", p.L, p.D);
     if (p.M == 0) return 0;
     dim3 grid(cdiv(p.M, 4)), block(256);
-    static const bool rows_on = !(getenv("D4_POOL_MIX_ROWS") && atoi(getenv("D4_POOL_MIX_ROWS")) == 0);
     // one block per row (its four waves split the hiddens) while that leaves the CUs short of waves — by M alone: measured at B = 256, L = 13:
     // M = 1280 (the final stage's compacted rows) 24.1 -> 14.3 us, M = 3584 25.3 -> 27.8 us (the wave-per-row form wins once it fills the chip)
-    static const int rows_max = getenv("D4_POOL_MIX_ROWS_MAX") ? atoi(getenv("D4_POOL_MIX_ROWS_MAX")) : 2048;
-    if (p.M <= rows_max && p.D <= 512 && rows_on) {
+    constexpr int rows_max = 2048;
+    if (p.M <= rows_max && p.D <= 512) {
         const double rb = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
         if (p.D <= 256) hipLaunchKernelGGL(pool_mix_rows_kernel<1>, dim3(p.M), block, 0, stream, p);
         else D4_GLUE_LAUNCH(GL_POOL_MIX, rb, pool_mix_rows_kernel<2>, dim3(p.M), block, 0, stream, p);
@@ -1044,10 +1041,9 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
     if (waves == 0) return 0;
     // algorithmic bytes: k, v, value residual read from the projection rows; K and V written into the cache
     const double ka_bytes = 4.0 * waves * p.dh * 5.0;
-    static const bool one_head = getenv("D4_KV_APPEND_LEGACY") != nullptr;         // the one-head-per-wave form
     const bool al4 = (p.ldp % 4) == 0 && (p.ldv % 4) == 0 && ((uintptr_t)p.proj % 16) == 0 && ((uintptr_t)p.vres % 16) == 0 && ((uintptr_t)p.cache % 16) == 0 &&
                      ((uintptr_t)p.k_gamma % 16) == 0 && ((uintptr_t)p.inv_freq % 16) == 0 && (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
-    if (p.dh == 64 && (p.H % 4) == 0 && al4 && !one_head)
+    if (p.dh == 64 && (p.H % 4) == 0 && al4)               // four heads per wave; else the one-head-per-wave form
         D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append4_kernel, dim3(cdiv(waves / 4, 4)), dim3(256), 0, stream, p);
     else if (p.dh == 64) D4_GLUE_LAUNCH(GL_TIME_KV_APPEND, ka_bytes, time_kv_append_kernel<64>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
     else if (p.dh == 32) hipLaunchKernelGGL(time_kv_append_kernel<32>, dim3(cdiv(waves, 4)), dim3(256), 0, stream, p);
@@ -1059,14 +1055,13 @@ int time_kv_append(const TimeAttnArgs& p, hipStream_t stream) {
 // Cached decode of ONE frame (Tq == 1): append + attend in one launch — every (column, head) computes its own new K / V row, stores it and
 // attends over its history with the new row taken from registers.  Same arithmetic and kernel choice (history bucket) as the two launches;
 // anything the fused forms do not cover (several frames per pass, head dims 16 / 32, unaligned rows) runs as the two launches.
+int g_time_attn_fused_append = 1;
 int time_attn_append(const TimeAttnArgs& p, hipStream_t stream) {
-    const char* fa = getenv("D4_TIME_ATTN_FUSED_APPEND");          // (read per call: the A/B test flips it inside one process)
-    const bool fused_on = !(fa && atoi(fa) == 0);
-    static const bool legacy = getenv("D4_TIME_ATTN_LEGACY") != nullptr || getenv("D4_KV_APPEND_LEGACY") != nullptr;
+    const bool fused_on = g_time_attn_fused_append != 0;           // (test hook d4_debug_switch("time_attn_fused_append"): the bitwise A/B of the two forms)
     auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     const bool al4 = (p.ldp % 4) == 0 && (p.ldv % 4) == 0 && (p.ldo % 4) == 0 && al(p.proj) && al(p.vres) && al(p.cache) && al(p.out) && al(p.k_gamma) && al(p.inv_freq) &&
                      (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
-    if (!(fused_on && !legacy && p.Tq == 1 && p.dh == 64 && al4)) {
+    if (!(fused_on && p.Tq == 1 && p.dh == 64 && al4)) {
         if (int rc = time_kv_append(p, stream)) return rc;
         return time_attn(p, stream);
     }
@@ -1075,11 +1070,10 @@ int time_attn_append(const TimeAttnArgs& p, hipStream_t stream) {
     if (units == 0) return 0;
     // algorithmic bytes: the append's (k, v, value residual read; K, V written) + the attention's (history K / V, q read, out written)
     const double bytes = 4.0 * units * 64.0 * 5.0 + 4.0 * units * 64.0 * (2.0 * (p.t0 + 1) + 2.0);
-    static const bool no_few = getenv("D4_TIME_ATTN_FEW") && atoi(getenv("D4_TIME_ATTN_FEW")) == 0;
     const int bucket = time_history_bucket(p.t0);
-    if (bucket == 0 && (p.H % 4) == 0 && !no_few)
+    if (bucket == 0 && (p.H % 4) == 0)
         D4_GLUE_LAUNCH(GL_TIME_ATTN, bytes, (time_attn64_few_kernel<8, true>), dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
-    else if (bucket == 1 && (p.H % 4) == 0 && !no_few)
+    else if (bucket == 1 && (p.H % 4) == 0)
         D4_GLUE_LAUNCH(GL_TIME_ATTN, bytes, (time_attn64_few_kernel<16, true>), dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
     else D4_GLUE_LAUNCH(GL_TIME_ATTN, bytes, (time_attn64_kernel<false, true>), dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
     D4_LAUNCH_CHECK();
@@ -1089,18 +1083,16 @@ int time_attn_append(const TimeAttnArgs& p, hipStream_t stream) {
 int time_attn(const TimeAttnArgs& p, hipStream_t stream) {
     const int waves = p.B * p.Tq * p.S * p.H;
     if (waves == 0) return 0;
-    static const bool legacy = getenv("D4_TIME_ATTN_LEGACY") != nullptr;       // the one-key-per-reduction form (kept for head dims 16 / 32)
-    if (p.dh == 64 && !legacy && (p.ldp % 4) == 0 && (p.ldo % 4) == 0) {
+    if (p.dh == 64 && (p.ldp % 4) == 0 && (p.ldo % 4) == 0) {         // (else the one-key-per-reduction form: head dims 16 / 32, unaligned rows)
         const int units = p.B * p.S * p.H;
         // algorithmic bytes (cached decode): the K and V of frames 0..t0 of every (column, head) read once + q read + out written
         const double ta_bytes = 4.0 * units * 64.0 * (2.0 * (p.t0 + 1) + 2.0);
-        static const bool no_few = getenv("D4_TIME_ATTN_FEW") && atoi(getenv("D4_TIME_ATTN_FEW")) == 0;
         const bool al4 = ((uintptr_t)p.proj % 16) == 0 && ((uintptr_t)p.cache % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.inv_freq % 16) == 0 &&
                          (((int64_t)p.cache_batch * (p.cache_S > 0 ? p.cache_S : p.S) * p.H * p.Tcap) % 4) == 0;
         const int bucket = time_history_bucket(p.t0);                           // the same rule eagerly and under graph replay (graphs are keyed on it)
-        if (p.Tq == 1 && bucket == 0 && (p.H % 4) == 0 && al4 && !no_few)           // a short history: four heads per wave
+        if (p.Tq == 1 && bucket == 0 && (p.H % 4) == 0 && al4)           // a short history: four heads per wave
             D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel<8>, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
-        else if (p.Tq == 1 && bucket == 1 && (p.H % 4) == 0 && al4 && !no_few)
+        else if (p.Tq == 1 && bucket == 1 && (p.H % 4) == 0 && al4)
             D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_few_kernel<16>, dim3(cdiv(units / 4, 4)), dim3(256), 0, stream, p);
         else if (p.Tq == 1) D4_GLUE_LAUNCH(GL_TIME_ATTN, ta_bytes, time_attn64_kernel<false>, dim3(cdiv(units, 4)), dim3(256), 0, stream, p);
         else {

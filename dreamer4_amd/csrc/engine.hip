@@ -131,10 +131,9 @@ int engine_layout(d4_engine* e, bool assign) {
     }
     e->shadows.clear();
     if (e->bf16 && !e->fp32_planes() && !e->decoder && !e->encoder) {
-        static const bool shadows_on = !(getenv("D4_BF16_ACT") && atoi(getenv("D4_BF16_ACT")) == 0);       // 0: fp32 activations into every bf16 GEMM (the round-2 form)
         auto sh = [&](const float* src, size_t n, bool only) {
             uint16_t* dst = reinterpret_cast<uint16_t*>(alloc_bytes(n * sizeof(uint16_t)));
-            if (shadows_on) e->shadows.push_back({src, n, dst, only});
+            e->shadows.push_back({src, n, dst, only});
         };
         sh(e->slabs, (size_t)e->nslab * M * D, false);
         sh(e->xpool, M * D, false);
@@ -529,8 +528,7 @@ static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
                 g->Ab = e->shadow_of(g->A);
                 ok = ok && g->Wb && g->Ab;
             }
-            static const bool pair_on = !(getenv("D4_BF16A_PAIR") && atoi(getenv("D4_BF16A_PAIR")) == 0);
-            if (ok && pair_on && gemm_bf16a_pair_applicable(pa, pb)) return gemm_bf16a_pair(pa, pb, s);
+            if (ok && gemm_bf16a_pair_applicable(pa, pb)) return gemm_bf16a_pair(pa, pb, s);
         }
     }
     int rc;
@@ -721,7 +719,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         if (t_bf16 && D > 512) pm.hid_b = t_bf16->shadow_of(hiddens);     // (D <= 512 may take the block-per-row form, which reads fp32)
         if (t_bf16) if (uint16_t* ub = t_bf16->shadow_of(e->pool_u)) { pm.u_b = ub; if (t_bf16->shadow_only(e->pool_u)) pm.u = nullptr; }   // only the value GEMM reads the mixes
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
-        // D4_FRAME_FUSED=2: the mix stays its own kernel and only the tail is fused
+        // frame_fused mode 2 (test hook): the mix stays its own kernel and only the tail is fused
         if (S > 0 && M % S == 0 && !e->pv_t.empty() && (!t_bf16 || t_bf16->fp32_planes()) && frame_pool_tail_applicable(M / S, S, D, c.pool_heads)) {
             const bool tail_only = frame_fused_mode() == 2;
             if (!tail_only) return frame_pool(pm, e->pv_t[p], e->po_t[p], M / S, S, x, D, y, D, y_compact, D, e->keep_lo, e->keep_hi, has_agent, s);
@@ -1487,6 +1485,15 @@ int d4_profile_glue_read_flops(double* flops, int nclass) { return d4::glue_prof
 const char* d4_profile_glue_class_name(int c) { return d4::glue_class_name(c); }
 int d4_frame_fused_set(int mode) { return d4::frame_fused_set(mode); }
 
+int d4_debug_switch(const char* name, int value) {
+    int* sw = nullptr;
+    if (name && !strcmp(name, "time_attn_fused_append")) sw = &d4::g_time_attn_fused_append;
+    else if (name && !strcmp(name, "attn_out_cols")) sw = &d4::g_attn_out_cols;
+    if (!sw) return -1;
+    const int old = *sw;
+    *sw = value;
+    return old;
+}
 int d4_gemm_force_config(int id) {
     if (id >= 500 || id == -1) d4::gemm_bf16a_force_config(id >= 500 ? id - 500 : -1);    // 500 + c: tile configuration c of the bf16-activation kernel (gemm_bf16a.hip)
     if (id >= 500) return d4::gemm_force_config(-1);

@@ -302,11 +302,9 @@ __global__ __launch_bounds__(AOC_NW * 64) void attn_out_cols_kernel(SmallAttnArg
 }
 
 // ---- launchers --------------------------------------------------------------------------------------------------
-static int g_frame_fused = -1;         // -1: from the environment (D4_FRAME_FUSED, default 1); 0 off; 1 on; 2 tails only (the pool mix stays its own kernel)
-int frame_fused_mode() {
-    if (g_frame_fused < 0) g_frame_fused = getenv("D4_FRAME_FUSED") ? atoi(getenv("D4_FRAME_FUSED")) : 1;
-    return g_frame_fused;
-}
+static int g_frame_fused = 1;          // 0 off; 1 on (default); 2 tails only (the pool mix stays its own kernel) — test hook d4_frame_fused_set
+int g_attn_out_cols = 1;               // test hook d4_debug_switch("attn_out_cols"): 0 keeps attention and out-projection as two launches at <= 4 frames
+int frame_fused_mode() { return g_frame_fused; }
 int frame_fused_set(int mode) { const int old = frame_fused_mode(); g_frame_fused = mode; return old; }
 static bool frame_fused_on() { return frame_fused_mode() != 0; }
 
@@ -344,8 +342,7 @@ int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const floa
 // BASELINE config 4): B = 1 1.73 -> 1.69 ms per env step, but B = 16 2.79 -> 2.87 ms: 16 frames x 32 column workgroups each recomputing a frame's
 // attention cost more than the launch they save
 bool attn_out_cols_applicable(const SmallAttnArgs& sa, int D) {
-    const char* ev = getenv("D4_ATTN_OUT_COLS");                  // (read per call: the A/B test flips it inside one process)
-    const bool on = !(ev && atoi(ev) == 0);
+    const bool on = g_attn_out_cols != 0;
     auto al4 = [](const void* q, int64_t a, int64_t b) { return ((uintptr_t)q % 16) == 0 && (a % 4) == 0 && (b % 4) == 0; };
     return on && frame_fused_on() && sa.groups >= 1 && sa.groups <= 4 && sa.dh == 64 && sa.heads == 8 && sa.nq == sa.nk && sa.nk >= 1 && sa.nk <= 16 && sa.q_hi == 0 &&
            D % 16 == 0 && !sa.out_b &&

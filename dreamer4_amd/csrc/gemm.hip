@@ -692,11 +692,8 @@ static int autotune_v2(const GemmArgs& p, hipStream_t stream, int* best_out) {
 }
 
 // Which family runs a call is a RULE on the call's shape / layout (never a timing): the two families sum k in different orders,
-// so a timing-dependent choice between them would make results depend on the tuner.  D4_GEMM_V2=0 disables the second family.
-static bool use_v2(const GemmArgs& p) {
-    static const bool on = !(getenv("D4_GEMM_V2") && atoi(getenv("D4_GEMM_V2")) == 0);
-    return on && gemm2_applicable(p);
-}
+// so a timing-dependent choice between them would make results depend on the tuner.
+static bool use_v2(const GemmArgs& p) { return gemm2_applicable(p); }
 
 static int gemm_v2(const GemmArgs& p, hipStream_t stream) {
     const bool tune_on = tune_mode() != 0;
@@ -884,14 +881,13 @@ bool gemm_h2_takes(const GemmArgs& p) {
 
 // Two independent non-transposed fp32 GEMMs (the attention pool's query and key projections): ONE grid on the LDS-DMA family when both calls
 // would have run there anyway (same family, same k order, same bits as the two separate launches), else one after the other.  The tile
-// configuration is the one chosen for the larger problem.  D4_GEMM_PAIR=0 disables the grouping.
+// configuration is the one chosen for the larger problem.
 int gemm_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
     std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
-    static const bool on = !(getenv("D4_GEMM_PAIR") && atoi(getenv("D4_GEMM_PAIR")) == 0);
     GemmArgs a = a_in, b = b_in;
     const bool fp32_rule = (!a.Wb || (a.wplane > 0 && a.N < 2048)) && (!b.Wb || (b.wplane > 0 && b.N < 2048)) &&     // neither goes to a bf16 / split-operand kernel
                            !gemm_h2_takes(a) && !gemm_h2_takes(b);
-    if (on && fp32_rule && g_forced_cfg < 0 && a.M > 0 && b.M > 0 && a.K == b.K && use_v2(a) && use_v2(b) && !gemm_skinny_applicable(a) &&
+    if (fp32_rule && g_forced_cfg < 0 && a.M > 0 && b.M > 0 && a.K == b.K && use_v2(a) && use_v2(b) && !gemm_skinny_applicable(a) &&
         !gemm_skinny_applicable(b) && gemm2_pair_applicable(a, b)) {
         a.Wb = nullptr; a.wplane = 0; a.wscale = nullptr; b.Wb = nullptr; b.wplane = 0; b.wscale = nullptr;
         const GemmArgs& big = (double)a.M * a.N >= (double)b.M * b.N ? a : b;
@@ -946,24 +942,13 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
         // Which calls take it is a RULE on the call's shape (never a timing).  Measured on MI355X (tools/gemm_x3_bench.py,
         // profiles/r02_gemm_split_operands.txt): it wins where a launch has enough wide tiles to hide its heavier staging — the SiLU-GLU
         // input projections (N = 2 x 1376 ... 5504: 1.2-1.35x the f32-input MFMA kernels) and other N >= 2048 projections (level to 1.3x) —
-        // and loses on the N <= 1552 shapes (0.8-0.95x).  D4_GEMM_X3 = 0: never, 2: every applicable call (experiments).
-        static const int mode = getenv("D4_GEMM_X3") ? atoi(getenv("D4_GEMM_X3")) : 1;
-        // Round 3, late: the persistent form (gemm_x3sk.hip) runs the whole rounds of a launch as before and a last round that is at most
-        // half full as 128 x 64 half tiles (bit-identical; nothing crosses between workgroups).  gemm_x3sk_rule names the calls: at cfg 2
-        // the SiLU-GLU input projection of the denoising evaluations (616 tiles = 2 rounds + 104).  D4_GEMM_X3SK=0: never.
-        // Every split-operand call of >= 1024 rows runs on the persistent form (default 2; 1 = only the calls whose last round becomes half tiles):
-        // same-box A/B pairs (profiles/r03l_ab_late_changes.txt) put the step at 188.8 / 191.8-192.4 / 199.3-200.0 ms for 2 / 1 / 0 on a mid-speed box
-        // and 181.1-181.6 / 180.2-180.4 / 180.0 ms on the fastest one seen — the balanced end of a persistent launch is what the FOLLOWING kernels gain from.
-        static const int sk_mode = getenv("D4_GEMM_X3SK") ? atoi(getenv("D4_GEMM_X3SK")) : 2;
-        const bool sk_on = sk_mode != 0;
-        if (sk_on && mode >= 1 && g_forced_cfg < 0 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p) &&
-            (gemm_x3sk_rule(p) || (sk_mode == 2 && gemm_x3sk_applicable(p) && p.M >= 1024)))
-            return launch_v3sk(p, stream);
-        // 3 (experiment): also the long-K output projections (SiLU-GLU output: N = 512, K = 1376) as half tiles on 224 CUs
-        if (sk_mode == 3 && g_forced_cfg < 0 && p.K >= 1024 && p.N >= 512 && p.M >= 2048 && !gemm_skinny_applicable(p) && gemm_x3sk_applicable(p))
-            return launch_v3sk(p, stream);
-        const bool preferred = mode >= 2 || (mode == 1 && ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && p.M >= 256);
-        if (preferred && gemm_x3_applicable(p) && !gemm_skinny_applicable(p)) return gemm_v3(p, stream);
+        // and loses on the N <= 1552 shapes (0.8-0.95x; with the whole rollout as the clock +3 .. +6 ms: profiles/r05b_x3_every_call_ab.txt).
+        // Every such call of >= 1024 rows runs on the PERSISTENT form (gemm_x3sk.hip: whole rounds as plain tiles, a last round that is at most
+        // half full as 128 x 64 half tiles — bit-identical to the plain kernel; same-box A/B pairs, profiles/r03l_ab_late_changes.txt: 188.8 vs
+        // 191.8-192.4 (half-tile calls only) vs 199.3-200.0 ms (never) per step on a mid-speed box, level on the fastest one).
+        const bool wide = ((p.flags & GEMM_SWIGLU) || p.N >= 2048) && !gemm_skinny_applicable(p);
+        if (wide && g_forced_cfg < 0 && (gemm_x3sk_rule(p) || (gemm_x3sk_applicable(p) && p.M >= 1024))) return launch_v3sk(p, stream);
+        if (wide && p.M >= 256 && gemm_x3_applicable(p)) return gemm_v3(p, stream);
         GemmArgs q = p;
         q.Wb = nullptr; q.wplane = 0;
         return gemm(q, stream);

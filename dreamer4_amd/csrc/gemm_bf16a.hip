@@ -398,8 +398,7 @@ static int launch_va(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEv
             const long cost = (long)gm * BM + (long)(cols < nbn ? cols : nbn) * BN;
             if (best_cost < 0 || cost < best_cost) { best = gm; best_cost = cost; }
         }
-        static const bool grouped = !(getenv("D4_BF16A_GROUPED") && atoi(getenv("D4_BF16A_GROUPED")) == 0);
-        q.group_m = grouped ? best : 0;
+        q.group_m = best;
     } else if (q.group_m < 0) q.group_m = 0;
     if (ea) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)lds, stream, ea, eb, 0, q);
     else hipLaunchKernelGGL(k, grid, block, lds, stream, q);

@@ -157,14 +157,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_pair_kernel(GemmArgs a, G
     }
 }
 
-// Few rows: M <= D4_SKINNY_MAXM (default 32) rows, or the tiled kernel would have fewer than 64 tiles of 64 x 64 (a quarter of the
-// CUs) to work with.  By shape only, never by timing.
+// Few rows: M <= 32 rows, or the tiled kernel would have fewer than 64 tiles of 64 x 64 (a quarter of the CUs) to work with.  By shape only,
+// never by timing.
 bool gemm_skinny_applicable(const GemmArgs& p) {
-    static const bool on = !(getenv("D4_GEMM_SKINNY") && atoi(getenv("D4_GEMM_SKINNY")) == 0);
-    static const int max_tiles = getenv("D4_SKINNY_TILES") ? atoi(getenv("D4_SKINNY_TILES")) : 64;
-    static const int max_m = getenv("D4_SKINNY_MAXM") ? atoi(getenv("D4_SKINNY_MAXM")) : 32;
+    constexpr int max_tiles = 64, max_m = 32;
     const bool few = p.M <= max_m || (int64_t)cdiv(p.M, 64) * cdiv(p.N, 64) * (p.batch > 0 ? p.batch : 1) < max_tiles;
-    return on && p.M >= 1 && p.M <= 256 && few &&
+    return p.M >= 1 && p.M <= 256 && few &&
            !(p.flags & (GEMM_TRANS_A | GEMM_TRANS_B)) && (p.K % 4) == 0 && (p.C2 == nullptr || p.batch <= 1);
 }
 
@@ -178,16 +176,13 @@ static int launch_skinny(const GemmArgs& p, hipStream_t stream) {
 
 // waves per block from K: one round of <= 4 (6) load steps per wave up to K = 1024 (1536)
 static void skinny_shape(int K, int& nw, bool& u6) {
-    static const int force_nw = getenv("D4_SKINNY_NW") ? atoi(getenv("D4_SKINNY_NW")) : 0;          // experiments only
     const int steps = (K + 15) >> 4;
     nw = steps <= 16 ? 4 : (steps <= 32 ? 8 : 16);
-    if (force_nw) nw = force_nw;
     u6 = nw == 16 && steps > 64 && steps <= 96;
 }
 
 bool gemm_skinny_pair_applicable(const GemmArgs& a, const GemmArgs& b) {
-    static const bool on = !(getenv("D4_SKINNY_PAIR") && atoi(getenv("D4_SKINNY_PAIR")) == 0);
-    return on && gemm_skinny_applicable(a) && gemm_skinny_applicable(b) && a.K == b.K && !((a.flags | b.flags) & GEMM_SWIGLU) &&
+    return gemm_skinny_applicable(a) && gemm_skinny_applicable(b) && a.K == b.K && !((a.flags | b.flags) & GEMM_SWIGLU) &&
            a.batch <= 1 && b.batch <= 1 && a.Wb == nullptr && b.Wb == nullptr;
 }
 

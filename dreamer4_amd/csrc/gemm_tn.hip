@@ -134,8 +134,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 bool gemm_tn_applicable(const float* A, int lda, const float* B, int ldb, const float* C, int ldc, int M, int N, int K) {
-    static const bool on = !(getenv("D4_GEMM_TN") && atoi(getenv("D4_GEMM_TN")) == 0);
-    return on && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && M >= 4 && N >= 4 && K >= 1 &&
+    return M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && M >= 4 && N >= 4 && K >= 1 &&
            (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
 }
 
@@ -193,8 +192,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 int gemm_dx(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K, float* wt, hipStream_t s) {
-    static const bool on = !(getenv("D4_GEMM_DX_T") && atoi(getenv("D4_GEMM_DX_T")) == 0);
-    if (!on || !wt || K % 32 != 0 || ldy % 4 != 0 || M < 256) { GemmArgs g{dY, ldy, W, ldw, dX, ldx, nullptr, nullptr, 0, M, N, K, GEMM_TRANS_B, 0.f}; return gemm(g, s); }
+    if (!wt || K % 32 != 0 || ldy % 4 != 0 || M < 256) { GemmArgs g{dY, ldy, W, ldw, dX, ldx, nullptr, nullptr, 0, M, N, K, GEMM_TRANS_B, 0.f}; return gemm(g, s); }
     hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, W, ldw, wt, K, K, N);
     D4_LAUNCH_CHECK();
     GemmArgs g{dY, ldy, wt, K, dX, ldx, nullptr, nullptr, 0, M, N, K, 0, 0.f};

@@ -22,7 +22,7 @@
 // dispatched in index order: no residency assumption, no deadlock.  The wait is bounded all the same (a lost counter poisons the tile
 // with NaN instead of hanging the queue).  The fix-up clears the counter it consumed: a launch leaves the counters zero.
 //
-// IN THE ENGINE every split-operand call of >= 1024 rows runs here (gemm.hip; D4_GEMM_X3SK): whole tiles walked by 256 long-lived workgroups are
+// IN THE ENGINE every split-operand call of >= 1024 rows runs here (gemm.hip): whole tiles walked by 256 long-lived workgroups are
 // bit-identical to gemm_x3_kernel and, measured in situ on mid-speed boxes, leave the FOLLOWING kernels ~3-4 % faster than 476-660 short-lived
 // 120 KB workgroups do (profiles/r03l_ab_late_changes.txt: 188 / 191 / 199 ms per step for all calls / half-tile calls only / none).
 //

@@ -110,6 +110,8 @@ int gemm_profile_enable(int on);
 bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int gemm_profile_classes();
+extern int g_time_attn_fused_append;     // attn.hip: 1 (default) the cached decode's KV append rides in its time attention launch; 0 two launches (test hook)
+extern int g_attn_out_cols;              // frame_fused.hip: 1 (default) attention inside the column-split output projection at <= 4 frames; 0 two launches (test hook)
 int gemm_force_config(int id);                             // test hook; returns the number of configurations
 const char* gemm_profile_class_name(int c);
 

@@ -256,9 +256,14 @@ const char* d4_profile_glue_class_name(int c);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
  * split-operand fp32 family (gemm_x3.hip); 400 + c: tile c of the fp16x2 family (gemm_h2.hip); 500 + c: tile c of the bf16-activation kernel (gemm_bf16a.hip).
  * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
-/* Test hook for the per-frame fused block tails (csrc/frame_fused.hip; default from D4_FRAME_FUSED, 1): 0 separate kernels, 1 fused, 2 fused tails with the
+/* Test hook for the per-frame fused block tails (csrc/frame_fused.hip; default 1): 0 separate kernels, 1 fused, 2 fused tails with the
  * pool mix as its own kernel.  Returns the previous mode.  Which path runs is otherwise a rule on the call's shape. */
 int d4_frame_fused_set(int mode);
+/* Test hook for the two bit-identical launch fusions of the cached decode (each is asserted bitwise against its two-launch form): name =
+ * "time_attn_fused_append" (KV append inside the time attention, csrc/attn.hip) or "attn_out_cols" (attention inside the column-split output
+ * projection at <= 4 frames, csrc/frame_fused.hip); value 1 (default) fused, 0 two launches.  Returns the previous value, -1 for an unknown name.
+ * Read when a frame is ENQUEUED: a captured hipGraph keeps the form it was captured with. */
+int d4_debug_switch(const char* name, int value);
 int d4_gemm_force_config(int id);
 
 /* Test hook: device address of an engine-internal activation buffer (names: engine.hip d4_debug_buffer). */

@@ -341,14 +341,18 @@ def test_fused_kv_append_and_time_attention_equal_the_two_launches_bitwise(monke
     the same cache behind (a chained call continues from it)."""
     from dreamer4_amd import DynamicsWorldModel
     outs = []
-    for fused in ('1', '0'):
-        monkeypatch.setenv('D4_TIME_ATTN_FUSED_APPEND', fused)
-        monkeypatch.setenv('D4_GRAPH_MAX_ROWS', '0')             # (a captured graph would bake the first arm's kernels in)
-        torch.manual_seed(0)
-        m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
-        nz = make_noise(oracle_config(m), 18, 4, 3)
-        e, tc = m.generate(18, batch_size=4, return_for_policy_optimization=True, noise=nz, return_time_cache=True)
-        outs.append((e, tc.kv().clone()))
+    lib = _lib.load()
+    monkeypatch.setenv('D4_GRAPH_MAX_ROWS', '0')                 # (a captured graph would bake the first arm's kernels in)
+    try:
+        for fused in (1, 0):
+            assert lib.d4_debug_switch(b'time_attn_fused_append', fused) in (0, 1)
+            torch.manual_seed(0)
+            m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+            nz = make_noise(oracle_config(m), 18, 4, 3)
+            e, tc = m.generate(18, batch_size=4, return_for_policy_optimization=True, noise=nz, return_time_cache=True)
+            outs.append((e, tc.kv().clone()))
+    finally:
+        lib.d4_debug_switch(b'time_attn_fused_append', 1)
     (a, ka), (b, kb) = outs
     assert torch.equal(a.latents, b.latents) and torch.equal(a.agent_embed, b.agent_embed) and torch.equal(a.values, b.values)
     assert torch.equal(a.actions.discrete, b.actions.discrete) and torch.equal(ka, kb)
@@ -361,13 +365,17 @@ def test_few_frame_fused_attention_out_projection_equals_the_two_launches_bitwis
     few-row GEMM — same MFMA feed, same k slices, same fold order."""
     from dreamer4_amd import DynamicsWorldModel
     outs = []
-    for fused in ('1', '0'):
-        monkeypatch.setenv('D4_ATTN_OUT_COLS', fused)
-        monkeypatch.setenv('D4_GRAPH_MAX_ROWS', '0')             # (a captured graph would bake the first arm's kernels in)
-        torch.manual_seed(0)
-        m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
-        nz = make_noise(oracle_config(m), 6, B, 3)
-        outs.append(m.generate(6, batch_size=B, return_for_policy_optimization=True, noise=nz))
+    lib = _lib.load()
+    monkeypatch.setenv('D4_GRAPH_MAX_ROWS', '0')                 # (a captured graph would bake the first arm's kernels in)
+    try:
+        for fused in (1, 0):
+            assert lib.d4_debug_switch(b'attn_out_cols', fused) in (0, 1)
+            torch.manual_seed(0)
+            m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=16, num_latent_tokens=4, num_spatial_tokens=4, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+            nz = make_noise(oracle_config(m), 6, B, 3)
+            outs.append(m.generate(6, batch_size=B, return_for_policy_optimization=True, noise=nz))
+    finally:
+        lib.d4_debug_switch(b'attn_out_cols', 1)
     a, b = outs
     assert torch.equal(a.latents, b.latents) and torch.equal(a.agent_embed, b.agent_embed) and torch.equal(a.values, b.values)
     assert torch.equal(a.actions.discrete, b.actions.discrete)

@@ -322,7 +322,8 @@ def test_every_environment_switch_is_in_the_knob_table():
     assert found - set(KNOBS) == set(), f'switches missing from dreamer4_amd/knobs.py: {sorted(found - set(KNOBS))}'
     assert set(KNOBS) - found == set(), f'stale entries in dreamer4_amd/knobs.py: {sorted(set(KNOBS) - found)}'
     assert all(kind in ('experiment', 'mode', 'io') and doc for _, kind, doc in KNOBS.values())
-    assert experiment_overrides({'D4_GEMM_X3': '0', 'D4_FORCE_PG': '1'}) == {'D4_GEMM_X3': '0'}
+    assert len(KNOBS) <= 12 and not [k for k, (_, kind, _) in KNOBS.items() if kind == 'experiment'], 'round 5 retired every experiment switch'
+    assert experiment_overrides({'D4_FORCE_PG': '1'}) == {}
 
 
 def test_shortcut_coin_replays_when_the_generator_is_reseeded():
