@@ -99,7 +99,10 @@ struct d4_engine {
     std::vector<Mirror> mirrors;
     // bf16 mode (not split): bf16 IMAGES of the activation buffers the trunk GEMMs read (same element offsets / leading dimensions as the fp32
     // buffer).  Producers write them (GEMM epilogue `Cb`, attention / pool-mix `out_b`, a conversion pass elsewhere) and consumers read them
-    // through gemm_bf16a.hip (both operands by LDS-DMA) — numerically the rounding the fp32-activation kernel applied on its way into LDS.
+    // through gemm_bf16a.hip (both operands by LDS-DMA) — for the GEMMs numerically the rounding the fp32-activation kernel applied on its way into LDS.
+    // One NON-GEMM consumer reads images too at D > 512: the attention pool's mix takes the bf16 images of the layer hiddens for its softmax-weighted
+    // VALUE mix and its in-kernel RMS (fp32 before round 4) — an extra rounding of bf16 mode (a precision trade-off of that mode, not of the kernel), inside the
+    // engine-level bf16-vs-fp32 bound of tests/test_gpu_bf16.py (config-5 shape: latents 7.7e-3 max, asserted < 3e-2).
     // `only`: nothing reads the fp32 buffer when the image exists (the producer may skip the fp32 store).
     struct Shadow { const float* src; size_t n; uint16_t* dst; bool only; };
     std::vector<Shadow> shadows;

@@ -138,10 +138,19 @@ int engine_layout(d4_engine* e, bool assign) {
         sh(e->slabs, (size_t)e->nslab * M * D, false);
         sh(e->xpool, M * D, false);
         sh(e->att, M * hd, false);
-        // `only` (the producer skips the fp32 store) where the ONE consumer is certain to take the bf16-activation kernel: its K % 64 == 0
-        sh(e->ffh, M * e->inner_pad, e->inner_pad % 64 == 0 && D % 64 == 0);
-        sh(e->pool_att, M * hp, hp % 64 == 0 && D % 64 == 0);
-        sh(e->pool_u, M * (size_t)e->php * D, D % 64 == 0);
+        // `only` (the producer skips the fp32 store) where the ONE consumer is certain to take the bf16-activation kernel — decided by the SAME predicate
+        // that consumer call evaluates (gemm_bf16a_applicable on its leading dimensions, strides and contraction; operands from this allocator are
+        // 256-byte aligned), not by K % 64 alone: ffh -> the SiLU-GLU output projection, pool_att -> the pool's output projection,
+        // pool_u -> the per-head value projection (batch = pool heads, strideA = D, strideW = 64 D)
+        auto consumer_takes_images = [&](int K, int lda, int ldw, int batch, int64_t strideA, int64_t strideW) {
+            alignas(16) static const uint16_t probe[8] = {0};
+            GemmArgs g{nullptr, lda, nullptr, ldw, nullptr, 0, nullptr, nullptr, 0, 1, 64, K, 0, RMS_EPS};
+            g.Ab = probe; g.Wb = probe; g.batch = batch; g.strideA = strideA; g.strideW = strideW;
+            return gemm_bf16a_applicable(g);
+        };
+        sh(e->ffh, M * e->inner_pad, consumer_takes_images(e->inner_pad, e->inner_pad, e->inner_pad, 1, 0, 0));
+        sh(e->pool_att, M * hp, consumer_takes_images(hp, hp, hp, 1, 0, 0));
+        sh(e->pool_u, M * (size_t)e->php * D, consumer_takes_images(D, e->php * D, D, e->php, D, (int64_t)64 * D));
     }
     e->cq = fl(Fr * KQ * e->ldcq);
     e->ckv = fl(M * 2 * hd);
@@ -1513,7 +1522,11 @@ int d4_debug_buffer(d4_engine* e, const char* name, float** ptr) {
         {"cache", e->cache}, {"lin_q", e->lin_q}, {"lin_gate", e->lin_gate}, {"lout_q", e->lout_q},
         {"l_logits", e->l_logits}, {"l_dlogits", e->l_dlogits}, {"l_adv", e->l_adv}, {"l_returns", e->l_returns}, {"l_mask", e->l_mask},
     };
-    for (auto& t : tbl) if (!strcmp(t.n, name)) { *ptr = t.p; return 0; }
+    for (auto& t : tbl) if (!strcmp(t.n, name)) {
+        // a bf16 engine keeps some activation buffers ONLY as bf16 images (nothing writes the fp32 buffer): handing out the stale fp32 view would mislead
+        D4_REQUIRE(!e->shadow_only(t.p), "debug buffer '%s' exists only as a bf16 image in this engine (matmul_bf16 = 1)", name);
+        *ptr = t.p; return 0;
+    }
     D4_REQUIRE(false, "unknown debug buffer '%s'", name);
 }
 
@@ -1604,8 +1617,8 @@ int d4_gemm_bf16a_batched(const uint16_t* Ab, int lda, const uint16_t* Wb, int l
     g.Ab = Ab; g.Wb = Wb; g.Cb = Cb;
     g.batch = batch; g.strideA = strideA; g.strideW = strideW; g.strideC = strideC;
     D4_REQUIRE(C || Cb, "d4_gemm_bf16a_batched: no output");
-    D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a_batched: call not supported (K %% 64, lda / ldw / strides %% 8, 16-byte aligned operands)");
     if (M == 0) return 0;
+    D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a_batched: call not supported (K %% 64, lda / ldw / strides %% 8, 16-byte aligned operands)");
     return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
 }
 int d4_cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, void* stream) {

@@ -455,6 +455,14 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
                         break
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def load_state_dict(self, state_dict, strict=True, **kwargs):
+        """A checkpoint written before the nested tokenizer became a registered submodule (round 4; the reference registers it, dreamer4.py:4787-4794) has no
+        `video_tokenizer.*` keys: the tokenizer this model was constructed with keeps its weights and the strict load of everything else still applies."""
+        if self.video_tokenizer is not None and not any(k.startswith('video_tokenizer.') for k in state_dict):
+            state_dict = dict(state_dict)
+            state_dict.update({'video_tokenizer.' + k: v for k, v in self.video_tokenizer.state_dict().items()})
+        return super().load_state_dict(state_dict, strict=strict, **kwargs)
+
     def policy_head_parameters(self):
         """dreamer4.py:5343-5355"""
         return [*self.policy_head.parameters(), self.action_embedder.discrete_action_unembed,

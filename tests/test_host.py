@@ -358,3 +358,21 @@ def test_bench_launches_itself_for_several_gpus():
                          timeout=300, env=env)
     assert out.returncode != 0
     assert 'needs an MI355X' in out.stderr and 'WORLD_SIZE=1' not in out.stderr, out.stderr[-2000:]
+
+
+def test_state_dict_without_tokenizer_keys_still_loads_strictly():
+    """A checkpoint from before the nested tokenizer was a registered submodule (no `video_tokenizer.*` keys) loads with strict=True: the constructor's
+    tokenizer keeps its weights, every other key is still checked."""
+    from dreamer4_amd import VideoTokenizer
+    torch.manual_seed(0)
+    tok = VideoTokenizer(dim=32, dim_latent=8, patch_size=4, image_height=8, image_width=8, num_latent_tokens=4, encoder_depth=1, decoder_depth=1, attn_heads=2)
+    m = DynamicsWorldModel(dim=32, dim_latent=8, depth=1, num_discrete_actions=3, attn_heads=2, attn_dim_head=16, video_tokenizer=tok)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert any(k.startswith('video_tokenizer.') for k in sd)
+    old = {k: v for k, v in sd.items() if not k.startswith('video_tokenizer.')}
+    before = {k: v.clone() for k, v in m.video_tokenizer.state_dict().items()}
+    m.load_state_dict(old)                                           # strict
+    assert all(torch.equal(v, before[k]) for k, v in m.video_tokenizer.state_dict().items())
+    del old['register_tokens']
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(old)
