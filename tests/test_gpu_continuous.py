@@ -205,3 +205,47 @@ def test_beta_link_descriptor_in_the_training_forward_continuous_loss(link):
     with pytest.raises(ValueError, match='continuous_beta_param'):
         from dreamer4_amd import DynamicsWorldModel
         DynamicsWorldModel(dim=32, dim_latent=8, num_latent_tokens=4, depth=2, num_continuous_actions=2, continuous_beta_param='sigmoid')
+
+
+def test_learn_at_config5_size_vs_oracle():
+    """BASELINE config 5's actor/critic step (bench.py `cfg5_bf16.actor_critic_step_ms`): learn_from_experience(ppo) on the continuous (Beta) head at dim 1024,
+    B = 128 trajectories x 16 frames = 2048 learner rows, against the oracle on ONE Experience (the GPU's own fp32 rollout of a depth-2 trunk of that width —
+    the learner only sees agent embeddings, so the trunk's depth is irrelevant to it): both losses and every gradient of policy_head.*, value_head.* and
+    continuous_action_unembed, with the tolerance taken from the oracle's own sensitivity to a 2e-6 rounding of its inputs (as the config-2 test)."""
+    from dreamer4_amd import Actions, DynamicsWorldModel
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(dim=1024, dim_latent=32, num_latent_tokens=64, depth=2, time_block_every=2, num_continuous_actions=6), terminal_bias=-10.)
+    cfg, W = oracle_config(m), oracle_weights(m)
+    B, T = 128, 16
+    m = m.cuda()
+    e = m.generate(T, batch_size=B, return_for_policy_optimization=True, noise=make_noise(cfg, T, B, 1234))
+    assert e.agent_embed.shape == (B, T, 1024) and e.actions.continuous.shape[-1] == 6
+    cpu = lambda x: x.detach().cpu()
+    ref = dict(latents=cpu(e.latents), agent_embed=cpu(e.agent_embed), rewards=cpu(e.rewards), values=cpu(e.values), log_probs_cont=cpu(e.log_probs.continuous),
+               actions_cont=cpu(e.actions.continuous), lens=cpu(e.lens), terminals=cpu(e.terminals), is_truncated=cpu(e.is_truncated),
+               old_cont_params=cpu(e.old_action_unembeds.continuous), step_size=e.step_size)
+    heads = ('policy_head', 'value_head', 'action_embedder.continuous_action_unembed')
+    grads = lambda: {k: (v.clone().requires_grad_() if k.startswith(heads) and v.numel() > 0 else v) for k, v in W.items()}
+    Wg = grads()
+    pl_o, vl_o = restate.learn_losses(cfg, Wg, ref, 'ppo')
+    pl_o.backward(); vl_o.backward()
+    gen = torch.Generator().manual_seed(7)
+    jig = lambda x, r: x * (1 + r * (2 * torch.rand(x.shape, generator=gen) - 1))
+    ref2 = dict(ref, values=jig(ref['values'], 2e-6), rewards=jig(ref['rewards'], 2e-6), agent_embed=jig(ref['agent_embed'], 2e-6),
+                log_probs_cont=ref['log_probs_cont'] + 2e-6 * ref['log_probs_cont'].abs().max() * (2 * torch.rand(ref['log_probs_cont'].shape, generator=gen) - 1))
+    Wp = grads()
+    pl_p, vl_p = restate.learn_losses(cfg, Wp, ref2, 'ppo')
+    pl_p.backward(); vl_p.backward()
+    pl, vl = m.learn_from_experience(e, objective='ppo')
+    close(pl, pl_o, atol=2e-5 + 20 * abs(pl_p.item() - pl_o.item())); close(vl, vl_o, atol=2e-5 + 20 * abs(vl_p.item() - vl_o.item()))
+    pl.backward(retain_graph=True); vl.backward()
+    P = dict(m.named_parameters())
+    n = 0
+    for k, v in Wg.items():
+        if v.requires_grad and v.grad is not None:
+            go, gg = v.grad.double(), P[k].grad.detach().cpu().double()
+            sens = (Wp[k].grad.double() - go).norm().item()
+            assert (gg - go).norm().item() <= 20 * sens + 1e-5 * go.norm().item() + 1e-12, (k, (gg - go).norm().item(), sens, go.norm().item())
+            n += 1
+    assert n >= 10
