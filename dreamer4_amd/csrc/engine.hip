@@ -1571,8 +1571,7 @@ int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_str
     g.Wb = W3; g.wplane = plane_stride;
     D4_REQUIRE(d4::gemm_x3_applicable(g), "d4_gemm_split: call not supported (M=%d N=%d K=%d flags=%d: K %% 32, ldw %% 8, plane_stride %% 8, 16-byte alignment)", M, N, K, flags);
     if (M == 0) return 0;
-    if (config == d4::gemm_x3_configs() || config == d4::gemm_x3_configs() + 1)      // 6: the persistent form's k-cut, 7: its half tiles (the engine's form)
-        return d4::gemm_x3sk_launch(g, static_cast<hipStream_t>(stream), nullptr, nullptr, config == d4::gemm_x3_configs() ? 1 : 0);
+    if (config == d4::gemm_x3_configs()) return d4::gemm_x3sk_launch(g, static_cast<hipStream_t>(stream));      // 6: the persistent form (the engine's)
     if (config >= 0) return d4::gemm_x3_launch(config, g, static_cast<hipStream_t>(stream));
     return d4::gemm_x3_launch(d4::gemm_x3_heuristic(g), g, static_cast<hipStream_t>(stream));
 }

@@ -1,52 +1,25 @@
-// Persistent form of the split-operand fp32 GEMM (gemm_x3.hip, 128 x 128 tiles on 8 waves): ONE workgroup per CU walks a static list of
-// work items, and the tiles that do not fill a whole round of the machine are cut along k into S slices that S workgroups multiply
-// concurrently ("stream-K" with an integer split) and a third kind of work item sums in k order.
+// Persistent form of the split-operand fp32 GEMM (gemm_x3.hip, 128 x 128 tiles on 8 waves): ONE workgroup per CU walks a static list of work items.
 //
 // Why: this tile needs 120 KB of LDS, so exactly one workgroup fits a CU and a launch proceeds in rounds of 256 tiles
 // (profiles/r03g_x3_quantisation_sweep.txt is a staircase in steps of 256 tiles; a k-tile step takes ~1.8 us).  The cfg-2 shapes sit badly on
-// that staircase: the SiLU-GLU input projection is 616 tiles = 2.4 rounds and pays 3.  Here the F = floor(T / P) whole rounds run as
-// before and the R = T - F P remaining tiles are cut into S = floor(P / R) k-slices: 2.4 -> 2.5 rounds.
-//
-// Order of a workgroup's items: (1) its k-slice of a remaining tile FIRST — the slice's sums (hi + lo per element, the folded RMSNorm's
-// partial row sums) go to a workspace slot and the tile's counter is bumped; (2) its F whole tiles, with the epilogue as in
-// gemm_x3_kernel; (3) fix-ups: a remaining tile's slices are read back in k order, summed, and put through the epilogue.  The fix-ups are
-// dealt to the highest workgroup indices — the P - R S workgroups that had no slice and are ahead by a slice's time — so the
-// store -> flag -> load chain of the exchange (several memory round trips, ~10 us) is off every workgroup's critical path: by the time a
-// fix-up starts, its slices were written a whole tile-time ago.  (A first version let the slice-0 workgroup wait for the others right
-// after its own k-loop: the chain then sat at the end of the launch and ate the gain — 88.9 vs 90.1 us on the SiLU-GLU input projection.)
-//
-// Exchange between workgroups: L2 is per XCD and not coherent across XCDs inside a kernel, so the partial tiles and the counters go
-// through agent-scope relaxed atomics (write-through / re-fetch: the idiom tools/micro/grid_barrier_bench.hip validated) — no fence,
-// no cache flush.  THIS EXCHANGE IS WHAT THE FORM COSTS: a 64 KB slice takes ~10-20 us to cross between workgroups by agent-scope dword
-// accesses, and an uncached allocation (hipDeviceMallocUncached, plain 16-byte accesses) is slower still (profiles/r03i_gemm_x3sk.txt).  A slice never waits; a fix-up waits only for slices, which are every workgroup's FIRST item, and workgroups are
-// dispatched in index order: no residency assumption, no deadlock.  The wait is bounded all the same (a lost counter poisons the tile
-// with NaN instead of hanging the queue).  The fix-up clears the counter it consumed: a launch leaves the counters zero.
+// that staircase: the SiLU-GLU input projection is 616 tiles = 2.4 rounds and pays 3.
 //
 // IN THE ENGINE every split-operand call of >= 1024 rows runs here (gemm.hip): whole tiles walked by 256 long-lived workgroups are
 // bit-identical to gemm_x3_kernel and, measured in situ on mid-speed boxes, leave the FOLLOWING kernels ~3-4 % faster than 476-660 short-lived
 // 120 KB workgroups do (profiles/r03l_ab_late_changes.txt: 188 / 191 / 199 ms per step for all calls / half-tile calls only / none).
 //
-// HALF TILES: when the remaining tiles number at most half the workgroups, they are not cut along k but along N — 2 R
-// work items of 128 x 64 (the 8 waves as 4 x 2 with 32 x 32 wave tiles; a SiLU-GLU column group is one such item: its value wave and its
-// gate wave meet through LDS in the epilogue), one per workgroup, after the whole rounds.  Nothing is exchanged between workgroups and
-// every element keeps its k order: bit-identical to gemm_x3_kernel, 2.4 rounds -> 2 rounds + one shorter one (a half tile takes ~0.88 of a
-// whole tile's time — the k-tile step is bound by the per-wave split / LDS / barrier chain, not by the MFMAs: 83.3 vs 86.5 us on the
-// SiLU-GLU input projection, the one cfg-2 call gemm_x3sk_rule sends here).
+// HALF TILES: when the tiles of the last partial round number at most half the workgroups, they run as 2 R work items of 128 x 64 (the 8 waves as
+// 4 x 2 with 32 x 32 wave tiles; a SiLU-GLU column group is one such item: its value wave and its gate wave meet through LDS in the epilogue), one
+// per workgroup, after the whole rounds.  Nothing is exchanged between workgroups and every element keeps its k order: bit-identical to
+// gemm_x3_kernel, 2.4 rounds -> 2 rounds + one shorter one (a half tile takes ~0.88 of a whole tile's time — the k-tile step is bound by the
+// per-wave split / LDS / barrier chain, not by the MFMAs: 83.3 vs 86.5 us on the SiLU-GLU input projection).
 //
-// STATUS of the k-cut (measured, profiles/r03i_gemm_x3sk.txt): correct on every shape and epilogue, but at K = 512 the exchange gives back what the cut
-// saves — SiLU-GLU input projection 87.3 us vs 89.0 us for the plain kernel, the output projection (K = 1376) 58.6 us vs 49-52 us on the
-// f32-input kernels.  It pays where the cut removes most of a long round: 1792 x 5504 x 1024 127 us vs 144 us plain / 188 us f32-input.
-// The k-cut is reachable through d4_gemm_split config 6 only: no call of the engine takes it.
-//
-// Bits: whole tiles are bit-identical to gemm_x3_kernel (same k order, same instruction).  A cut tile is
-// (hi + lo)[slice 0] + (hi + lo)[slice 1] + ... — fp32 re-association at S - 1 points of the k sum, and its folded-RMSNorm row sums are
-// added per slice; which tiles are cut is a function of the shape and the CU count alone (never of timing), so results are
-// deterministic.  Error against float64: as gemm_x3_kernel (tests/test_gpu_kernels.py::test_gemm_split_stream_k).
+// (Rounds 3-4 also carried a k-cut of the last round — "stream-K" with an integer split, partial tiles exchanged through agent-scope atomics.  Correct on
+// every epilogue but a measured no-go: a 64 KB slice takes 10-20 us to cross between workgroups, which is what the cut saves at K = 512
+// (profiles/r03i_gemm_x3sk.txt).  Removed in round 5 together with its workspace allocation.)
 #include "common.h"
 #include <hip/hip_ext.h>
 #include "kernels.h"
-#include <map>
-#include <mutex>
 #include <type_traits>
 
 namespace d4 {
@@ -59,17 +32,13 @@ constexpr int SK_BM = 128, SK_BN = 128, SK_WGM = 4, SK_WGN = 2, SK_D = 3;
 constexpr int SK_BK = 32, SK_LD = SK_BK + 8, SK_NT = SK_WGM * SK_WGN * 64;
 constexpr int SK_G = SK_BK / 8;
 constexpr int SK_APL = SK_BM * SK_LD, SK_BPL = SK_BN * SK_LD;   // one plane of one buffer (elements); half tiles use the first 64 rows of a B plane
-constexpr int SK_SLOT = SK_BM * SK_BN + SK_BM;                  // floats of one partial tile: accumulators in register order, then row sums
 constexpr size_t SK_LDS = (size_t)(2 * 3 * (SK_BM + SK_BN) * SK_LD) * 2 + SK_BM * sizeof(float) + 16;
 static_assert(SK_BM * SK_G == SK_NT && SK_BN * SK_G == SK_NT, "one 8-element group of each operand per thread and k-tile");
 
 struct SkArgs {
     GemmArgs p;
-    int P, F, R, S;           // grid; whole rounds; remaining tiles; k slices per remaining tile
-    int half;                 // 1: the remaining tiles run as 2 R half tiles of 128 x 64 (S = 1)
-    int nfb;                  // the last nfb workgroups take the fix-ups (S > 1)
-    float* ws;                // [R * S][SK_SLOT] the slices' sums
-    unsigned* flags;          // [R] slices done per remaining tile, zero between launches
+    int P, F, R;              // grid; whole rounds; tiles of the last partial round
+    int half;                 // 1: the remaining tiles run as 2 R half tiles of 128 x 64
 };
 
 __device__ __forceinline__ void split3(float a, __bf16& h1, __bf16& h2, __bf16& h3) {
@@ -79,14 +48,13 @@ __device__ __forceinline__ void split3(float a, __bf16& h1, __bf16& h2, __bf16& 
     h3 = (__bf16)(r - (float)h2);
 }
 
-enum { ROLE_WHOLE = 0, ROLE_SLICE = 1, ROLE_FIXUP = 2 };
 
-// One work item on the calling workgroup: rows bm0 .. bm0 + 127, columns bn0 .. bn0 + 64 TNV - 1, k-tiles kt0 .. kt1 - 1.
-// TNV = 2: a 128 x 128 tile (wave tile 32 x 64); TNV = 1: a half tile of 128 x 64 (wave tile 32 x 32), role WHOLE only.
+// One work item on the calling workgroup: rows bm0 .. bm0 + 127, columns bn0 .. bn0 + 64 TNV - 1, all of K.
+// TNV = 2: a 128 x 128 tile (wave tile 32 x 64); TNV = 1: a half tile of 128 x 64 (wave tile 32 x 32).
 template <int TNV>
-__device__ __forceinline__ void sk_item(const SkArgs& s, const int bm0, const int bn0, const int kt0, const int kt1, const int role, const int slot,
-                                        const int jrem, __bf16* As, __bf16* Bs, float* rowscale_s, int* fail_s) {
+__device__ __forceinline__ void sk_item(const SkArgs& s, const int bm0, const int bn0, __bf16* As, __bf16* Bs, float* rowscale_s) {
     const GemmArgs& p = s.p;
+    const int kt0 = 0, kt1 = p.K / SK_BK;
     constexpr int BNV = 64 * TNV;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,7 +150,7 @@ __device__ __forceinline__ void sk_item(const SkArgs& s, const int bm0, const in
 
     const int nk = kt1 - kt0, kbeg = kt0 * SK_BK;
     const int klast = kbeg + (nk - 1) * SK_BK;
-    if (role != ROLE_FIXUP) {
+    {
         load_tile(S0{}, kbeg);
         load_tile(S1{}, min(kbeg + SK_BK, klast));
         load_tile(S2{}, min(kbeg + 2 * SK_BK, klast));
@@ -236,48 +204,6 @@ __device__ __forceinline__ void sk_item(const SkArgs& s, const int bm0, const in
     }
     const bool row_lane = (tid % SK_G) == 0;
 
-    if constexpr (TNV == 2) {
-        if (role == ROLE_SLICE) {
-            float* w = s.ws + (int64_t)slot * SK_SLOT;
-#pragma unroll
-            for (int j = 0; j < TNV; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) __hip_atomic_store(w + (j * 16 + e) * SK_NT + tid, hi[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rms && row_lane) __hip_atomic_store(w + SK_BM * SK_BN + srow, rsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_s_waitcnt(0);             // every store of this thread has been acknowledged ...
-            __syncthreads();                           // ... and of the workgroup
-            if (tid == 0) __hip_atomic_fetch_add(s.flags + jrem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (role == ROLE_FIXUP) {
-            if (tid == 0) {
-                int failed = 0;
-                unsigned spins = 0;
-                while (__hip_atomic_load(s.flags + jrem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s.S) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) { failed = 1; break; }
-                }
-                __hip_atomic_store(s.flags + jrem, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *fail_s = failed;
-            }
-            __syncthreads();
-            const float poison = *fail_s ? __builtin_nanf("") : 0.f;
-            for (int c = 0; c < s.S; ++c) {            // slices in k order
-                const float* w = s.ws + (int64_t)(slot + c) * SK_SLOT;
-#pragma unroll
-                for (int j = 0; j < TNV; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float v = __hip_atomic_load(w + (j * 16 + e) * SK_NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + poison;
-                        hi[j][e] = c == 0 ? v : hi[j][e] + v;
-                    }
-                if (rms && row_lane) {
-                    const float v = __hip_atomic_load(w + SK_BM * SK_BN + srow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    rsum = c == 0 ? v : rsum + v;
-                }
-            }
-        }
-    }
     if (rms) {
         if (row_lane) rowscale_s[srow] = rsqrtf(rsum / (float)p.K + p.rms_eps);
         __syncthreads();
@@ -350,7 +276,7 @@ __device__ __forceinline__ void sk_item(const SkArgs& s, const int bm0, const in
             }
         }
     }
-    __syncthreads();                                   // rowscale_s / fail_s / the LDS tiles are rewritten by the next item
+    __syncthreads();                                   // rowscale_s / the LDS tiles are rewritten by the next item
 }
 
 __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
@@ -359,7 +285,6 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
     __bf16* As = reinterpret_cast<__bf16*>(smem_raw);                 // [2][3][BM][LD]
     __bf16* Bs = As + 2 * 3 * SK_APL;                                 // [2][3][BN][LD]
     float* rowscale_s = reinterpret_cast<float*>(Bs + 2 * 3 * SK_BPL);   // [BM]
-    int* fail_s = reinterpret_cast<int*>(rowscale_s + SK_BM);
 
     const int b = blockIdx.x;
     const int nbn = (p.N + SK_BN - 1) / SK_BN, nbm = (p.M + SK_BM - 1) / SK_BM;
@@ -380,7 +305,7 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
         // whole rounds, then the remaining tiles as 2 R half tiles: item h = (remaining tile h / 2, column half h & 1) on workgroup h % P
         for (int i = 0; i < s.F; ++i) {
             tile_of(b + i * s.P, tm, tn);
-            sk_item<2>(s, tm * SK_BM, tn * SK_BN, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
+            sk_item<2>(s, tm * SK_BM, tn * SK_BN, As, Bs, rowscale_s);
         }
         // remaining tile j's two halves go to workgroups j and R8 + j (R8 = R rounded up to 8): both sit on XCD j % 8, the XCD whose L2 the banded
         // walk gave tile F P + j's neighbours to (with h / 2 on workgroup h the halves landed on other XCDs: +18 MB of fabric reads per launch)
@@ -390,46 +315,24 @@ __global__ __launch_bounds__(SK_NT, 2) void gemm_x3sk_kernel(SkArgs s) {
             if (j >= 0 && j < s.R && (b < s.R || b >= R8)) {
                 tile_of(s.F * s.P + j, tm, tn);
                 const int bn0 = tn * SK_BN + half * 64;
-                if (bn0 < p.N) sk_item<1>(s, tm * SK_BM, bn0, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
+                if (bn0 < p.N) sk_item<1>(s, tm * SK_BM, bn0, As, Bs, rowscale_s);
             }
             return;
         }
         for (int h = b; h < 2 * s.R; h += s.P) {
             tile_of(s.F * s.P + h / 2, tm, tn);
             const int bn0 = tn * SK_BN + (h & 1) * 64;
-            if (bn0 < p.N) sk_item<1>(s, tm * SK_BM, bn0, 0, nk_all, ROLE_WHOLE, 0, 0, As, Bs, rowscale_s, fail_s);
+            if (bn0 < p.N) sk_item<1>(s, tm * SK_BM, bn0, As, Bs, rowscale_s);
         }
         return;
     }
-    const int nsl = b < s.R * s.S ? 1 : 0;
-    int nfix = 0;
-    if (s.S > 1 && b >= s.P - s.nfb) {
-        const int j0 = s.P - 1 - b;
-        nfix = j0 < s.R ? (s.R - 1 - j0) / s.nfb + 1 : 0;
-    }
-    const int nitems = nsl + s.F + nfix;
-    for (int it = 0; it < nitems; ++it) {
-        int tile, kt0 = 0, kt1 = nk_all, role = ROLE_WHOLE, slot = 0, jrem = 0;
-        if (it < nsl) {
-            jrem = b % s.R;
-            const int z = b / s.R;
-            tile = s.F * s.P + jrem;
-            kt0 = (int)((int64_t)z * nk_all / s.S); kt1 = (int)((int64_t)(z + 1) * nk_all / s.S);
-            if (s.S > 1) { role = ROLE_SLICE; slot = jrem * s.S + z; }
-        } else if (it < nsl + s.F) tile = b + (it - nsl) * s.P;
-        else {
-            jrem = s.P - 1 - b + (it - nsl - s.F) * s.nfb;
-            tile = s.F * s.P + jrem; role = ROLE_FIXUP; slot = jrem * s.S;
-        }
-        tile_of(tile, tm, tn);
-        sk_item<2>(s, tm * SK_BM, tn * SK_BN, kt0, kt1, role, slot, jrem, As, Bs, rowscale_s, fail_s);
+    // whole tiles only: F rounds, then the last partial round's R tiles on the first R workgroups
+    for (int i = 0; i < s.F + (b < s.R ? 1 : 0); ++i) {
+        tile_of(b + i * s.P, tm, tn);
+        sk_item<2>(s, tm * SK_BM, tn * SK_BN, As, Bs, rowscale_s);
     }
 }
 
-// one workspace (partial tiles + counters, 17 MB) per stream for the k-cut mode ONLY, allocated at its first use outside graph capture and kept for
-// the life of the process (the half-tile mode the engine uses allocates nothing)
-struct SkWs { float* ws = nullptr; unsigned* flags = nullptr; };
-static std::map<hipStream_t, SkWs> g_sk_ws;
 static std::atomic<int> g_sk_cus[64];            // per device id (a process may drive several devices); 0 = not queried yet
 
 static int sk_cus() {
@@ -451,21 +354,6 @@ bool gemm_x3sk_applicable(const GemmArgs& p) {
     return gemm_x3_applicable(p) && p.batch <= 1 && p.M > 0 && (!(p.flags & GEMM_SWIGLU) || (p.N % 64) == 0);
 }
 
-// F whole rounds, R remaining tiles cut into S k-slices; returns the k-tile steps the longest workgroup walks (the launch's length)
-int gemm_x3sk_plan(const GemmArgs& p, int* F, int* R, int* S, int* P_out) {
-    const int P = sk_cus();
-    const int T = cdiv(p.M, SK_BM) * cdiv(p.N, SK_BN), nk = p.K / SK_BK;
-    int f = T / P, r = T - f * P, sl = 1;
-    if (r > 0) {
-        sl = P / r;
-        if (sl > 4) sl = 4;                            // a slice shorter than ~6 k-tiles is mostly prologue
-        while (sl > 1 && nk / sl < 6) --sl;
-    }
-    *F = f; *R = r; *S = sl;
-    if (P_out) *P_out = P;
-    return f * nk + (r > 0 ? cdiv(nk, sl) + (sl > 1 ? 2 : 0) : 0);
-}
-
 // Half tiles: the remaining tiles (at most half the workgroups) run as 2 R items of 128 x 64 after the F whole rounds
 bool gemm_x3sk_half_plan(const GemmArgs& p, int* F, int* R, int* P_out) {
     const int P = sk_cus();
@@ -485,38 +373,14 @@ bool gemm_x3sk_rule(const GemmArgs& p) {
     return gemm_x3sk_half_plan(p, &F, &R, &P) && F >= 1 && F <= 3;
 }
 
-// mode 0: half tiles where the plan allows them, else whole tiles only (the engine's form: nothing crosses between workgroups);
-// mode 1: the k-cut of the remaining tiles (slices + fix-ups through the workspace)
-int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb, int mode) {
+// half tiles where the plan allows them, else whole tiles only: nothing crosses between workgroups
+int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
     D4_REQUIRE(gemm_x3sk_applicable(p), "gemm_x3sk: call not supported (M=%d N=%d K=%d flags=%d batch=%d)", p.M, p.N, p.K, p.flags, p.batch);
     SkArgs a;
     a.p = p;
-    a.ws = nullptr; a.flags = nullptr;
-    a.nfb = 0; a.half = 0;
-    if (mode == 0) {
-        a.S = 1;
-        a.half = gemm_x3sk_half_plan(p, &a.F, &a.R, &a.P) ? 1 : 0;
-    } else
-        gemm_x3sk_plan(p, &a.F, &a.R, &a.S, &a.P);
+    a.half = gemm_x3sk_half_plan(p, &a.F, &a.R, &a.P) ? 1 : 0;
     const int T = a.F * a.P + a.R;
-    if (T < a.P && a.S == 1 && !a.half) a.P = T;       // a small call: one tile per workgroup, nothing persistent
-    if (a.S > 1) {
-        const int nfree = a.P - a.R * a.S, third = cdiv(a.R, 3);
-        a.nfb = nfree > third ? nfree : third;         // the workgroups without a slice take the fix-ups, up to three each; else more share them
-        static std::mutex ws_mu;                       // d4_gemm_split reaches this without the dispatcher's lock
-        std::lock_guard<std::mutex> lock(ws_mu);
-        SkWs& w = g_sk_ws[stream];
-        if (!w.ws) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(stream, &cap);
-            D4_REQUIRE(cap == hipStreamCaptureStatusNone, "gemm_x3sk: the partial-tile workspace of a stream cannot be created during graph capture (run the call once before capturing)");
-            const int P = sk_cus();
-            D4_HIP(hipMalloc(reinterpret_cast<void**>(&w.ws), (size_t)P * SK_SLOT * sizeof(float)));
-            D4_HIP(hipMalloc(reinterpret_cast<void**>(&w.flags), (size_t)P * sizeof(unsigned)));
-            D4_HIP(hipMemset(w.flags, 0, (size_t)P * sizeof(unsigned)));
-        }
-        a.ws = w.ws; a.flags = w.flags;
-    }
+    if (T < a.P && !a.half) a.P = T;                   // a small call: one tile per workgroup, nothing persistent
     static DeviceOnce attr_set;
     if (attr_set.need()) {
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SK_LDS));

@@ -85,12 +85,11 @@ bool gemm_h2_takes(const GemmArgs& p);                     // the dispatcher's r
 int gemm_h2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 int split_f16x2_rows(const float* src, uint16_t* dst, int rows, int cols, int ld, int64_t plane, float* inv_scale, hipStream_t s);
 int row_scale_exp(const float* A, int64_t lda, int rows, int K, int* out, hipStream_t s);      // GemmArgs::aexp of an activation matrix
-// persistent form of the 128 x 128 split-operand kernel (gemm_x3sk.hip): one workgroup per CU, the tiles of the last partial round cut along k
+// persistent form of the 128 x 128 split-operand kernel (gemm_x3sk.hip): one workgroup per CU, the tiles of the last partial round as half tiles
 bool gemm_x3sk_applicable(const GemmArgs& p);
 bool gemm_x3sk_rule(const GemmArgs& p);                    // the calls that take it (a rule on the shape and the CU count)
-int gemm_x3sk_plan(const GemmArgs& p, int* F, int* R, int* S, int* P);
 const char* gemm_x3sk_name();
-int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr, int mode = 0);   // mode 0: half tiles, 1: k-cut
+int gemm_x3sk_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 // second fp32 family (gemm2.hip): 16x16x4 MFMA fed by an LDS-DMA ring; non-transposed operands, K % 32 == 0
 bool gemm2_applicable(const GemmArgs& p);
 bool gemm2_config_valid(int c, const GemmArgs& p);

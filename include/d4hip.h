@@ -308,8 +308,8 @@ int d4_cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, 
  * bf16 numbers and a product is accumulated from its six leading bf16 x bf16 terms in fp32 — fp32 accuracy (error against float64 no
  * larger than the f32-input MFMA kernels'), 6/16 of their matrix-pipe time.  d4_split_bf16x3 writes the three planes of W
  * (dst[p * plane_stride + i], p = 0..2; plane_stride % 8 == 0); d4_gemm_split takes A in fp32 and splits it on the fly.  `config` = -1: the
- * dispatcher's choice, 0..5 one tile configuration of the family (all give the same bits), 6 the persistent form (csrc/gemm_x3sk.hip:
- * one workgroup per CU, the tiles of the last partial round cut along k and summed in k order — whole tiles keep the family's bits). */
+ * dispatcher's choice, 0..5 one tile configuration of the family (all give the same bits), 6 the persistent form the engine uses (csrc/gemm_x3sk.hip:
+ * one workgroup per CU, a last partial round of at most half the workgroups as 128 x 64 half tiles — the same bits). */
 int d4_split_bf16x3(const float* src, uint16_t* dst, int64_t n, int64_t plane_stride, void* stream);
 int d4_gemm_split(const float* A, int lda, const uint16_t* W3, int64_t plane_stride, int ldw, float* C, int ldc, const float* bias,
                   const float* R, int ldr, int M, int N, int K, int flags, float rms_eps, int config, void* stream);

@@ -224,14 +224,11 @@ def test_gemm_split_operands_is_fp32_accurate(lib, M, N, K, flags):
 
 @pytest.mark.parametrize('M,N,K,flags', [(3584, 2752, 512, 5), (3584, 512, 1376, 0), (3584, 1552, 512, 1), (3840, 2752, 512, 5), (1000, 300, 96, 1),
                                          (130, 129, 2048, 0), (257, 64, 64, 2), (3584, 512, 1376, 32)])
-def test_gemm_split_stream_k(lib, M, N, K, flags):
-    """gemm_x3sk.hip (d4_gemm_split config 6): the persistent form of the 128 x 128 split-operand kernel — one workgroup per CU, the tiles of the
-    last partial round cut along k into slices that are summed in k order through agent-scope atomics.  Whole tiles keep the family's
-    bits; a cut tile differs from the plain kernel by fp32 re-association at the cuts only.  Checked: error against float64 no larger
-    than the plain kernel's (+ 5 %), elementwise distance to the plain kernel within a few output roundings, repeated launches
-    bit-identical (the ready flags are left cleared), every epilogue, ragged edges, and a 4-slice cut (130 x 129 x 2048).
-    The half-tile mode (config 7: the last round as 128 x 64 items, SiLU-GLU value / gate waves meeting through LDS) is BIT-IDENTICAL to the
-    plain kernel."""
+def test_gemm_split_persistent_form_is_bit_identical(lib, M, N, K, flags):
+    """gemm_x3sk.hip (d4_gemm_split config 6, the form the engine uses): the persistent form of the 128 x 128 split-operand kernel — one workgroup per CU,
+    whole rounds of tiles, then a last partial round of at most half the workgroups as 128 x 64 half tiles (SiLU-GLU value / gate waves meeting through
+    LDS).  Nothing crosses between workgroups and every element keeps its k order: BIT-IDENTICAL to the plain kernel on every epilogue, ragged edges and
+    the accumulating form; repeated launches bit-identical.  (The k-cut of the last round that rounds 3-4 carried was removed in round 5.)"""
     g = torch.Generator(device='cuda').manual_seed(11)
     A = torch.randn(M, K, device='cuda', generator=g); W = torch.randn(N, K, device='cuda', generator=g) / K ** 0.5
     b = torch.randn(N, device='cuda', generator=g)
@@ -255,20 +252,14 @@ def test_gemm_split_stream_k(lib, M, N, K, flags):
     if accumulate:
         ref = ref + C0.double()
     outs = []
-    for cfg in (4, 6, 6, 6, 7):
+    for cfg in (4, 6, 6):
         o = C0.clone() if accumulate else torch.full((M, Nout), float('nan'), device='cuda')
         _lib.check(lib.d4_gemm_split(_lib.ptr(A), K, _lib.ptr(W3), plane, K, _lib.ptr(o), Nout, _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, cfg, stream()))
         outs.append(o)
     torch.cuda.synchronize()
     plain, sk = outs[0], outs[1]
-    # config 7, the form the engine uses: whole rounds + a last round of 128 x 64 half tiles — every element keeps its k order
-    assert torch.equal(outs[4], plain)
     assert torch.isfinite(sk).all()
-    assert torch.equal(outs[2], sk) and torch.equal(outs[3], sk)
-    rms = lambda x: (x.double() - ref).pow(2).mean().sqrt().item()
-    scale = ref.pow(2).mean().sqrt().item()
-    assert rms(sk) <= 1.05 * rms(plain) + 6e-8 * scale
-    assert (sk - plain).abs().max().item() <= 2e-6 * max(1., ref.abs().max().item())
+    assert torch.equal(sk, plain) and torch.equal(outs[2], sk)
     tol = 3e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
     assert (sk.double() - ref).abs().max().item() <= tol
 
