@@ -14,6 +14,7 @@ KNOBS = {
     'D4_TRUNK_SAVE_FORWARD': ('1', 'mode', 'training blocks keep their forward workspace (0: recompute in the backward, less memory)'),
     'D4_TRUNK_DISPATCHER': ('0', 'mode', '1: training blocks go through torch.ops.d4hip.* (torch.compile-traceable) instead of autograd.Function'),
     'D4_DP_BACKEND': ('gloo', 'mode', 'tests/dp_gpu_worker.py: process-group backend'),
+    'D4_DP_SIZE': ('small', 'mode', 'tests/dp_gpu_worker.py: `headline` runs the two-rank equivalence at config 2\'s architecture, global batch 256 x 16 frames'),
     'D4_BENCH_BACKEND': ('nccl', 'mode', 'bench.py: process-group backend (gloo: run the N-rank path on fewer devices than ranks, tests only)'),
     'D4_BENCH_STRICT_TUNE': ('0', 'mode', 'bench.py: force D4_GEMM_AUTOTUNE=strict on one rank (the multi-rank setting)'),
     # --- io

@@ -35,15 +35,26 @@ def main():
         torch.cuda.set_device(0)
     parallel.init_from_env(backend)
     rank, world = parallel.rank(), parallel.world_size()
-    Bg, T = 6, 4
-    m = small_model().cuda()
+    headline = os.environ.get('D4_DP_SIZE', 'small') == 'headline'
+    Bg, T = (256, 16) if headline else (6, 4)
+
+    def build():
+        if not headline:
+            return small_model().cuda()
+        # BASELINE config 3's per-rank model: config 2's architecture, the global batch sharded by trajectory (here 2 x 128 of 256)
+        from dreamer4_amd import DynamicsWorldModel
+        from dreamer4_amd.synthetic import randomize_weights
+        torch.manual_seed(0)
+        return randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), seed=0, terminal_bias=-3.).cuda()
+    small_model_ = build
+    m = small_model_()
     cfg = oracle_config(m)
     nz = make_noise(cfg, T, Bg, 55)
     lo, hi = parallel.shard_range(Bg)
     local = {k: v[:, lo:hi].contiguous() for k, v in nz.items()}
     losses, grads, pol, val = run(m, local, hi - lo, T, None)
     if rank == 0:
-        ref_model = small_model().cuda()
+        ref_model = small_model_()
         # single process over the whole global batch (no process group => world 1 semantics)
         dist_backup = parallel.world_size
         parallel.world_size = lambda group=None: 1
@@ -51,7 +62,8 @@ def main():
         parallel.world_size = dist_backup
         assert torch.allclose(losses, l_ref, atol=2e-5), (losses, l_ref)
         # gradients: equal up to the summation order of the two shards
-        assert torch.allclose(grads, g_ref, rtol=1e-3, atol=1e-6 * float(g_ref.abs().max())), (grads - g_ref).abs().max()
+        assert torch.allclose(grads, g_ref, rtol=1e-3, atol=(2e-5 if headline else 1e-6) * float(g_ref.abs().max())), (grads - g_ref).abs().max()
+        assert (grads.double() - g_ref.double()).norm() <= 1e-4 * g_ref.double().norm()
         # weights after clip + AdamW: the first Adam step moves every element by ~lr * g / (|g| + eps), so elements whose
         # gradient is at round-off level may differ by a fraction of lr = 3e-4
         assert torch.allclose(pol, p_ref, atol=1e-4) and torch.allclose(val, v_ref, atol=1e-4)

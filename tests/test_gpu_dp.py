@@ -19,6 +19,19 @@ def test_two_ranks_equal_one_process_at_the_global_batch():
     assert out.stdout.count('DPGPU_OK_') == 2, out.stdout
 
 
+def test_two_ranks_equal_one_process_at_the_headline_size():
+    """The same at BASELINE config 3's per-rank shape: config 2's architecture (dim 512, depth 6), a global batch of 256 trajectories x 16 frames sharded
+    over two ranks (128 each: every GEMM runs at other row counts than the single-process 256), a terminal bias that ends a share of the trajectories
+    early so that the global advantage statistics and masked-mean denominators matter: losses, the all-reduced gradients of both heads and the weights
+    after clip + AdamW equal a single process over the global batch."""
+    env = dict(os.environ, D4_DP_SIZE='headline', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29675', os.path.join(ROOT, 'tests', 'dp_gpu_worker.py')]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count('DPGPU_OK_') == 2, out.stdout
+
+
 def test_two_ranks_over_rccl_equal_one_process_at_the_global_batch():
     """The same check with one MI355X per rank and backend "nccl" (= RCCL over xGMI): the gradient buckets, the global statistics and the
     parameter checks cross devices through the collective library the 8-GPU run uses (trainers.py:1388-1396, 1436-1452 — the reference's
