@@ -1,21 +1,25 @@
-// fp32 GEMM on the fp16 matrix cores by operand splitting with exact power-of-two scales ("fp16x2 operands, three products") — the fourth
-// fp32 GEMM family, round 5.  It replaces the bf16x3 / six-product scheme of gemm_x3.hip in the engine: half the MFMAs, two thirds of the
-// planes through LDS (tools/micro/x3_planes_probe.hip, profiles/r05b_x3_planes_probe.txt: x1.3-1.65 on every cfg-2 shape in the same kernel body).
+// fp32-CLASS GEMM on the fp16 matrix cores by operand splitting with exact power-of-two scales ("fp16x2 operands, three products") — round 5, the
+// engine's OPT-IN `matmul_bf16 = 3` mode (Python: matmul_dtype='fp32_fp16x2').  Against the default bf16x3 / six-product scheme of gemm_x3.hip: half the
+// MFMAs, two thirds of the planes through LDS (tools/micro/x3_planes_probe.hip, profiles/r05b_x3_planes_probe.txt: x1.3-1.65 on every cfg-2 shape in
+// the same kernel body; whole rollout 176.5 -> 152.0 ms).  NOT the default and NOT what bench.py's `dtype: f32` is measured on: see "What this is".
 //
 //   C[m, n] = epilogue( rowscale[m] * sum_k A[m, k] * W[n, k] )        A fp32 [M][K], W fp32 given as two fp16 planes + a scale per row, C fp32
 //
 // Every fp32 operand row gets an exact power-of-two scale s that puts its largest magnitude into [2^14, 2^15) (the top of fp16's range), and each
 // scaled element x = a s is written as
-//       x = hi + lo 2^-11 + r,    hi = fp16(x),  lo = fp16((x - hi) 2^11),   |r| <= 2^-22 |x|     (x - hi and the 2^11 are exact in fp32)
+//       x = hi + lo 2^-11 + r,    hi = fp16(x),  lo = fp16((x - hi) 2^11),   |r| <= 2^-23 |x|     (x - hi and the 2^11 are exact in fp32)
 // A product is accumulated from its three leading fp16 x fp16 terms — each EXACT in fp32 (11 x 11 significant bits) — with v_mfma_f32_32x32x16_f16:
 //       hi_a.hi_w                 -> accumulator `hi`        (K / 16 rounded additions; the f32-input MFMA chain takes K)
-//       hi_a.lo_w + lo_a.hi_w     -> accumulator `lo`        (terms 2^-11 smaller; the dropped lo_a.lo_w is 2^-22 of the product)
+//       hi_a.lo_w + lo_a.hi_w     -> accumulator `lo`        (terms 2^-11 smaller; the dropped lo_a.lo_w is up to 2^-22 of the product)
 // and C = ldexp(hi + lo 2^-11, -(ea + ew)) undoes the two scales by ONE exact exponent shift (never a product of two floats: no intermediate
-// overflow).  What this is: fp32 arithmetic re-associated, carried on 22-bit operand images.  Its error against float64 is BELOW the f32-input
-// MFMA's for every K (the fmaf chain of K rounded additions dominates that one: 0.3x at K = 512, 0.8x at K = 32; tools/x3_products_fp16.py,
-// tests/test_gpu_kernels.py::test_gemm_h2_*: the same three criteria the bf16x3 scheme is held to — float64 error <= the f32-input MFMA's on
-// every epilogue and ragged shape, operands spanning 2^120 inside a row within fp32 rounding of sum |a w|, non-finite operands poison exactly
-// the outputs that depend on them).
+// overflow).
+//
+// What this is: fp32 arithmetic re-associated, carried on 23-bit operand images.  On dot products its error against float64 is BELOW the
+// f32-input MFMA's for every K (the fmaf chain of K rounded additions dominates that one: 0.43-0.45x at K = 512 on the GPU) and non-finite operands
+// poison exactly the outputs that depend on them — two of the three criteria the bf16x3 scheme is held to (tests/test_gpu_kernels.py::test_gemm_h2_*).
+// The third it FAILS: with operands spanning 2^120 inside a row every output is one product, and one product carries up to 2^-21 relative error where
+// fp32 has 2^-24: 5.5e-7 of sum |a w| against 3.1e-7 for the f32-input MFMA (allowed: 1.25 x + 6e-8).  Completing the product (lo.lo) or a third
+// plane of W does not fix it (5.0e-7, 4.95e-7: the fp16 MFMA's own accumulation is the rest): profiles/r05_x3_products.txt.
 //
 // Range: an element more than 2^28 below its row's largest keeps fewer bits (fp16 subnormal hi, lo), one more than ~2^38 below counts as zero:
 // its absolute error is <= 2^-50 of the row maximum — invisible against sum_k |a_k w_k| unless the OTHER operand is >= 2^26 above its own
