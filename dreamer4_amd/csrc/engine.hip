@@ -1056,16 +1056,10 @@ int mlp_forward(d4_engine* e, const Mlp& m, const float* x, int ldx, int rows, f
             lin_in = e->hnorm; ld_in = din;
         }
         const int act = (!last && !post) ? 1 : 0;          // SiLU fused into the linear's epilogue unless a LayerNorm sits in between
-        // few rows x long K (B x 2048 x 2048): a handful of 64 x 64 tiles would each walk all of K serially on a
-        // fraction of the CUs -> slice K across the grid (batched GEMM over K-slices) and combine in fixed order
-        int S = 1;
-        while (S < 8 && din % (2 * S * 32) == 0 && din / (2 * S) >= 256 && (int64_t)cdiv(rows, 64) * cdiv(dout, 64) * S < 1024) S *= 2;
-        if (S > 1 && rows <= e->maxB && ld_in == din) {
-            GemmArgs g{lin_in, din, m.w[i], din, e->splitk, dout, nullptr, nullptr, 0, rows, dout, din / S, 0, RMS_EPS};
-            g.batch = S; g.strideA = din / S; g.strideW = din / S; g.strideC = (int64_t)rows * dout;
-            if ((rc = gemm(g, s))) return rc;
-            if ((rc = splitk_reduce(e->splitk, S, rows, dout, m.b[i], act, y, ldy, s))) return rc;
-        } else if ((rc = gemm_simple(lin_in, ld_in, m.w[i], din, y, ldy, rows, dout, din, act ? GEMM_SILU : 0, m.b[i], nullptr, 0, s))) return rc;
+        // ONE launch per layer (bias + SiLU in the epilogue).  Rounds 1-4 sliced K over the grid and combined the slices in a reduce kernel (few rows x
+        // long K on 64 x 64 tiles); with the 32 x 32 tiles of the LDS-DMA family the direct form is level on the 2048 x 2048 layers (30.1 us vs 22.8 + a
+        // 5 us reduce + a boundary) and ahead on the first and last layers (K = 512: 9.7 vs 13.7 us) — tools/splitk_probe.py — so the reduce launches are gone
+        if ((rc = gemm_simple(lin_in, ld_in, m.w[i], din, y, ldy, rows, dout, din, act ? GEMM_SILU : 0, m.b[i], nullptr, 0, s))) return rc;
         if (post && (rc = layernorm_rows(y, ldy, m.g[i], m.nb[i], y, ldy, rows, dout, LN_EPS, 1, s))) return rc;
         cur = y; ld = ldy;
     }
