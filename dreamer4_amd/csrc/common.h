@@ -80,6 +80,8 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float siluf(float x) { return x / (1.f + expf(-x)); }
+// bf16 engine only (its GEMM epilogues round to bf16 right after): v_exp_f32 + v_rcp_f32, ~1e-7 relative, 5 instructions instead of ~25
+__device__ __forceinline__ float siluf_fast(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 
 // fp32 -> bf16 (round to nearest even) bit patterns, for the bf16 activation images the bf16 engine's GEMMs read
 __device__ __forceinline__ uint16_t bf16_bits(float v) { const __bf16 h = (__bf16)v; return __builtin_bit_cast(uint16_t, h); }

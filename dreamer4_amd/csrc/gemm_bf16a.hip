@@ -269,7 +269,7 @@ __device__ __forceinline__ void gemm_bf16a_body(GemmArgs p, const int block_x, c
                     for (int e = 0; e < 4; ++e) {
                         float val = acc[i][j][e] * rs, gate = acc[i][j + 2][e] * rs;
                         if (p.bias) { val += p.bias[gn + e]; gate += p.bias[gn + e + 32]; }
-                        o[e] = val * siluf(gate);
+                        o[e] = val * siluf_fast(gate);
                     }
                     const int on = (gn / 64) * 32 + (gn % 64);
                     float* cp = p.C + (int64_t)gm * p.ldc + on;
@@ -355,8 +355,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16a_pair_kernel(GemmArgs
 // 32x64       2 x 2    16 x 32     32 x 64     4 x 12 KB       3
 // 256x128     4 x 2    64 x 64    256 x 128    3 x 48 KB       1          SiLU-GLU capable (large problems)
 // 256x192     4 x 3    64 x 64    256 x 192    2 x 56 KB       1          SiLU-GLU capable; 12 waves; where its tile count fits the machine's rounds better
-// 256x256     4 x 4    64 x 64    256 x 256    2 x 64 KB       1          SiLU-GLU capable; 16 waves; half the operand bytes per flop of 128 x 128 (these
-//                                                                        kernels are bound by what the L2s deliver: ~14 TB/s measured on the cfg-5 shapes)
+// 256x256     2 x 4   128 x 64    256 x 256    8 x 16 KB       1          SiLU-GLU capable; gemm_bf16p.hip (round 6): 8 waves, phased k-loop with the two wave rows half a
+//                                                                        phase apart, ring of half-tiles 1.5 k-tiles deep.  It replaced the 16-wave two-slot form of
+//                                                                        round 4 (4 x 4 waves of 64 x 64, one barrier per k-tile): cube 8192 1174 -> 1298 TF/s, the
+//                                                                        SiLU-GLU input projection at 14336 rows 180 -> 162 us on one box (profiles/r06_bf16p_probe.txt)
 // Measured and retired (round 4, tools/bf16a_probe.py): rings of 4 - 8 stages at one workgroup per CU (the whole LDS in flight) are level or slower
 // than these — two co-resident workgroups hide more than a deeper ring; the k-loop step (~0.6 - 0.7 us for 128 x 128 x 64 even on a quarter of
 // the CUs) is bound inside the workgroup (barrier / DMA issue / fragment reads per k-tile), not by bytes in flight.
@@ -415,7 +417,7 @@ int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t e
         case VA_64x64_s: return launch_va<4, 1, 1, 4, 4>(p, stream, ea, eb);
         case VA_32x64: return launch_va<2, 2, 1, 2, 4>(p, stream, ea, eb);
         case VA_256x128: return launch_va<4, 2, 4, 4, 3>(p, stream, ea, eb);
-        case VA_256x256: return launch_va<4, 4, 4, 4, 2>(p, stream, ea, eb);
+        case VA_256x256: return gemm_bf16p_launch(p, stream, ea, eb);          // (round 6: the phased kernel of gemm_bf16p.hip replaced the 16-wave two-slot form)
         case VA_256x192: return launch_va<4, 3, 4, 4, 2>(p, stream, ea, eb);
     }
     return 2;

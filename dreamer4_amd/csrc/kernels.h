@@ -60,6 +60,7 @@ bool gemm_bf16a_config_valid(int c, const GemmArgs& p);
 int gemm_bf16a_configs();
 int gemm_bf16a_rule(const GemmArgs& p);
 int gemm_bf16a_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+int gemm_bf16p_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);      // gemm_bf16p.hip: the phased 256 x 256 form (configuration 6 of gemm_bf16a_launch)
 bool gemm_bf16a_pair_applicable(const GemmArgs& a, const GemmArgs& b);      // two RMS-folded products of equal K in one grid
 int gemm_bf16a_pair_launch(const GemmArgs& a, const GemmArgs& b, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 int gemm_bf16a_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream);      // ... with gemm_bf16.hip's optional event pair

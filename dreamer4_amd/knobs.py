@@ -27,8 +27,20 @@ KNOBS = {
 # hooks (d4_frame_fused_set, d4_debug_switch), never through the environment.
 
 
+# The retired names: setting one no longer does anything, so a run that sets one is NOT the run its author thinks it is — tests/conftest.py and bench.py
+# refuse to start (the same guard that used to catch a live experiment switch).
+RETIRED = (
+    'D4_ATTN_OUT_COLS', 'D4_BF16A_GROUPED', 'D4_BF16A_PAIR', 'D4_BF16_ACT', 'D4_BF16_DMA', 'D4_FRAME_FUSED', 'D4_GEMM_DX_T', 'D4_GEMM_PAIR', 'D4_GEMM_SKINNY',
+    'D4_GEMM_TN', 'D4_GEMM_V2', 'D4_GEMM_X3', 'D4_GEMM_X3SK', 'D4_KV_APPEND_LEGACY', 'D4_POOL_MIX_ROWS', 'D4_POOL_MIX_ROWS_MAX', 'D4_SKINNY_MAXM', 'D4_SKINNY_NW',
+    'D4_SKINNY_PAIR', 'D4_SKINNY_TILES', 'D4_SPACE_ATTN_MFMA', 'D4_TIME_ATTN_FEW', 'D4_TIME_ATTN_FUSED_APPEND', 'D4_TIME_ATTN_LEGACY',
+)
+
+
 def experiment_overrides(environ=None):
-    """The experiment switches set in the environment (name -> value).  Empty in every valid test / bench run."""
+    """The experiment switches set in the environment (name -> value): live ones (none since round 5) and RETIRED names, which are silently ignored by the
+    library and therefore must not be set.  Empty in every valid test / bench run."""
     import os
     env = os.environ if environ is None else environ
-    return {k: env[k] for k, (_, kind, _) in KNOBS.items() if kind == 'experiment' and k in env}
+    live = {k: env[k] for k, (_, kind, _) in KNOBS.items() if kind == 'experiment' and k in env}
+    live.update({k: env[k] + ' (retired: ignored by the library)' for k in RETIRED if k in env})
+    return live

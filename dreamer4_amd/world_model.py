@@ -455,13 +455,22 @@ class DynamicsWorldModel(SaveLoad, nn.Module):
                         break
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def load_state_dict(self, state_dict, strict=True, **kwargs):
-        """A checkpoint written before the nested tokenizer became a registered submodule (round 4; the reference registers it, dreamer4.py:4787-4794) has no
-        `video_tokenizer.*` keys: the tokenizer this model was constructed with keeps its weights and the strict load of everything else still applies."""
-        if self.video_tokenizer is not None and not any(k.startswith('video_tokenizer.') for k in state_dict):
+    def load_state_dict(self, state_dict, strict=True, allow_missing_tokenizer=False, **kwargs):
+        """The nested tokenizer is a registered submodule as in the reference (dreamer4.py:4787-4794), so a strict load RAISES on a checkpoint without
+        `video_tokenizer.*` keys — a checkpoint saved with video_tokenizer=None, or one with its tokenizer keys stripped, must not pass silently and leave
+        unrelated tokenizer weights in place.  `allow_missing_tokenizer=True` is the explicit opt-in for checkpoints written before round 4 (which kept the
+        tokenizer outside the module tree): only when NO tokenizer key is present, the tokenizer this model was constructed with keeps its weights, every other
+        key is still checked, a warning says so and `self.tokenizer_restored` records it (True after a load that carried the tokenizer)."""
+        has_tok = any(k.startswith('video_tokenizer.') for k in state_dict)
+        if self.video_tokenizer is not None and not has_tok and allow_missing_tokenizer:
+            import warnings
+            warnings.warn('load_state_dict: the checkpoint holds no video_tokenizer.* keys - the tokenizer of this model keeps the weights it was constructed '
+                          'with (allow_missing_tokenizer=True)', stacklevel=2)
             state_dict = dict(state_dict)
             state_dict.update({'video_tokenizer.' + k: v for k, v in self.video_tokenizer.state_dict().items()})
-        return super().load_state_dict(state_dict, strict=strict, **kwargs)
+        out = super().load_state_dict(state_dict, strict=strict, **kwargs)
+        self.tokenizer_restored = bool(has_tok) if self.video_tokenizer is not None else None
+        return out
 
     def policy_head_parameters(self):
         """dreamer4.py:5343-5355"""

@@ -48,7 +48,7 @@ def test_gemm_bf16_kernel(M, N, K, flags):
 
 
 @pytest.mark.parametrize('M,N,K,flags', [(128, 128, 64, 0), (1792, 1024, 512, 0), (200, 300, 128, 1), (1920, 2752, 1024, 5), (45, 388, 64, 3), (1792, 1552, 1024, 1),
-                                         (17, 64, 2752, 0)])
+                                         (17, 64, 2752, 0), (700, 520, 192, 1), (515, 1088, 320, 5)])
 def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
     """gemm_bf16a.hip (d4_gemm_bf16a): both operands bf16 in HBM, LDS-DMA ring, v_mfma_f32_16x16x32_bf16.  Every tile configuration against a
     float64 product of the SAME bf16 operands (row scale from the bf16 activations), all epilogues, partial tiles; the bf16 copy of the output
@@ -73,7 +73,7 @@ def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
         ref = ref + R.double()
     tol = 3e-6 * max(1., ref.abs().max().item()) * max(1., K / 256) ** 0.5
     ran = 0
-    for cfg in (-1, 0, 1, 2, 3, 4, 5):
+    for cfg in (-1, 0, 1, 2, 3, 4, 5, 6, 7):              # 6: the phased 256 x 256 form (gemm_bf16p.hip); odd and even k-tile counts, partial tiles in both directions
         out = torch.full((M, Nout), float('nan'), device='cuda'); outb = torch.zeros(M, Nout, device='cuda', dtype=torch.bfloat16)
         rc = lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, _lib.ptr(outb), _lib.ptr(b), _lib.ptr(R), N, M, N, K, flags, eps, cfg, stream())
         if rc != 0:
@@ -82,6 +82,10 @@ def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
         ran += 1
         assert (out.double() - ref).abs().max().item() <= tol, (cfg, (out.double() - ref).abs().max().item(), tol)
         assert torch.equal(outb, out.to(torch.bfloat16)), cfg
+        if swiglu:          # the engine's form: only the bf16 image is written (the phased kernel stages it through LDS into 16-byte stores)
+            only = torch.zeros(M, Nout, device='cuda', dtype=torch.bfloat16)
+            _lib.check(lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, None, Nout, _lib.ptr(only), _lib.ptr(b), None, 0, M, N, K, flags, eps, cfg, stream()))
+            assert torch.equal(only, outb), cfg
     assert ran >= 4
     with pytest.raises(_lib.D4Error, match='not supported'):
         _lib.check(lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, None, None, None, 0, M, N, 96, 0, eps, -1, stream()))
