@@ -159,6 +159,20 @@ PEAK_BF16_MFMA_TFLOPS = 2500.          # MI355X_MICROARCH.md "Peak BF16/FP16 MFM
 FLOP_PER_IMAGINED_STEP_CFG5 = 33.9e9   # cfg 5, per generated frame of one trajectory
 
 
+def measured_peaks(device, lib):
+    """What THIS box sustains (csrc/peaks.hip; outside every timed region, < 1 s): float4 stream copy over 2 x 512 MiB (read + write GB/s) and bare MFMA streams
+    on random operands.  Reported BESIDE the datasheet peaks every `frac` is priced against (8000 GB/s, 157.3 / 2500 TFLOP/s), never instead of them."""
+    from dreamer4_amd import _lib
+    buf = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+    hbm, f32, b16 = C.c_double(), C.c_double(), C.c_double()
+    _lib.check(lib.d4_measure_peaks(_lib.ptr(buf), buf.numel(), C.byref(hbm), C.byref(f32), C.byref(b16), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    del buf
+    torch.cuda.empty_cache()
+    return dict(hbm_stream_copy_gbs=round(hbm.value, 1), mfma_f32_tflops=round(f32.value, 1), mfma_bf16_tflops=round(b16.value, 1),
+                what='float4 stream copy through 2 x 512 MiB (read + write bytes / s); v_mfma_f32_16x16x4_f32 and v_mfma_f32_32x32x16_bf16 streams, 12 independent '
+                     'accumulators, 2 waves per SIMD, random operands; datasheet: 8000 GB/s, 157.3 / 2500 TFLOP/s')
+
+
 def cfg4_env_latency(device, horizon=50):
     """BASELINE config 4, secondary numbers (driver-timed because they are part of this process): dim 512 depth 6, 4 x 16 latents,
     4 discrete user-chosen actions, one generated frame per call with the KV cache carried, exactly the call
@@ -286,7 +300,25 @@ def cfg2_fp16x2_mode(device, reps=3):
                 workload=f'cfg2 rollout only: B={B_LOCAL}, H={HORIZON}, num_steps={NUM_STEPS}')
 
 
-def cfg5_cpu_baseline(max_threads=16, budget_s=25.):
+def cfg5_error_vs_oracle(device, kept):
+    """The bf16 engine at config 5 against the oracle rollout the CPU baseline just timed (same weights, same injected draws incl. the Beta sampler's, the
+    bench's 16-frame horizon through the KV cache): max |difference| per tensor.  Outside every timed region; the oracle is the checker, never measured here."""
+    from dreamer4_amd import DynamicsWorldModel
+    from dreamer4_amd.synthetic import randomize_weights
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import rollout_parity_continuous
+    torch.manual_seed(0)
+    m = randomize_weights(DynamicsWorldModel(**CFG5, matmul_dtype='bf16'), terminal_bias=-10.).to(device)
+    nz = kept['noise']
+    e = m.generate(kept['frames'], batch_size=kept['batch'], return_for_policy_optimization=True, num_steps=NUM_STEPS, noise=nz).cpu()
+    rep = rollout_parity_continuous(e, kept['exp'])
+    rep['what'] = (f"the bf16 engine's rollout of B={kept['batch']} x {kept['frames']} frames vs oracle/restate.py (fp32) under the same injected draws; a trajectory is "
+                   "'tracked' while every sampled Beta action stays within track_tol of the oracle's (a rejection-sampling decision inside the bf16 error flips "
+                   "otherwise and the trajectory takes another path); *_max_abs over the tracked trajectories, *_max_abs_all over all")
+    return rep
+
+
+def cfg5_cpu_baseline(max_threads=16, budget_s=25., keep=None):
     """The CPU oracle at config 5's architecture (dim 1024, depth 12, 6 Beta actions; torch fp32 on the host), rank 0 at N = 1 only: a BOUNDED
     SAMPLE of the workload — the full one (B = 128, 16 frames: 69 TFLOP) would take minutes on the host — sized by a short probe to about `budget_s`."""
     from dreamer4_amd import DynamicsWorldModel
@@ -310,6 +342,8 @@ def cfg5_cpu_baseline(max_threads=16, budget_s=25.):
         Wg = {k: (v.clone().requires_grad_() if k.startswith(heads) else v) for k, v in W.items()}
         pl, vl = restate.learn_losses(cfg, Wg, exp, 'ppo')
         pl.backward(); vl.backward()
+        if keep is not None and frames == HORIZON + 1:
+            keep.update(exp=exp, noise=nz, batch=batch, frames=frames)
         return batch * exp['latents'].shape[1], time.perf_counter() - t0
 
     run(1, 1)
@@ -368,15 +402,18 @@ def main():
                            generate_kwargs=dict(return_for_policy_optimization=True, num_steps=NUM_STEPS))
     lib = _lib.load()
 
-    gpu_headline = None
+    gpu_headline, headline_error = None, None
     if world == 1 and not args.no_cpu_baseline:
         # parity at the headline size: the SAME rollout (B = 256, 16 frames) under injected draws with the INITIAL weights (before any optimiser step
         # moves the heads), compared at the end with the oracle run that `cpu_baseline` times anyway (outside the timed region; the oracle is the
         # checker here, never the thing measured)
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         from util import make_noise, oracle_config
-        nz = make_noise(oracle_config(model), HORIZON + 1, B_LOCAL, 1234)
-        gpu_headline = model.generate(HORIZON + 1, batch_size=B_LOCAL, return_for_policy_optimization=True, num_steps=NUM_STEPS, noise=nz).cpu()
+        try:                                              # (a failing parity leg must not cost the headline line)
+            nz = make_noise(oracle_config(model), HORIZON + 1, B_LOCAL, 1234)
+            gpu_headline = model.generate(HORIZON + 1, batch_size=B_LOCAL, return_for_policy_optimization=True, num_steps=NUM_STEPS, noise=nz).cpu()
+        except Exception as exc:                          # noqa: BLE001
+            gpu_headline, headline_error = None, repr(exc)
     timing = not args.no_kernel_timing
     ncls = lib.d4_profile_classes()
     raw_names = [lib.d4_profile_class_name(i).decode() for i in range(ncls)]
@@ -537,6 +574,10 @@ def main():
     if world == 1 and not args.no_secondary:
         del trainer, model
         torch.cuda.empty_cache()
+        try:
+            out['measured_peaks'] = measured_peaks(device, lib)
+        except Exception as exc:                      # noqa: BLE001
+            out['measured_peaks_error'] = repr(exc)
         for key, fn in (('cfg4_env_step', lambda: cfg4_env_latency(device)), ('cfg5_bf16', lambda: cfg5_bf16(device, lib)),
                         ('train_flow_step', lambda: train_flow_step(device)), ('cfg2_fp16x2_mode', lambda: cfg2_fp16x2_mode(device))):
             try:                                      # a failing secondary measurement must not cost the headline line
@@ -548,25 +589,29 @@ def main():
         out['cpu_baseline'] = cpu_baseline(keep=kept)
         out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
         if 'cfg5_bf16' in out:
+            kept5 = {}
             try:
-                out['cfg5_bf16']['cpu_baseline'] = cfg5_cpu_baseline()
+                out['cfg5_bf16']['cpu_baseline'] = cfg5_cpu_baseline(keep=kept5)
                 out['cfg5_bf16']['speedup_vs_cpu_baseline'] = round(out['cfg5_bf16']['whole_step_steps_per_sec'] / out['cfg5_bf16']['cpu_baseline']['value'], 1)
             except Exception as exc:                  # noqa: BLE001
                 out['cfg5_bf16']['cpu_baseline_error'] = repr(exc)
+            if kept5:
+                try:
+                    out['cfg5_bf16']['error_vs_oracle'] = cfg5_error_vs_oracle(device, kept5)
+                except Exception as exc:              # noqa: BLE001
+                    out['cfg5_bf16']['error_vs_oracle'] = dict(error=repr(exc))
         if kept and gpu_headline is not None:
-            from util import rollout_parity
+            from util import first_trajectories, rollout_parity
             b = kept['batch']
-            from dataclasses import fields, replace
-            from torch.utils._pytree import tree_map
-            first = lambda v: v[:b] if torch.is_tensor(v) and v.ndim >= 1 else v
-            sub = replace(gpu_headline, **{f.name: tree_map(first, getattr(gpu_headline, f.name)) for f in fields(gpu_headline)})
             try:
-                rep = rollout_parity(sub, kept['exp'], kept['noise'], kept['cfg'])
+                rep = rollout_parity(first_trajectories(gpu_headline, b), kept['exp'], kept['noise'], kept['cfg'])
             except Exception as exc:                      # noqa: BLE001 - the headline line must still be printed
                 rep = dict(error=repr(exc))
             rep['what'] = (f'the GPU rollout of the first {b} of the B={B_LOCAL} trajectories x {HORIZON + 1} frames vs oracle/restate.py under the same injected draws '
                            '(max |difference| per tensor over the trajectories whose sampling margins are well posed; integers must be equal there)')
             out['parity_at_headline'] = rep
+        elif headline_error:
+            out['parity_at_headline'] = dict(error=headline_error)
         if (os.cpu_count() or 1) >= 64:
             out['cpu_baseline_sharded'] = cpu_baseline_sharded()
     print(json.dumps(out))

@@ -124,6 +124,7 @@ SYMBOLS = {
     'd4_profile_glue_read': (_I, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _I]),
     'd4_profile_glue_classes': (_I, []),
     'd4_profile_glue_read_flops': (_I, [C.POINTER(C.c_double), _I]),
+    'd4_measure_peaks': (_I, [_P, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     'd4_profile_glue_class_name': (C.c_char_p, [_I]),
     'd4_debug_buffer': (_I, [_P, C.c_char_p, C.POINTER(_P)]),
     'd4_gemm': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

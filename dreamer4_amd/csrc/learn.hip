@@ -518,10 +518,39 @@ static int mlp_backward(d4_engine* e, const Mlp& m, const float* save, int R, co
     return 0;
 }
 
+// A rank whose trajectory shard is EMPTY (a global batch smaller than the number of ranks, or an uneven split): it has nothing to learn from but must
+// take part in every collective of the step with a zero contribution, in the order the other ranks issue them (three statistics all-reduces here, the
+// gradient all-reduce of each head in the caller), and ends up with the global losses and zero local gradients.
+static int learn_empty_shard(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
+    const d4_config& c = e->c;
+    int rc;
+    float* scal = e->l_scal;
+    D4_HIP(hipMemsetAsync(scal, 0, 64 * sizeof(float), s));
+    if ((rc = io->allreduce_sum(scal, 2, io->allreduce_user)) || (rc = io->allreduce_sum(scal + 2, 1, io->allreduce_user)) ||
+        (rc = io->allreduce_sum(scal + 4, 4, io->allreduce_user))) { set_error("allreduce callback failed (%d)", rc); return 5; }
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(1), 0, s, scal, io->losses, io->objective, c.policy_entropy_weight,
+                       io->objective == 2 ? c.pmpo_kl_div_loss_weight : 0.f);
+    D4_LAUNCH_CHECK();
+    for (const Mlp* m : {&e->policy, &e->value})
+        for (int i = 0; i < m->nl; ++i) {
+            const int din = m->dims[i], dout = m->dims[i + 1];
+            D4_REQUIRE(m->db[i] && m->dw[i], "learner: head parameters were bound without gradient buffers");
+            if ((rc = fill_f32(m->dw[i], 0.f, (int64_t)dout * din, s)) || (rc = fill_f32(m->db[i], 0.f, dout, s))) return rc;
+            if (m->dg[i] && (rc = fill_f32(m->dg[i], 0.f, m->post_norm(i) ? dout : din, s))) return rc;
+            if (m->dnb[i] && (rc = fill_f32(m->dnb[i], 0.f, dout, s))) return rc;
+        }
+    const int64_t mtp4d = (int64_t)c.multi_token_pred_len * 4 * e->D;
+    if (e->na > 0 && e->action_unembed_grad && (rc = fill_f32(e->action_unembed_grad, 0.f, e->A * mtp4d, s))) return rc;
+    if (e->nc > 0 && e->cont_unembed_grad && (rc = fill_f32(e->cont_unembed_grad, 0.f, 2 * e->nc * mtp4d, s))) return rc;
+    return 0;
+}
+
 int learn(d4_engine* e, const d4_learn_io* io, hipStream_t s) {
     const d4_config& c = e->c;
     D4_REQUIRE(e->prepared, "engine not prepared");
     const int B = io->batch, T = io->time, R = B * T;
+    D4_REQUIRE(io->objective >= 0 && io->objective <= 2, "unknown objective %d  [D4:6215]", io->objective);
+    if (R == 0 && io->allreduce_sum && io->losses) return learn_empty_shard(e, io, s);
     D4_REQUIRE(R > 0 && R <= e->LR, "learn: %d rows exceed max_learn_rows %d", R, e->LR);
     D4_REQUIRE(io->agent_embed && io->old_values && io->rewards && io->losses && (e->na == 0 || (io->actions && io->old_log_probs)) &&
                (e->nc == 0 || (io->actions_cont && io->old_log_probs_cont)),

@@ -252,6 +252,11 @@ int d4_profile_glue_classes(void);
 int d4_profile_glue_read_flops(double* flops, int nclass);      /* matrix work the per-frame fused classes carry; call before d4_profile_glue_read */
 const char* d4_profile_glue_class_name(int c);
 
+/* Measured denominators for the roofline fractions (nothing of the reference is replaced: it has no measurement layer): what THIS device
+ * sustains on a float4 stream copy through `scratch` (two halves; >= 1 GiB so that the 256 MB Infinity Cache cannot serve it; read + write GB/s) and on
+ * bare v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x16_bf16 streams with random operands (TFLOP/s).  Well under a second; synchronises the stream. */
+int d4_measure_peaks(void* scratch, size_t scratch_bytes, double* hbm_copy_gbs, double* mfma_f32_tflops, double* mfma_bf16_tflops, void* stream);
+
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
  * split-operand fp32 family (gemm_x3.hip); 400 + c: tile c of the fp16x2 family (gemm_h2.hip); 500 + c: tile c of the bf16-activation kernel (gemm_bf16a.hip).

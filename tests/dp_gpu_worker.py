@@ -13,13 +13,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 from dreamer4_amd import DreamTrainer, parallel      # noqa: E402
-from util import make_noise, oracle_config, small_model  # noqa: E402
+from util import first_trajectories, make_noise, oracle_config, small_model  # noqa: E402
 
 
 def run(model, noise, B, T, group):
     tr = DreamTrainer(model, batch_size=B, generate_timesteps=T - 1, process_group=group, stats='global')
-    dreams = model.generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
-                            return_log_probs_and_values=True, noise=noise)
+    if B == 0:
+        # an EMPTY trajectory shard (6 trajectories over 8 ranks): nothing to roll out, but the rank takes part in every collective of the step with a
+        # zero contribution and must end up with the same weights as the others.  (An Experience of zero trajectories: one rolled out, none kept.)
+        dreams = first_trajectories(model.generate(T, batch_size=1, return_rewards_per_frame=True, return_agent_actions=True,
+                                                   return_log_probs_and_values=True, noise=make_noise(oracle_config(model), T, 1, 7)), 0)
+    else:
+        dreams = model.generate(T, batch_size=B, return_rewards_per_frame=True, return_agent_actions=True,
+                                return_log_probs_and_values=True, noise=noise)
     losses = tr.learn(dreams)
     grads = torch.cat([model._groups['policy']['grad'].cpu(), model._groups['value']['grad'].cpu()])     # after the all-reduce
     return losses.cpu(), grads, torch.cat([p.detach().flatten().cpu() for p in model.policy_head_parameters() if p.numel()]), \

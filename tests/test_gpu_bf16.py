@@ -196,6 +196,33 @@ def test_config5_shape_bf16_vs_fp32_at_the_per_gpu_batch():
     assert (pa - pb).abs().max().item() < 2e-2 * pa.abs().max().item()            # raw parameters of scale ~25: 1-2 % relative
 
 
+def test_config5_bf16_engine_vs_oracle_at_the_bench_horizon():
+    """BASELINE config 5 as bench.py times it — dim 1024, depth 12, 64 x 32 latents, 6 continuous (Beta) actions, the bf16 engine, 16 frames x (4 + 1)
+    evaluations through the KV cache — against the fp32 CPU oracle (oracle/restate.py) under the same injected draws, Beta sampler included (B = 8: the
+    oracle finishes in seconds).  No exactness claim in this mode; the STATED bounds after 16 chained frames, on the trajectories whose sampled actions
+    stayed on the oracle's path (a rejection-sampling decision inside the bf16 error sends a trajectory down another path: reported, not compared):
+    latents (clamped to [-1, 1]) 4e-2 max / 4e-3 mean, agent embedding 6e-2 of its scale, values (range +-20) 0.3, Beta log-probs 0.3, actions 5e-2."""
+    from oracle import restate
+    from util import oracle_weights, rollout_parity_continuous
+    kw = dict(dim=1024, dim_latent=32, num_latent_tokens=64, depth=12, num_continuous_actions=6)
+    torch.manual_seed(0)
+    ref_m = randomize_weights(DynamicsWorldModel(**kw), terminal_bias=-10.)
+    cfg, W = oracle_config(ref_m), oracle_weights(ref_m)
+    m = DynamicsWorldModel(**kw, matmul_dtype='bf16')
+    m.load_state_dict(ref_m.state_dict())
+    B, T = 8, 16
+    nz = make_noise(cfg, T, B, 1234)
+    with torch.no_grad():
+        ref = restate.generate(cfg, W, T, batch_size=B, noise=nz, num_steps=4)
+    e = m.cuda().generate(T, batch_size=B, return_for_policy_optimization=True, num_steps=4, noise=nz).cpu()
+    rep = rollout_parity_continuous(e, ref)
+    print('\ncfg5 bf16 vs oracle, 16 frames:', {k: (round(v, 5) if isinstance(v, float) else v) for k, v in rep.items()})
+    assert rep['frames_equal'] and rep['tracked_trajectories'] >= B // 2, rep
+    assert rep['latents_max_abs'] < 4e-2 and rep['latents_mean_abs'] < 4e-3, rep
+    assert rep['agent_embed_max_abs'] < 6e-2 * max(1., rep['agent_embed_scale']), rep
+    assert rep['values_max_abs'] < 0.3 and rep['cont_logp_max_abs'] < 0.3 and rep['actions_cont_max_abs'] <= 5e-2, rep
+
+
 def test_fp32_default_with_split_operand_projections_equals_the_f32_mfma_engine_to_fp32_accuracy():
     """matmul_dtype='fp32' (default) runs the SiLU-GLU input projections as split-operand fp32 GEMMs on the bf16 matrix cores
     (csrc/gemm_x3.hip); 'fp32_mfma' keeps every GEMM on the f32-input MFMA.  Both are fp32 arithmetic: at config 2's architecture

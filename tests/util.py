@@ -172,3 +172,43 @@ def rollout_parity(e, ref, nz, cfg, margin=1e-3):
         out[name + '_max_abs'] = float((a - b).abs().max())
         out[name + '_scale'] = float(b.abs().max())
     return out
+
+
+def rollout_parity_continuous(e, ref, track_tol=5e-2):
+    """A REDUCED-PRECISION product rollout `e` (the bf16 engine, continuous actions only) against the oracle's fp32 `ref` under the same injected noise.
+    A Beta draw is a ratio of rejection-sampled gammas: an accept / reject decision whose margin is below the engine's error flips, the sample jumps
+    and that trajectory takes another path from there on (the action feeds the next frames).  A trajectory is 'tracked' while every sampled action stays
+    within `track_tol` of the oracle's; the float fields are compared on the tracked trajectories (and, separately, on all of them).  Plain numbers."""
+    c = lambda x: x.detach().cpu().float()
+    B, F_ = ref['latents'].shape[:2]
+    out = dict(trajectories=B, frames=F_, frames_equal=bool(e.latents.shape[1] == F_), track_tol=track_tol)
+    if not out['frames_equal']:
+        return out
+    da = (c(e.actions.continuous) - ref['actions_cont'].float()).abs().flatten(1).max(dim=1).values
+    tracked = da <= track_tol
+    out['tracked_trajectories'] = int(tracked.sum())
+    out['actions_cont_max_abs_all'] = float(da.max())
+    fields = (('latents', e.latents, ref['latents']), ('agent_embed', e.agent_embed, ref.get('agent_embed')), ('values', e.values, ref.get('values')),
+              ('rewards', e.rewards, ref.get('rewards')), ('cont_logp', e.log_probs.continuous if e.log_probs is not None else None, ref.get('log_probs_cont')),
+              ('actions_cont', e.actions.continuous, ref.get('actions_cont')))
+    for name, a, b in fields:
+        if a is None or b is None:
+            continue
+        d = (c(a) - b.float()).abs().flatten(1)
+        out[name + '_scale'] = float(b.abs().max())
+        out[name + '_max_abs_all'] = float(d.max())
+        if tracked.any():
+            out[name + '_max_abs'] = float(d[tracked].max())
+            out[name + '_mean_abs'] = float(d[tracked].mean())
+    return out
+
+
+def first_trajectories(exp, b):
+    """The first `b` trajectories of an Experience: every tensor whose leading dimension is the batch (the payload's) is sliced, anything else —
+    scalars, per-model tensors of another leading size — is kept as it is."""
+    from dataclasses import fields, replace
+    from torch.utils._pytree import tree_map
+    payload = exp.latents if exp.latents is not None else exp.video
+    batch = payload.shape[0]
+    cut = lambda v: v[:b] if torch.is_tensor(v) and v.ndim >= 1 and v.shape[0] == batch else v
+    return replace(exp, **{f.name: tree_map(cut, getattr(exp, f.name)) for f in fields(exp)})
