@@ -134,6 +134,7 @@ SYMBOLS = {
     'd4_gemm_bf16': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'd4_gemm_bf16a': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     'd4_cvt_bf16': (_I, [_P, _P, _L, _P]),
+    'd4_gemm_bf16a_compact': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'd4_gemm_bf16a_batched': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _L, _L, _L, _I, _P]),
     'd4_cvt_rows_bf16': (_I, [_P, _L, _P, _L, _I, _I, _P]),
     'd4_split_bf16x3': (_I, [_P, _P, _L, _L, _P]),

@@ -151,7 +151,7 @@ struct d4_engine {
     int* fstate;                           // device frame state {t0} read by the time-attention kernels under graph replay
     int64_t* tasks_dev;                    // engine-owned copy of the task ids (stable address for captured graphs)
     float* cache;
-    float *agent_c, *hbuf[2], *hnorm, *rlogits, *term_pool, *term_logit, *splitk, *l_dwpart = nullptr;
+    float *agent_c, *hbuf[2], *hnorm, *rlogits, *term_pool, *term_logit, *l_dwpart = nullptr;
 
     // ---- learner (workspace; sized by max_learn_rows)
     int LR = 0;

@@ -184,7 +184,6 @@ int engine_layout(d4_engine* e, bool assign) {
     e->rlogits = fl((size_t)e->maxB * c.reward_num_bins);
     e->term_pool = fl((size_t)e->maxB * dl);
     e->term_logit = fl(e->maxB);
-    e->splitk = fl(hb * 8);                // split-K partials of the head GEMMs (up to 8 K-slices)
 
     // learner
     e->LR = c.max_learn_rows;
@@ -1498,11 +1497,18 @@ int d4_debug_switch(const char* name, int value) {
     return old;
 }
 int d4_gemm_force_config(int id) {
-    if (id >= 500 || id == -1) d4::gemm_bf16a_force_config(id >= 500 ? id - 500 : -1);    // 500 + c: tile configuration c of the bf16-activation kernel (gemm_bf16a.hip)
-    if (id >= 500) return d4::gemm_force_config(-1);
-    if (id >= 300) return d4::gemm_force_config(id);           // 300 + c: tile c of the split-operand fp32 family (gemm_x3.hip); 400 + c: of the fp16x2 family (gemm_h2.hip)
-    if (id >= 200 || id == -1) d4::gemm_bf16_force_config(id >= 200 ? id - 200 : -1);
-    return d4::gemm_force_config(id >= 200 ? -1 : id);
+    // one family is forced at a time; every call first clears the hooks of the other families, and returns the number of configurations of the family
+    // it addressed (id < 0: everything back to the rules / the tuner, returns the first family's count)
+    d4::gemm_bf16a_force_config(-1);
+    d4::gemm_bf16_force_config(-1);
+    const int n_main = d4::gemm_force_config(-1);
+    if (id < 0) return n_main;
+    if (id >= 500) { d4::gemm_bf16a_force_config(id - 500); return d4::gemm_bf16a_configs(); }     // tile c of the bf16-activation kernel (gemm_bf16a.hip)
+    if (id >= 400) { d4::gemm_force_config(id); return d4::gemm_h2_configs(); }                     // tile c of the fp16x2 family (gemm_h2.hip)
+    if (id >= 300) { d4::gemm_force_config(id); return d4::gemm_x3_configs(); }                     // tile c of the split-operand fp32 family (gemm_x3.hip)
+    if (id >= 200) return d4::gemm_bf16_force_config(id - 200);                                     // configuration c of the fp32-activation bf16 kernel
+    d4::gemm_force_config(id);                                                                      // < 100 first fp32 family, 100 + c second (gemm2.hip)
+    return id >= 100 ? d4::gemm2_configs() : n_main;
 }
 const char* d4_profile_class_name(int c) { return d4::gemm_profile_class_name(c); }
 
@@ -1601,6 +1607,17 @@ int d4_gemm_bf16a(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, floa
     g.Ab = Ab; g.Wb = Wb; g.Cb = Cb;
     D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a: call not supported (K %% 64, lda / ldw %% 8, 16-byte aligned operands)");
     if (config >= 100) { g.group_m = -1; config -= 100; }       // 100 + c: configuration c with the plain row-major tile order (A/B of the grouped order)
+    return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
+}
+
+int d4_gemm_bf16a_compact(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
+                          int M, int N, int K, int flags, float rms_eps, float* C2, uint16_t* C2b, int ldc2, int c2_S, int c2_lo, int c2_hi, int c2_last,
+                          int config, void* stream) {
+    d4::GemmArgs g{nullptr, lda, nullptr, ldw, C, ldc, bias, R, ldr, M, N, K, flags, rms_eps};
+    g.Ab = Ab; g.Wb = Wb; g.Cb = Cb;
+    g.C2 = C2; g.C2b = C2b; g.ldc2 = ldc2; g.c2_S = c2_S; g.c2_lo = c2_lo; g.c2_hi = c2_hi; g.c2_last = c2_last;
+    D4_REQUIRE(C2 && c2_S >= 1 && c2_lo >= 0 && c2_hi >= c2_lo && c2_hi <= c2_S, "d4_gemm_bf16a_compact: bad compaction arguments");
+    D4_REQUIRE(d4::gemm_bf16a_applicable(g), "d4_gemm_bf16a_compact: call not supported (K %% 64, lda / ldw %% 8, 16-byte aligned operands)");
     return d4::gemm_bf16a_launch(config >= 0 ? config : d4::gemm_bf16a_rule(g), g, static_cast<hipStream_t>(stream));
 }
 

@@ -629,6 +629,9 @@ static int launch_t(const GemmArgs& p, hipStream_t stream) {
     (void)hipStreamIsCapturing(stream, &cap);
     if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
         return launch_id<TA, TB>(heuristic_cfg<TA, TB>(p), p, stream);
+    // strict mode: a FEW-ROW product missing from the table (the heads' MLPs at a per-rank batch other than the shipped 256: M = the batch) takes the static
+    // choice — a rule on the shape, so every rank still makes the same one without a clock; anything larger must be in the table
+    if (tune_mode() == 2 && p.M <= 512) return launch_id<TA, TB>(heuristic_cfg<TA, TB>(p), p, stream);
     D4_TUNE_STRICT_CHECK(p, nb);
     int best = 0;
     if (int rc = autotune<TA, TB>(p, stream, &best)) return rc;
@@ -707,6 +710,7 @@ static int gemm_v2(const GemmArgs& p, hipStream_t stream) {
     (void)hipStreamIsCapturing(stream, &cap);
     if (!tune_on || !idempotent || cap != hipStreamCaptureStatusNone || 2.0 * p.M * p.N * p.K * nb < 1e8)
         return launch_v2(heuristic_v2(p), p, stream);
+    if (tune_mode() == 2 && p.M <= 512) return launch_v2(heuristic_v2(p), p, stream);      // strict mode, few-row product missing from the table: the static rule (see launch_t)
     D4_TUNE_STRICT_CHECK(p, nb);
     int best = 0;
     if (int rc = autotune_v2(p, stream, &best)) return rc;

@@ -525,6 +525,7 @@ static int learn_empty_shard(d4_engine* e, const d4_learn_io* io, hipStream_t s)
     const d4_config& c = e->c;
     int rc;
     float* scal = e->l_scal;
+    D4_REQUIRE(e->LR > 0 && scal, "learn: an empty shard still needs an engine created with max_learn_rows >= 1 (the learner's scalar workspace)");
     D4_HIP(hipMemsetAsync(scal, 0, 64 * sizeof(float), s));
     if ((rc = io->allreduce_sum(scal, 2, io->allreduce_user)) || (rc = io->allreduce_sum(scal + 2, 1, io->allreduce_user)) ||
         (rc = io->allreduce_sum(scal + 4, 4, io->allreduce_user))) { set_error("allreduce callback failed (%d)", rc); return 5; }

@@ -133,12 +133,12 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
         actions = exp.actions.discrete
         actions = actions[..., None] if actions.ndim == 2 else actions
         actions = bt(actions).long()
-        old_lp = bt(exp.log_probs.discrete.float().reshape(B, -1, na))
+        old_lp = bt(exp.log_probs.discrete.float().reshape(B, exp.log_probs.discrete.shape[1], na))      # (explicit time length: -1 is ambiguous for an empty shard)
     if nc > 0:
         actions_c = exp.actions.continuous
         actions_c = actions_c[..., None] if actions_c.ndim == 2 else actions_c
         actions_c = bt(actions_c.float())
-        old_lp_c = bt(exp.log_probs.continuous.float().reshape(B, -1, nc))
+        old_lp_c = bt(exp.log_probs.continuous.float().reshape(B, exp.log_probs.continuous.shape[1], nc))
     old_values = bt(exp.values.float())
     rewards = bt(exp.rewards.float())
     old_logits = old_cparams = None
@@ -153,7 +153,7 @@ def run_learner(model, experience: Experience, objective='ppo', use_delight_gati
     trunc = trunc.to(torch.uint8).contiguous()
     terms = exp.terminals.to(torch.uint8).contiguous() if exp.terminals is not None else None
 
-    model._ensure_engine(learn_rows=B * T)
+    model._ensure_engine(learn_rows=max(B * T, 1))       # (an EMPTY trajectory shard still needs the learner's scalar workspace for the collectives it joins)
     lib = _lib.load()
     losses = torch.zeros(2, device=dev)
     returns = torch.empty(B, T, device=dev) if want_returns else None

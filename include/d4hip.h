@@ -260,7 +260,9 @@ int d4_measure_peaks(void* scratch, size_t scratch_bytes, double* hbm_copy_gbs, 
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
  * split-operand fp32 family (gemm_x3.hip); 400 + c: tile c of the fp16x2 family (gemm_h2.hip); 500 + c: tile c of the bf16-activation kernel (gemm_bf16a.hip).
- * Returns the number of configurations.  Every configuration must produce the same bits (tests/test_gpu_kernels.py). */
+ * ONE family is forced at a time: every call first clears the hooks of the other families (so forcing, say, 400 + c also switches off the special forms
+ * that only run un-forced: the persistent split-operand kernel, the pair launches).  Returns the number of configurations of the family addressed
+ * (id = -1: of the first family).  Every configuration of a family must produce the same bits (tests/test_gpu_kernels.py). */
 /* Test hook for the per-frame fused block tails (csrc/frame_fused.hip; default 1): 0 separate kernels, 1 fused, 2 fused tails with the
  * pool mix as its own kernel.  Returns the previous mode.  Which path runs is otherwise a rule on the call's shape. */
 int d4_frame_fused_set(int mode);
@@ -306,6 +308,12 @@ int d4_cvt_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);
  * 2105-2116, 2143-2177; here a bf16 IMAGE of it is what the next Linear reads): C may be NULL when only the bf16 image Cb is wanted; `batch` > 1 runs
  * `batch` independent products A + b * strideA, Wb + b * strideW -> C / Cb + b * strideC (the attention pool's per-head value projection).
  * d4_cvt_rows_bf16: rows x cols of a strided fp32 matrix -> bf16 (round to nearest even), the pass behind producers that cannot write the image. */
+/* ... with the engine's second, ROW-COMPACTED copy of the output (the rows the final attention pool and the latent head read: token rows s = m % c2_S with
+ * c2_lo <= s < c2_hi, plus the last token of a frame when c2_last; fp32 `C2` and optionally its bf16 image `C2b`, [frames * (c2_hi - c2_lo + c2_last)][ldc2]).
+ * It replaces the reference's indexing of the layer hiddens at D4:3242-3246 / 7251 (the trunk keeps every token row; only these are consumed). */
+int d4_gemm_bf16a_compact(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
+                          int M, int N, int K, int flags, float rms_eps, float* C2, uint16_t* C2b, int ldc2, int c2_S, int c2_lo, int c2_hi, int c2_last,
+                          int config, void* stream);
 int d4_gemm_bf16a_batched(const uint16_t* Ab, int lda, const uint16_t* Wb, int ldw, float* C, int ldc, uint16_t* Cb, const float* bias, const float* R, int ldr,
                           int M, int N, int K, int flags, float rms_eps, int batch, int64_t strideA, int64_t strideW, int64_t strideC, int config, void* stream);
 int d4_cvt_rows_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int rows, int cols, void* stream);

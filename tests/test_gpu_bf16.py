@@ -48,7 +48,7 @@ def test_gemm_bf16_kernel(M, N, K, flags):
 
 
 @pytest.mark.parametrize('M,N,K,flags', [(128, 128, 64, 0), (1792, 1024, 512, 0), (200, 300, 128, 1), (1920, 2752, 1024, 5), (45, 388, 64, 3), (1792, 1552, 1024, 1),
-                                         (17, 64, 2752, 0), (700, 520, 192, 1), (515, 1088, 320, 5)])
+                                         (17, 64, 2752, 0), (700, 520, 192, 1), (515, 1088, 320, 5), (130, 390, 128, 1)])
 def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
     """gemm_bf16a.hip (d4_gemm_bf16a): both operands bf16 in HBM, LDS-DMA ring, v_mfma_f32_16x16x32_bf16.  Every tile configuration against a
     float64 product of the SAME bf16 operands (row scale from the bf16 activations), all epilogues, partial tiles; the bf16 copy of the output
@@ -89,6 +89,30 @@ def test_gemm_bf16_with_bf16_activations_every_configuration(M, N, K, flags):
     assert ran >= 4
     with pytest.raises(_lib.D4Error, match='not supported'):
         _lib.check(lib.d4_gemm_bf16a(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), Nout, None, None, None, 0, M, N, 96, 0, eps, -1, stream()))
+
+
+@pytest.mark.parametrize('frames,S,N,K,lo,hi,last', [(40, 15, 512, 128, 1, 5, 1), (37, 14, 320, 64, 1, 5, 0), (300, 15, 1024, 256, 1, 5, 1)])
+def test_gemm_bf16a_row_compacted_second_output(frames, S, N, K, lo, hi, last):
+    """The engine's second output of a residual-stream GEMM: the token rows the final attention pool / latent head read (tokens [lo, hi) of every frame of S
+    tokens, plus the frame's last token when `last`), fp32 and its bf16 image, written by the same epilogue — every tile configuration (the phased
+    256 x 256 form stages its epilogue through LDS: rows are re-assigned to lanes there) equals a row gather of the full output."""
+    lib = _lib.load()
+    g = torch.Generator(device='cuda').manual_seed(1)
+    M = frames * S
+    Ab = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16).contiguous()
+    Wb = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).to(torch.bfloat16).contiguous()
+    R = torch.randn(M, N, device='cuda', generator=g)
+    keep = hi - lo + last
+    rows = torch.tensor([f * S + t for f in range(frames) for t in list(range(lo, hi)) + ([S - 1] if last else [])], device='cuda')
+    for cfg in (-1, 0, 1, 2, 3, 4, 5, 6, 7):
+        out = torch.full((M, N), float('nan'), device='cuda'); outb = torch.zeros(M, N, device='cuda', dtype=torch.bfloat16)
+        c2 = torch.full((frames * keep, N), float('nan'), device='cuda'); c2b = torch.zeros(frames * keep, N, device='cuda', dtype=torch.bfloat16)
+        _lib.check(lib.d4_gemm_bf16a_compact(_lib.ptr(Ab), K, _lib.ptr(Wb), K, _lib.ptr(out), N, _lib.ptr(outb), None, _lib.ptr(R), N, M, N, K, 0, 1e-6,
+                                             _lib.ptr(c2), _lib.ptr(c2b), N, S, lo, hi, last, cfg, stream()))
+        torch.cuda.synchronize()
+        ref = Ab.double() @ Wb.double().t() + R.double()
+        assert (out.double() - ref).abs().max().item() <= 3e-6 * max(1., ref.abs().max().item()), cfg
+        assert torch.equal(c2, out[rows]) and torch.equal(c2b, outb[rows]) and torch.equal(outb, out.to(torch.bfloat16)), cfg
 
 
 @pytest.mark.parametrize('M,N,K,flags,batch', [(1792, 1024, 512, 0, 1), (1920, 2752, 1024, 5, 1), (1792, 64, 1024, 0, 4), (130, 256, 192, 1, 1)])
