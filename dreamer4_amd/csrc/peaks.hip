@@ -9,13 +9,15 @@
 namespace d4 {
 
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {                     // four 16-byte loads in flight per lane
-        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    // a block moves contiguous 16 KB pieces (4 x 256 lanes x 16 B), four 16-byte loads in flight per lane, non-temporal both ways
+    const int64_t step = (int64_t)gridDim.x * 1024;
+    int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 768 < n4; i += step) {
+        const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + 256);
+        const f32x4 c = __builtin_nontemporal_load(src + i + 512), d = __builtin_nontemporal_load(src + i + 768);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + 256);
+        __builtin_nontemporal_store(c, dst + i + 512); __builtin_nontemporal_store(d, dst + i + 768);
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 typedef __bf16 bf16x8_k __attribute__((ext_vector_type(8)));
@@ -59,19 +61,19 @@ extern "C" int d4_measure_peaks(void* scratch, size_t scratch_bytes, double* hbm
     float ms = 0.f;
     // ---- stream copy
     const size_t half = (scratch_bytes / 2) & ~(size_t)255;
-    const int64_t n4 = (int64_t)(half / 16);
+    const int64_t n4 = (int64_t)(half / 16) & ~(int64_t)1023;          // whole 16 KB pieces
     const f32x4* src = static_cast<const f32x4*>(scratch);
     f32x4* dst = reinterpret_cast<f32x4*>(static_cast<char*>(scratch) + half);
     D4_HIP(hipMemsetAsync(scratch, 0x3c, half, s));
     const int reps = 4;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(n_cu * 8), dim3(256), 0, s, src, dst, n4);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(n_cu * 16), dim3(256), 0, s, src, dst, n4);
     D4_HIP(hipEventRecord(e0, s));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_copy_kernel, dim3(n_cu * 8), dim3(256), 0, s, src, dst, n4);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_copy_kernel, dim3(n_cu * 16), dim3(256), 0, s, src, dst, n4);
     D4_HIP(hipEventRecord(e1, s));
     D4_HIP(hipEventSynchronize(e1));
     D4_LAUNCH_CHECK();
     D4_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *hbm_copy_gbs = 2.0 * (double)half * reps / (ms * 1e-3) / 1e9;
+    *hbm_copy_gbs = 2.0 * (double)n4 * 16.0 * reps / (ms * 1e-3) / 1e9;
     // ---- matrix pipes: random operands from a small table at the start of the scratch buffer, results behind it
     static float host[8192];
     unsigned seed = 12345u;
