@@ -491,7 +491,12 @@ __global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int l = l0 + 4 * j;
-            kv[j] = l < L ? *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (l >= L) kv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else if (p.k_b) {                            // bf16 keys (bf16 engine: the only copy)
+                const uint2 raw = *reinterpret_cast<const uint2*>(p.k_b + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
+                kv[j] = f32x4{__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
+                              __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
+            } else kv[j] = *reinterpret_cast<const f32x4*>(p.k + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
         }
     };
     auto load_hid = [&](int l0, f32x4 (&v)[4][ITER]) {

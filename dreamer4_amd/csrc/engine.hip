@@ -151,6 +151,10 @@ int engine_layout(d4_engine* e, bool assign) {
         sh(e->ffh, M * e->inner_pad, consumer_takes_images(e->inner_pad, e->inner_pad, e->inner_pad, 1, 0, 0));
         sh(e->pool_att, M * hp, consumer_takes_images(hp, hp, hp, 1, 0, 0));
         sh(e->pool_u, M * (size_t)e->php * D, consumer_takes_images(D, e->php * D, D, e->php, D, (int64_t)64 * D));
+        // the attention pools' projected KEYS (mix path): written as a bf16 image only — the pool's key projection at N = 256 is bound by its output
+        // bytes (170 flop per byte with fp32 keys), and the pool mix reads every key row once: half the bytes on both sides.  The scores then see keys
+        // rounded to bf16 like every other activation of this mode.
+        if (c.pool_heads == 4 && D <= 1024) sh(e->pool_kv, (size_t)e->nslab * M * 2 * hp, true);
     }
     e->cq = fl(Fr * KQ * e->ldcq);
     e->ckv = fl(M * 2 * hd);
@@ -526,7 +530,7 @@ static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
     // bf16 engine: both activations have bf16 images and neither output has one -> one grid on the bf16-activation kernel (the pool's query
     // projection rides in the key projection's launch)
     if (d4_engine* e = t_bf16) {
-        if (!e->fp32_planes() && !e->shadows.empty() && !e->shadow_of(a.C) && !e->shadow_of(b.C)) {
+        if (!e->fp32_planes() && !e->shadows.empty()) {
             GemmArgs pa = a, pb = b;
             bool ok = true;
             for (GemmArgs* g : {&pa, &pb}) {
@@ -535,6 +539,8 @@ static int gemm_two(GemmArgs a, GemmArgs b, hipStream_t s) {
                     if (g->W >= m.src && g->W < m.src + m.n) { g->Wb = m.dst + (g->W - m.src); break; }
                 g->Ab = e->shadow_of(g->A);
                 ok = ok && g->Wb && g->Ab;
+                g->Cb = e->shadow_of(g->C);                                   // an output with an image: written by the same epilogue,
+                if (g->Cb && e->shadow_only(g->C)) g->C = nullptr;            // ... alone when nothing reads the fp32 values (the pools' keys)
             }
             if (ok && gemm_bf16a_pair_applicable(pa, pb)) return gemm_bf16a_pair(pa, pb, s);
         }
@@ -725,6 +731,7 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
         pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
         if (t_bf16 && D > 512) pm.hid_b = t_bf16->shadow_of(hiddens);     // (D <= 512 may take the block-per-row form, which reads fp32)
+        if (t_bf16) pm.k_b = t_bf16->shadow_of(e->pool_kv);               // bf16 keys (the only copy of them in this mode)
         if (t_bf16) if (uint16_t* ub = t_bf16->shadow_of(e->pool_u)) { pm.u_b = ub; if (t_bf16->shadow_only(e->pool_u)) pm.u = nullptr; }   // only the value GEMM reads the mixes
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
         // frame_fused mode 2 (test hook): the mix stays its own kernel and only the tail is fused

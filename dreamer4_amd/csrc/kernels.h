@@ -153,6 +153,7 @@ struct PoolMixArgs {
     int M, L, heads;
     float eps;
     uint16_t* u_b = nullptr;           // optional bf16 image of u (bf16 engine: the per-head value GEMM reads this one)
+    const uint16_t* k_b = nullptr;     // optional bf16 image of the projected keys (same [L*M][ldk] layout; bf16 engine): read INSTEAD of `k`
     const uint16_t* hid_b = nullptr;   // optional bf16 image of the hiddens (bf16 engine): read instead of `hid` by the one-wave-per-row form — the
                                        // values the pool's key GEMM consumed, at half the bytes of the kernel's dominant stream
 };

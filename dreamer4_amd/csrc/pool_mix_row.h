@@ -36,7 +36,12 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
         f32x4 kb[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j)
-            kb[j] = l0 + j < L ? *reinterpret_cast<const f32x4*>(p.k + ((int64_t)(l0 + j) * p.M + m) * p.ldk + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (l0 + j >= L) kb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            else if (p.k_b) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(p.k_b + ((int64_t)(l0 + j) * p.M + m) * p.ldk + lane * 4);
+                kb[j] = f32x4{__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
+                              __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
+            } else kb[j] = *reinterpret_cast<const f32x4*>(p.k + ((int64_t)(l0 + j) * p.M + m) * p.ldk + lane * 4);
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const int l = l0 + j;
