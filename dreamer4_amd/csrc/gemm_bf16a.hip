@@ -489,7 +489,9 @@ int gemm_bf16a_rule(const GemmArgs& p) {
         // the square tile stays (193 vs 216 us)
         const int64_t c256 = t256 >= 140 ? (int64_t)cdiv(t256, 256) * 256 * 256 : INT64_MAX;
         const int64_t c192 = t192 >= 140 ? (int64_t)cdiv(t192, 256) * 256 * 192 : INT64_MAX;
-        return c192 < c256 ? VA_256x192 : VA_256x256;
+        // (round 6: the 256 x 256 form is the phased kernel, ~15 % faster per tile area than the two-slot structure the 256 x 192 form still has —
+        //  tools/bf16p_probe.py: 14336 x 1552 68 vs 67 us, 14336 x 5504 154 vs 196 us, 1792 x 5504 27.5 vs 26.8 us)
+        return (double)c192 < 0.85 * (double)c256 ? VA_256x192 : VA_256x256;
     }
     if (swiglu) return t128 >= 200 ? VA_128x128 : VA_64x64_s;
     if (t128 >= 400 && p.N >= 128) return VA_128x128;
