@@ -447,7 +447,7 @@ int small_attn(const SmallAttnArgs& p, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------
 // AttentionPool (D4:2143-2177) with the value side restructured (see PoolMixArgs).  One wave per token row.
-template <int ITER, bool DEEP = false>
+template <int ITER, bool DEEP = false, bool KB16 = false>
 __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     constexpr int PH = 4, LMAX = 64;
     __shared__ float psh[4][LMAX * PH];
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
     const int m = blockIdx.x * 4 + wslot;
     if (m >= p.M) return;
     const int lane = threadIdx.x & 63;
-    pool_mix_row<ITER, DEEP>(p, m, lane, psh[wslot], gws, [&](int h, int c4, const f32x4& v) {
+    pool_mix_row<ITER, DEEP, KB16>(p, m, lane, psh[wslot], gws, [&](int h, int c4, const f32x4& v) {
         if (p.u) reinterpret_cast<f32x4*>(p.u + ((int64_t)m * PH + h) * D)[c4] = v;
         if (p.u_b) store_bf16x4(p.u_b + ((int64_t)m * PH + h) * D + 4 * c4, v);
     });
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void pool_mix_kernel(PoolMixArgs p) {
 // hiddens (l = w, w + 4, ...) so every wave has all of its loads in flight at once — with one wave per row the kernel is L
 // dependent memory round trips long (12 us at L = 13).  The partial mixes are folded through LDS in wave order (fixed).  Chosen by
 // M alone (pool_mix below), so a given shape always takes the same arithmetic path.
-template <int ITER>
+template <int ITER, bool KB16 = false>
 __global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
     constexpr int PH = 4, LMAX = 64;
     __shared__ float ps[LMAX * PH];
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
         for (int j = 0; j < 4; ++j) {
             const int l = l0 + 4 * j;
             if (l >= L) kv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            else if (p.k_b) {                            // bf16 keys (bf16 engine: the only copy)
+            else if constexpr (KB16) {                   // bf16 keys (bf16 engine: the only copy)
                 const uint2 raw = *reinterpret_cast<const uint2*>(p.k_b + ((int64_t)l * p.M + m) * p.ldk + lane * 4);
                 kv[j] = f32x4{__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
                               __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
@@ -628,21 +628,24 @@ int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     // one block per row (its four waves split the hiddens) while that leaves the CUs short of waves — by M alone: measured at B = 256, L = 13:
     // M = 1280 (the final stage's compacted rows) 24.1 -> 14.3 us, M = 3584 25.3 -> 27.8 us (the wave-per-row form wins once it fills the chip)
     constexpr int rows_max = 2048;
+    const bool kb = p.k_b != nullptr;                // bf16 engine: keys from their bf16 image (template flag of both kernels)
     if (p.M <= rows_max && p.D <= 512) {
         const double rb = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
-        if (p.D <= 256) hipLaunchKernelGGL(pool_mix_rows_kernel<1>, dim3(p.M), block, 0, stream, p);
+        if (p.D <= 256) { if (kb) hipLaunchKernelGGL((pool_mix_rows_kernel<1, true>), dim3(p.M), block, 0, stream, p); else hipLaunchKernelGGL(pool_mix_rows_kernel<1>, dim3(p.M), block, 0, stream, p); }
+        else if (kb) hipLaunchKernelGGL((pool_mix_rows_kernel<2, true>), dim3(p.M), block, 0, stream, p);
         else D4_GLUE_LAUNCH(GL_POOL_MIX, rb, pool_mix_rows_kernel<2>, dim3(p.M), block, 0, stream, p);
         D4_LAUNCH_CHECK();
         return 0;
     }
     // algorithmic bytes: L hiddens + L projected keys per token row, queries + the row itself, the per-head mixes written
     const double pm_bytes = 4.0 * p.M * ((double)p.L * (p.D + p.ldk) + p.ldq + p.D + (double)p.heads * p.D);
-    if (p.D <= 256) hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p);
-    else if (p.D <= 512) D4_GLUE_LAUNCH(GL_POOL_MIX, pm_bytes, pool_mix_kernel<2>, grid, block, 0, stream, p);
+    if (p.D <= 256) { if (kb) hipLaunchKernelGGL((pool_mix_kernel<1, false, true>), grid, block, 0, stream, p); else hipLaunchKernelGGL(pool_mix_kernel<1>, grid, block, 0, stream, p); }
+    else if (p.D <= 512) { if (kb) hipLaunchKernelGGL((pool_mix_kernel<2, false, true>), grid, block, 0, stream, p); else D4_GLUE_LAUNCH(GL_POOL_MIX, pm_bytes, pool_mix_kernel<2>, grid, block, 0, stream, p); }
     // D > 512 (BASELINE config 5: dim 1024, 1792 rows x up to 25 hiddens: 32 us per launch = ~3.6 TB/s of hiddens + keys).  Measured in round 4 and NOT
     // adopted, all level with this form: the deep-prefetch variant, reading the bf16 hidden images (kept: half the bytes), and a block-per-row kernel
     // whose four waves split the features with every load issued up front — the launch is bound by what the memory side delivers for rows that
     // were written many kernels ago, not by the wave structure
+    else if (kb) hipLaunchKernelGGL((pool_mix_kernel<4, false, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL(pool_mix_kernel<4>, grid, block, 0, stream, p);
     D4_LAUNCH_CHECK();
     return 0;

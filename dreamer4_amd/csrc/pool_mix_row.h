@@ -12,7 +12,9 @@ namespace d4 {
 // DEEP: key rows requested in batches of 8 and hidden rows 3 ahead (instead of one load per iteration / one row ahead) — for callers that run
 // few waves per SIMD (the per-frame fused kernel: 2), where a row is otherwise 2 L dependent memory round trips; with 3.5 waves per SIMD the
 // stand-alone kernel is bandwidth-bound and the deeper form measured 5 % slower there.
-template <int ITER, bool DEEP = false, class Store>
+// KB16: the projected keys are read from their bf16 image p.k_b (bf16 engine) instead of p.k — a template flag, not a run-time branch: a branch
+// inside the unrolled load batches keeps the compiler from issuing them together (measured: +26 % on the block-per-row kernel).
+template <int ITER, bool DEEP = false, bool KB16 = false, class Store>
 __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int lane, float* ps, const f32x4* gws, Store store) {
     constexpr int PH = 4;
     const int L = p.L, D = p.D;
@@ -37,7 +39,7 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
 #pragma unroll
         for (int j = 0; j < KB; ++j)
             if (l0 + j >= L) kb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            else if (p.k_b) {
+            else if constexpr (KB16) {
                 const uint2 raw = *reinterpret_cast<const uint2*>(p.k_b + ((int64_t)(l0 + j) * p.M + m) * p.ldk + lane * 4);
                 kb[j] = f32x4{__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
                               __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
