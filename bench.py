@@ -483,7 +483,7 @@ def main():
     ev_ms_per_step = None
     if timing:
         psteps = max(1, min(args.steps, 3))
-        lib.d4_profile_enable(((1 << dom) | ((1 << dom2) if dom2 is not None else 0)) | (EVENT_STRIDE << 26))
+        lib.d4_profile_enable(((1 << dom) | ((1 << dom2) if dom2 is not None else 0)) | (EVENT_STRIDE << 27))
         torch.cuda.synchronize()
         tp = time.perf_counter()
         for k in range(psteps):

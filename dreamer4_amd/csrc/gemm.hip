@@ -355,8 +355,8 @@ bool gemm_profile_active() { return g_prof_mask != 0 || gemm_bf16_profile_active
 static std::recursive_mutex& gemm_mutex();
 int gemm_profile_enable(int mask) {
     std::lock_guard<std::recursive_mutex> lock(gemm_mutex());
-    g_prof_stride = (mask >> 26) > 0 ? (mask >> 26) : 1;          // bits 26..30: stride; bits 0..25: configurations
-    mask &= 0x3FFFFFF;
+    g_prof_stride = (mask >> 27) > 0 ? (mask >> 27) : 1;          // bits 27..30: stride; bits 0..26: configurations (27 classes since round 6)
+    mask &= 0x7FFFFFF;
     g_prof_tick = 0;
     g_prof_mask = mask;
     return 0;
@@ -442,8 +442,9 @@ static const char* const kTileKernel[N_TILE_CFG] = {
     "gemm_kernel<128, 128, 2, 4, 32, 1", "gemm_kernel<128, 128, 4, 2, 32, 1", "gemm_kernel<128, 96, 4, 1, 32, 1", "gemm_kernel<64, 128, 2, 2, 32, 1",
     "gemm_kernel<64, 64, 2, 2, 32, 1", "gemm_kernel<256, 128, 4, 4, 32, 1", "gemm_kernel<64, 128, 2, 2, 16, 1", "gemm_kernel<64, 64, 2, 2, 16, 1"};
 // profile classes: the N_TILE_CFG configurations of this family, then the configurations of the second family (gemm2.hip)
-int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 2; }     // + the persistent split-operand form (gemm_x3sk.hip) + the fp16x2 family (gemm_h2.hip, one class)
+int gemm_profile_classes() { return N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 3; }     // + the persistent split-operand form (gemm_x3sk.hip) + the fp16x2 family (gemm_h2.hip, one class) + the few-row k-split form (gemm2.hip)
 const char* gemm_profile_class_name(int c) {
+    if (c == N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 2) return "gemm2_ksplit_kernel";
     if (c == N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 1) return "gemm_h2_kernel";
     if (c == N_TILE_CFG + gemm2_configs() + gemm_x3_configs()) return gemm_x3sk_name();
     if (c >= N_TILE_CFG + gemm2_configs()) return gemm_x3_config_name(c - N_TILE_CFG - gemm2_configs());
@@ -651,6 +652,20 @@ static int launch_v2(int c, const GemmArgs& p, hipStream_t stream) {
     gemm2_config_tile(c, &rec.bm, &rec.bn);
     rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K * (p.batch > 0 ? p.batch : 1);
     if (int rc = gemm2_launch(c, p, stream, rec.a, rec.b)) return rc;
+    g_prof.push_back(rec);
+    return 0;
+}
+
+static int launch_v2ks(const GemmArgs& p, hipStream_t stream) {
+    const int cls = N_TILE_CFG + gemm2_configs() + gemm_x3_configs() + 2;
+    const bool timed = ((g_prof_mask >> cls) & 1) && (g_prof_tick++ % g_prof_stride) == 0;
+    if (!timed) return gemm2_ksplit_launch(p, stream);
+    ProfRec rec{};
+    rec.a = prof_event(); rec.b = prof_event(); rec.cls = cls;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.flags = p.flags; rec.batch = p.batch;
+    rec.bm = 32; rec.bn = 64;
+    rec.flops = p.algo_flops > 0 ? p.algo_flops : 2.0 * p.M * p.N * p.K;
+    if (int rc = gemm2_ksplit_launch(p, stream, rec.a, rec.b)) return rc;
     g_prof.push_back(rec);
     return 0;
 }
@@ -962,6 +977,8 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     // test hook: 100 + c forces configuration c of the second family, 0 .. N_TILE_CFG-1 a configuration of this one
     if (g_forced_cfg >= 100 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);
     if (gemm_skinny_applicable(p)) return gemm_skinny(p, stream);
+    // few rows x long K (the heads' hidden layers at rollout batch): the contraction cut four ways inside the workgroup — a rule on the shape
+    if (g_forced_cfg < 0 && gemm2_ksplit_rule(p)) return launch_v2ks(p, stream);
     if ((g_forced_cfg < 0 || g_forced_cfg >= 300) && use_v2(p)) return gemm_v2(p, stream);      // (300 + c forces a tile of the split-operand family only)
     if (!ta && !tb) return launch_t<false, false>(p, stream);
     if (!ta && tb) return launch_t<false, true>(p, stream);

@@ -318,6 +318,163 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm2_pair_kernel(GemmArgs a, G
     else gemm2_body<WGM, WGN, TM, TN, NS, BK, RMS>(b, bid - nblk_a, 0);
 }
 
+// ---- few rows x long K: the contraction cut FOUR ways inside the workgroup (round 6) ---------------------------------------------------
+// The heads' hidden layers at rollout batch (256 x 2048 x 2048, 128 x 4096 x 4096 at config 5) are 512 tiles of 32 x 32 whose 64 k-tiles run one after
+// the other: 40 us of k-loop LATENCY at 54 TF/s with half the chip idle.  Here a workgroup of 16 waves owns one 32 x 64 tile and its four wave groups
+// (each exactly the 32 x 64 configuration above: 2 x 2 waves, wave tile 16 x 32, its own ring of three stages) each multiply one QUARTER of K; the four
+// partial tiles meet in LDS (the rings are free by then) and are summed in group order — a fixed order, nothing crosses between workgroups, no atomics:
+// deterministic, but NOT the bits of the family's other configurations (their k order is one chain), so this form is taken by a RULE on the shape
+// (gemm2_ksplit_rule), never by the tuner.  Epilogue on the row-contiguous image: bias, SiLU, residual, 16-byte stores.
+constexpr int KS_GROUPS = 4, KS_NS = 3, KS_BM = 32, KS_BN = 64, KS_BK = 32;
+constexpr int KS_STAGE_F = (KS_BM + KS_BN) * KS_BK;                 // floats per ring stage of one group
+constexpr int KS_RING_F = KS_NS * KS_STAGE_F;                       // 9216 floats = 36 KB per group
+constexpr int KS_LDP = KS_BN + 4;                                   // partial tile row stride (floats)
+
+__global__ __launch_bounds__(1024) void gemm2_ksplit_kernel(GemmArgs p) {
+    constexpr int BK = KS_BK, CH = 8, RPP = 8, BM = KS_BM, BN = KS_BN, NS = KS_NS, LPW = 3, NSLOT = (BM + BN) / RPP;      // 12 pieces per stage, 3 per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // [4 groups][3 stages][96 rows][32]; afterwards [4][32][68] partial tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w = wave & 3, wm = w >> 1, wn = w & 1;
+    int bid = blockIdx.x;
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    {
+        const int nblk = nbm * nbn, nx = 8;
+        const int q = nblk / nx, r = nblk % nx, x = bid % nx, o = bid / nx;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    }
+    const int bm0 = (bid / nbn) * BM, bn0 = (bid % nbn) * BN;
+    const int rowsA = min(BM, p.M - bm0), rowsB = min(BN, p.N - bn0);
+    auto uniform_rsrc = [](const float* base, int64_t bytes) {
+        const uint64_t b = reinterpret_cast<uint64_t>(base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+        const int nb = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7FFFFFFF ? bytes : 0x7FFFFFFF));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, nb, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsA = uniform_rsrc(p.A + (int64_t)bm0 * p.lda, ((int64_t)(rowsA - 1) * p.lda + p.K) * 4);
+    const __amdgpu_buffer_rsrc_t rsB = uniform_rsrc(p.W + (int64_t)bn0 * p.ldw, ((int64_t)(rowsB - 1) * p.ldw + p.K) * 4);
+    uint32_t voff[LPW];
+    const int prow = lane / CH;
+    const int src_chunk = (lane % CH) ^ chunk_swizzle<BK>(prow);
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int slot = w + 4 * i;
+        const int r = slot * RPP + prow;
+        voff[i] = (uint32_t)((slot * RPP < BM ? r * p.lda : (r - BM) * p.ldw) * 4 + src_chunk * 16);
+    }
+    float* ring = smem + grp * KS_RING_F;
+    const int nk = p.K / (BK * KS_GROUPS), kt0 = grp * nk;          // this group's k-tiles
+#define D4_KS_ISSUE(KT, BUF)                                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < LPW; ++i_) {                                                                           \
+        const int slot_ = w + 4 * i_;                                                                                               \
+        float* dst_ = ring + (BUF) * KS_STAGE_F + slot_ * 256;                                                                      \
+        if (slot_ * RPP < BM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)dst_, 16, (uint32_t)voff[i_], (kt0 + (KT)) * BK * 4, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)dst_, 16, (uint32_t)voff[i_], (kt0 + (KT)) * BK * 4, 0, 0);              \
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int kq = lane >> 4, frow = lane & 15;
+    const int foff0 = frow * BK + ((kq ^ chunk_swizzle<BK>(frow)) << 2);
+    const int a_base = wm * 16 * BK, b_base = BM * BK + wn * 32 * BK;
+    auto wait_allow = [&](int stages) {
+        if (stages >= 2) wait_vmcnt<2 * LPW>();
+        else if (stages == 1) wait_vmcnt<LPW>();
+        else wait_vmcnt<0>();
+    };
+    f32x4 af[2], bf[2][2];
+    auto read_frags = [&](const float* st, int set, int second_half) {
+        const int fo = second_half ? (foff0 ^ 16) : foff0;
+        af[set] = *reinterpret_cast<const f32x4*>(st + a_base + fo);
+        bf[set][0] = *reinterpret_cast<const f32x4*>(st + b_base + fo);
+        bf[set][1] = *reinterpret_cast<const f32x4*>(st + b_base + 16 * BK + fo);
+    };
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) { D4_KS_ISSUE(st, st) }
+    wait_allow(min(NS - 2, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    read_frags(ring, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            wait_allow(min(kt + NS - 2, nk - 1) - (kt + 1));
+            __builtin_amdgcn_s_barrier();
+            if (kt + NS - 1 < nk) { D4_KS_ISSUE(kt + NS - 1, (kt + NS - 1) % NS) }
+        }
+        const float* st = ring + (kt % NS) * KS_STAGE_F;
+        const float* nxt = ring + ((kt + 1) % NS) * KS_STAGE_F;
+        read_frags(st, 1, 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[0][j][e], af[0][e], acc[j], 0, 0, 0);
+        if (kt + 1 < nk) read_frags(nxt, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[1][j][e], af[1][e], acc[j], 0, 0, 0);
+    }
+#undef D4_KS_ISSUE
+    __syncthreads();                                                 // every group is past its last fragment read: the rings become the partial tiles
+    float* part = smem + grp * KS_RING_F;                            // [32][KS_LDP]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<f32x4*>(part + (wm * 16 + frow) * KS_LDP + wn * 32 + j * 16 + kq * 4) = acc[j];
+    __syncthreads();
+    if (tid >= BM * BN / 4) return;
+    const int row = tid / (BN / 4), c4 = (tid % (BN / 4)) * 4;
+    const int gm = bm0 + row, gn = bn0 + c4;
+    if (gm >= p.M || gn >= p.N) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * KS_LDP + c4);
+#pragma unroll
+    for (int g = 1; g < KS_GROUPS; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(smem + g * KS_RING_F + row * KS_LDP + c4);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    const bool full = gn + 3 < p.N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (!full && gn + e >= p.N) continue;
+        float x = v[e];
+        if (p.bias) x += p.bias[gn + e];
+        if (p.flags & GEMM_SILU) x = siluf(x);
+        if (p.R) x += p.R[(int64_t)gm * p.ldr + gn + e];
+        v[e] = x;
+    }
+    float* cp = p.C + (int64_t)gm * p.ldc + gn;
+    if (full && (p.ldc % 4) == 0 && ((uintptr_t)p.C % 16) == 0) *reinterpret_cast<f32x4*>(cp) = v;
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (full || gn + e < p.N) cp[e] = v[e];
+    }
+}
+
+// Measured (tools/gemm2_ksplit_probe.py, profiles/r06_gemm2_ksplit.txt): 256 x 2048 x 2048 27.2 us against 30.8 us for the best tiled configuration (40 us in
+// situ), 128 x 4096 x 4096 46 against 55 us; 512 rows lose (51.5 vs 44.8 us) -> at most 256 rows.  Same-box A/B of the whole rollout: cfg 2 181.75 -> 180.32 ms,
+// cfg 5 (bf16, B = 128, 6 frames) 78.0 -> 76.9 ms.
+// the calls that take it: few rows (at most 256), a long contraction in whole quarters of 32-k tiles, at most ~4 workgroups per CU, plain epilogue
+bool gemm2_ksplit_rule(const GemmArgs& p) {
+    if (!gemm2_applicable(p) || p.batch > 1 || p.C2 || p.Wb || p.Ab) return false;
+    if (p.flags & ~GEMM_SILU) return false;                       // (no folded RMSNorm, SiLU-GLU, accumulate or transposed operands)
+    if (p.M > 256 || p.K < 1024 || (p.K % (KS_BK * KS_GROUPS)) != 0) return false;
+    const int64_t tiles = (int64_t)cdiv(p.M, KS_BM) * cdiv(p.N, KS_BN);
+    return tiles >= 64 && tiles <= 1024;
+}
+
+int gemm2_ksplit_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
+    D4_REQUIRE(gemm2_ksplit_rule(p), "gemm2_ksplit: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
+    const size_t lds = (size_t)KS_GROUPS * KS_RING_F * sizeof(float);
+    static DeviceOnce attr_set;
+    if (attr_set.need()) {
+        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_ksplit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.done();
+    }
+    const dim3 grid(cdiv(p.M, KS_BM) * cdiv(p.N, KS_BN)), block(1024);
+    if (ea) hipExtLaunchKernelGGL(gemm2_ksplit_kernel, grid, block, (uint32_t)lds, stream, ea, eb, 0, p);
+    else hipLaunchKernelGGL(gemm2_ksplit_kernel, grid, block, lds, stream, p);
+    D4_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- configurations -------------------------------------------------------------------------------------------
 // name          waves   wave tile   block tile  BK  LDS ring     blocks (waves) / CU
 // 64x64         2 x 2     32 x 32     64 x 64   32  3 x 16 KB    3 (12)

@@ -232,8 +232,8 @@ int d4_adamw_clip(float* params, const float* grads, float* exp_avg, float* exp_
                   float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
                   float grad_scale, float* scratch, void* stream);
 
-/* Measurement hook (bench.py roofline leg): `mask` bit c (c < 26) enables tile configuration c of the GEMM kernels; every
- * (mask >> 26)-th launch (0 -> every launch) of an enabled configuration carries a HIP event pair on its dispatch (launch stream); d4_profile_read sums elapsed ms / algorithmic flops /
+/* Measurement hook (bench.py roofline leg): `mask` bit c (c < 27) enables tile configuration c of the GEMM kernels; every
+ * (mask >> 27)-th launch (0 -> every launch) of an enabled configuration carries a HIP event pair on its dispatch (launch stream); d4_profile_read sums elapsed ms / algorithmic flops /
  * launches per configuration and clears the log.  d4_profile_classes() configurations exist; d4_profile_class_name(c) is the
  * prefix of the kernel name rocprofv3 reports for configuration c ("gemm_kernel<BM, BN, WGM, WGN, BK, 1"). */
 /* bf16 path: every `stride`-th bf16 GEMM launch carries an event pair (0 = off); read sums ms / flops / launches and clears. */

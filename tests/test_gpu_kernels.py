@@ -103,6 +103,25 @@ def test_every_tile_configuration_gives_the_same_bits(lib, M, N, K, flags):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 2048, 2048), (128, 4096, 4096), (250, 1030, 1024), (37, 4100, 1152), (200, 516, 1024)])
+def test_gemm_few_rows_long_k_cut_inside_the_workgroup(lib, M, N, K):
+    """gemm2_ksplit_kernel (the heads' hidden layers at rollout batch: few rows, K >= 1024): a workgroup of 16 waves owns a 32 x 64 tile, its four wave groups
+    multiply one quarter of K each and the partial tiles are summed in LDS in group order.  Taken by a rule on the shape (the dispatcher, not the tuner);
+    against float64 with bias / SiLU / residual, ragged rows and column counts that are not multiples of 64 or 4; and deterministic (same bits twice)."""
+    cls = [lib.d4_profile_class_name(c).decode() for c in range(lib.d4_profile_classes())]
+    ks = cls.index('gemm2_ksplit_kernel')
+    for kw in (dict(), dict(flags=_lib.GEMM_SILU, bias=True), dict(bias=True, res=True)):
+        lib.d4_profile_enable(1 << ks)
+        a = run_gemm(lib, M, N, K, **kw)
+        torch.cuda.synchronize()
+        ms = (C.c_double * len(cls))(); fl = (C.c_double * len(cls))(); cnt = (C.c_int64 * len(cls))()
+        _lib.check(lib.d4_profile_read(ms, fl, cnt, len(cls)))
+        lib.d4_profile_enable(0)
+        assert cnt[ks] == 1, 'the call did not take the k-split kernel'
+        b = run_gemm(lib, M, N, K, **kw)
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('M,N,K', [(112, 64, 32), (3584, 512, 512), (200, 300, 64), (45, 388, 96), (1000, 255, 128), (3840, 1552, 512),
                                    (17, 20, 32), (3584, 512, 1376), (130, 129, 2048)])
 def test_gemm_second_family_every_configuration(lib, M, N, K):
