@@ -975,10 +975,10 @@ int gemm(const GemmArgs& p, hipStream_t stream) {
     if (p.Wb && p.Ab && gemm_bf16a_applicable(p)) return gemm_bf16a(p, stream);     // bf16 engine, the activation has a bf16 image: both operands by LDS-DMA
     if (p.Wb) return gemm_bf16(p, stream);
     // test hook: 100 + c forces configuration c of the second family, 0 .. N_TILE_CFG-1 a configuration of this one
-    if (g_forced_cfg >= 100 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);
+    if (g_forced_cfg >= 100 && g_forced_cfg != 199 && gemm2_config_valid(g_forced_cfg - 100, p)) return launch_v2(g_forced_cfg - 100, p, stream);
     if (gemm_skinny_applicable(p)) return gemm_skinny(p, stream);
     // few rows x long K (the heads' hidden layers at rollout batch): the contraction cut four ways inside the workgroup — a rule on the shape
-    if (g_forced_cfg < 0 && gemm2_ksplit_rule(p)) return launch_v2ks(p, stream);
+    if ((g_forced_cfg < 0 && gemm2_ksplit_rule(p)) || (g_forced_cfg == 199 && gemm2_ksplit_applicable(p))) return launch_v2ks(p, stream);      // (199: test hook, any shape it can run)
     if ((g_forced_cfg < 0 || g_forced_cfg >= 300) && use_v2(p)) return gemm_v2(p, stream);      // (300 + c forces a tile of the split-operand family only)
     if (!ta && !tb) return launch_t<false, false>(p, stream);
     if (!ta && tb) return launch_t<false, true>(p, stream);

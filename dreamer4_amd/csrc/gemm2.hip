@@ -364,13 +364,18 @@ __global__ __launch_bounds__(1024) void gemm2_ksplit_kernel(GemmArgs p) {
         voff[i] = (uint32_t)((slot * RPP < BM ? r * p.lda : (r - BM) * p.ldw) * 4 + src_chunk * 16);
     }
     float* ring = smem + grp * KS_RING_F;
-    const int nk = p.K / (BK * KS_GROUPS), kt0 = grp * nk;          // this group's k-tiles
+    // this group's k-tiles: the first (nkt % 4) groups take one more; every group RUNS nk = ceil(nkt / 4) iterations (same barrier sequence) and a
+    // group's tile past its share is "loaded" through a zero-record descriptor: zeros in LDS, its MFMAs add nothing
+    const int nkt = p.K / BK, nk = (nkt + KS_GROUPS - 1) / KS_GROUPS;
+    const int mine = nkt / KS_GROUPS + (grp < nkt % KS_GROUPS ? 1 : 0);
+    const int kt0 = grp * (nkt / KS_GROUPS) + min(grp, nkt % KS_GROUPS);
+    const __amdgpu_buffer_rsrc_t rs0 = uniform_rsrc(p.A, 0);
 #define D4_KS_ISSUE(KT, BUF)                                                                                                      \
     _Pragma("unroll") for (int i_ = 0; i_ < LPW; ++i_) {                                                                           \
         const int slot_ = w + 4 * i_;                                                                                               \
         float* dst_ = ring + (BUF) * KS_STAGE_F + slot_ * 256;                                                                      \
-        if (slot_ * RPP < BM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_ptr)dst_, 16, (uint32_t)voff[i_], (kt0 + (KT)) * BK * 4, 0, 0); \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_ptr)dst_, 16, (uint32_t)voff[i_], (kt0 + (KT)) * BK * 4, 0, 0);              \
+        const __amdgpu_buffer_rsrc_t rs_ = (KT) < mine ? (slot_ * RPP < BM ? rsA : rsB) : rs0;                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lds_void_ptr)dst_, 16, (uint32_t)voff[i_], (kt0 + (KT)) * BK * 4, 0, 0);           \
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const int kq = lane >> 4, frow = lane & 15;
@@ -452,16 +457,18 @@ __global__ __launch_bounds__(1024) void gemm2_ksplit_kernel(GemmArgs p) {
 // situ), 128 x 4096 x 4096 46 against 55 us; 512 rows lose (51.5 vs 44.8 us) -> at most 256 rows.  Same-box A/B of the whole rollout: cfg 2 181.75 -> 180.32 ms,
 // cfg 5 (bf16, B = 128, 6 frames) 78.0 -> 76.9 ms.
 // the calls that take it: few rows (at most 256), a long contraction in whole quarters of 32-k tiles, at most ~4 workgroups per CU, plain epilogue
+bool gemm2_ksplit_applicable(const GemmArgs& p) {               // what the kernel can run at all (test hook: d4_gemm_force_config(199))
+    return gemm2_applicable(p) && p.batch <= 1 && !p.C2 && !p.Wb && !p.Ab && !(p.flags & ~GEMM_SILU) && p.K >= 4 * KS_BK;
+}
 bool gemm2_ksplit_rule(const GemmArgs& p) {
-    if (!gemm2_applicable(p) || p.batch > 1 || p.C2 || p.Wb || p.Ab) return false;
-    if (p.flags & ~GEMM_SILU) return false;                       // (no folded RMSNorm, SiLU-GLU, accumulate or transposed operands)
-    if (p.M > 256 || p.K < 1024 || (p.K % (KS_BK * KS_GROUPS)) != 0) return false;
+    if (!gemm2_ksplit_applicable(p)) return false;
     const int64_t tiles = (int64_t)cdiv(p.M, KS_BM) * cdiv(p.N, KS_BN);
-    return tiles >= 64 && tiles <= 1024;
+    if (p.M <= 256) return p.K >= 1024 && tiles >= 64 && tiles <= 1024;
+    return false;
 }
 
 int gemm2_ksplit_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea, hipEvent_t eb) {
-    D4_REQUIRE(gemm2_ksplit_rule(p), "gemm2_ksplit: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
+    D4_REQUIRE(gemm2_ksplit_applicable(p), "gemm2_ksplit: call not supported (M=%d N=%d K=%d flags=%d)", p.M, p.N, p.K, p.flags);
     const size_t lds = (size_t)KS_GROUPS * KS_RING_F * sizeof(float);
     static DeviceOnce attr_set;
     if (attr_set.need()) {

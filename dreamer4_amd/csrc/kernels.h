@@ -98,6 +98,7 @@ int gemm2_configs();
 const char* gemm2_config_name(int c);
 void gemm2_config_tile(int c, int* bm, int* bn);
 int gemm2_launch(int c, const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
+bool gemm2_ksplit_applicable(const GemmArgs& p);
 bool gemm2_ksplit_rule(const GemmArgs& p);               // few rows x long K: the contraction cut four ways inside the workgroup (gemm2_ksplit_kernel)
 int gemm2_ksplit_launch(const GemmArgs& p, hipStream_t stream, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr);
 bool gemm2_pair_config_ok(int c);

@@ -260,6 +260,7 @@ int d4_measure_peaks(void* scratch, size_t scratch_bytes, double* hbm_copy_gbs, 
 /* Test hook: run GEMM tile configuration `id` wherever it is valid instead of the tuned / static choice (-1 restores it);
  * 100 + c: configuration c of the second fp32 family (gemm2.hip); 200 + c: configuration c of the bf16 kernel; 300 + c: tile c of the
  * split-operand fp32 family (gemm_x3.hip); 400 + c: tile c of the fp16x2 family (gemm_h2.hip); 500 + c: tile c of the bf16-activation kernel (gemm_bf16a.hip).
+ * 199: the few-row / long-K form of the second family (gemm2_ksplit_kernel) on every call it can run (normally taken by a rule on the shape).
  * ONE family is forced at a time: every call first clears the hooks of the other families (so forcing, say, 400 + c also switches off the special forms
  * that only run un-forced: the persistent split-operand kernel, the pair launches).  Returns the number of configurations of the family addressed
  * (id = -1: of the first family).  Every configuration of a family must produce the same bits (tests/test_gpu_kernels.py). */
