@@ -167,15 +167,17 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_tail_kernel(const float
 
 // The whole AttentionPool core + tail per frame: the softmax-weighted, gated mixes of the normalised layer hiddens (pool_mix_row, one wave per
 // token row) go straight into LDS instead of through HBM (29 MB written and read back per pool at B = 256), then the tail above.
-template <int DD, int PH>
-__global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, const float* __restrict__ wv_t, const float* __restrict__ wo_t, FrameOut fo) {
-    constexpr int LDU = DD + 4, HP = PH * 64, LDP = HP + 4, ITER = DD / 256, LMAX = 64;
+// NW waves: 8, or 16 (round 6) — with 16 every token row of the frame has a wave of its own in the mix phase (8 waves: two rows one after the other on six of them)
+// and the output projection's 16 units are one per wave; LM = rows of the per-wave score scratch (>= the number of hiddens).
+template <int DD, int PH, int NW, int LM>
+__global__ __launch_bounds__(NW * 64) void frame_pool_kernel(PoolMixArgs pm, const float* __restrict__ wv_t, const float* __restrict__ wo_t, FrameOut fo) {
+    constexpr int LDU = DD + 4, HP = PH * 64, LDP = HP + 4, ITER = DD / 256;
     extern __shared__ __attribute__((aligned(16))) float smem_pk[];
     float* Us = smem_pk;                          // [PH][16][LDU]
     float* Ps = Us + PH * 16 * LDU;               // [16][LDP]   pooled attention output of the frame (second phase)
     f32x4* gws = reinterpret_cast<f32x4*>(Ps);    // first phase only: head-gate weights [PH][ITER * 64] float4 ...
-    float* psh = Ps + PH * ITER * 64 * 4;         // ... and the per-wave score scratch [waves][LMAX * PH]
-    static_assert(PH * ITER * 64 * 4 + FF_NW * LMAX * PH <= 16 * LDP, "first-phase scratch must fit the second phase's tile");
+    float* psh = Ps + 16 * LDP;                   // ... and, behind the tile, the per-wave score scratch [waves][LM * PH]
+    static_assert(PH * ITER * 64 * 4 <= 16 * LDP, "first-phase scratch must fit the second phase's tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x;
     const int li = lane & 15, kq = lane >> 4;
@@ -186,25 +188,26 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
     FgRing ring;                                  // (filled AFTER the mix phase: its 64 registers held across the mix cost more — 187 vs 125 VGPRs —
                                                   //  than the head start of the weight stream gives; 180.5 vs 181.3 ms per rollout, round 4)
     constexpr int nf4 = DD / 4;
-    for (int i = tid; i < PH * ITER * 64; i += FF_NW * 64) {
+    for (int i = tid; i < PH * ITER * 64; i += NW * 64) {
         const int h = i / (ITER * 64), c4 = i % (ITER * 64);
         gws[i] = c4 < nf4 ? reinterpret_cast<const f32x4*>(pm.gate_w)[h * nf4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int i = tid; i < PH * (16 - fo.S) * (DD / 4); i += FF_NW * 64) {               // rows >= S of the mixes are zero
+    for (int i = tid; i < PH * (16 - fo.S) * (DD / 4); i += NW * 64) {               // rows >= S of the mixes are zero
         const int c4 = i % (DD / 4), r = (i / (DD / 4)) % (16 - fo.S), h = i / ((16 - fo.S) * (DD / 4));
         *reinterpret_cast<f32x4*>(Us + (h * 16 + fo.S + r) * LDU + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    for (int ml = wave; ml < fo.S; ml += FF_NW)
-        pool_mix_row<ITER, true>(pm, g * fo.S + ml, lane, psh + wave * LMAX * PH, gws,
+    for (int ml = wave; ml < fo.S; ml += NW)
+        pool_mix_row<ITER, true>(pm, g * fo.S + ml, lane, psh + wave * LM * PH, gws,
                            [&](int h, int c4, const f32x4& v) { *reinterpret_cast<f32x4*>(Us + (h * 16 + ml) * LDU + c4 * 4) = v; });
-    fg_prefetch(ring, unit1(wave));               // NU1 == waves
+    if (wave < NU1) fg_prefetch(ring, unit1(wave));
+    else fg_prefetch(ring, unit2(wave));          // (16 waves: the upper eight go straight to the output projection's weights)
     __syncthreads();
 
     f32x4 acc0, acc1;
-    for (int v = wave; v < NU1; v += FF_NW) {
+    for (int v = wave; v < NU1; v += NW) {
         const int h = v / 2;
-        const FgUnit nxt = v + FF_NW < NU1 ? unit1(v + FF_NW) : unit2(wave);
+        const FgUnit nxt = v + NW < NU1 ? unit1(v + NW) : unit2(wave);
         fg_unit<DD>(ring, unit1(v), nxt, Us + (h * 16 + li) * LDU + 4 * kq, acc0, acc1);
         *reinterpret_cast<f32x4*>(Ps + li * LDP + 32 * v + 4 * kq) = acc0;
         *reinterpret_cast<f32x4*>(Ps + li * LDP + 32 * v + 16 + 4 * kq) = acc1;
@@ -215,8 +218,8 @@ __global__ __launch_bounds__(FF_NW * 64) void frame_pool_kernel(PoolMixArgs pm, 
     const bool row_ok = li < fo.S;
     const int rank = (fo.c2 && row_ok) ? compact_rank(li, fo.S, fo.c2_lo, fo.c2_hi, fo.c2_last) : -1;
     const int64_t c2row = (int64_t)g * (fo.c2_hi - fo.c2_lo + fo.c2_last) + rank;
-    for (int v = wave; v < NU2; v += FF_NW) {
-        const FgUnit nxt = unit2(v + FF_NW < NU2 ? v + FF_NW : v);
+    for (int v = wave; v < NU2; v += NW) {
+        const FgUnit nxt = unit2(v + NW < NU2 ? v + NW : v);
         f32x4 r4[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -333,7 +336,7 @@ int frame_attn_out(const SmallAttnArgs& sa, const float* wo_t, int D, const floa
         D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_attn_out_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.done();
     }
-    D4_GLUE_LAUNCH_F(GL_FRAME_ATTN_OUT, bytes, flops, frame_attn_out_kernel<512>, dim3(sa.groups), dim3(FF_NW * 64), lds, s, sa, wo_t, D, fo);
+    D4_GLUE_LAUNCH_F(GL_FRAME_ATTN_OUT, bytes, flops, (frame_attn_out_kernel<512>), dim3(sa.groups), dim3(FF_NW * 64), lds, s, sa, wo_t, D, fo);
     D4_LAUNCH_CHECK();
     return 0;
 }
@@ -394,16 +397,29 @@ int frame_pool(const PoolMixArgs& pm, const float* wv_t, const float* wo_t, int 
                (!c2 || ldc2 % 4 == 0), "frame_pool: call not supported");
     FrameOut fo{resid, ldr, out, ldo, c2, ldc2, c2_lo, c2_hi, c2_last, S};
     constexpr int DD = 512, PH = 4;
-    const size_t lds = (size_t)(PH * 16 * (DD + 4) + 16 * (PH * 64 + 4)) * sizeof(float);
-    static DeviceOnce attr_set;
-    if (attr_set.need()) {
-        D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pool_kernel<DD, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set.done();
-    }
     // algorithmic bytes: L hiddens + L projected keys per token row, queries + the row itself, the block output (+ the two weight matrices per XCD)
     const double bytes = 4.0 * pm.M * ((double)pm.L * (pm.D + pm.ldk) + pm.ldq + 2.0 * pm.D) + 8.0 * 4.0 * 2.0 * PH * 64 * pm.D;
     const double flops = 2.0 * pm.M * ((double)PH * 64 * pm.D + (double)pm.D * PH * 64);
-    D4_GLUE_LAUNCH_F(GL_FRAME_POOL_TAIL, bytes, flops, (frame_pool_kernel<DD, PH>), dim3(frames), dim3(FF_NW * 64), lds, s, pm, wv_t, wo_t, fo);
+    if (pm.L <= 32) {
+        // 16 waves: a wave per token row in the mix phase (the score scratch of 16 waves fits the 160 KB beside the mixes for up to 32 hiddens)
+        constexpr int NW = 16, LM = 32;
+        const size_t lds = (size_t)(PH * 16 * (DD + 4) + 16 * (PH * 64 + 4) + NW * LM * PH) * sizeof(float);
+        static DeviceOnce attr_set;
+        if (attr_set.need()) {
+            D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pool_kernel<DD, PH, NW, LM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set.done();
+        }
+        D4_GLUE_LAUNCH_F(GL_FRAME_POOL_TAIL, bytes, flops, (frame_pool_kernel<DD, PH, NW, LM>), dim3(frames), dim3(NW * 64), lds, s, pm, wv_t, wo_t, fo);
+    } else {
+        constexpr int NW = 8, LM = 64;
+        const size_t lds = (size_t)(PH * 16 * (DD + 4) + 16 * (PH * 64 + 4) + NW * LM * PH) * sizeof(float);
+        static DeviceOnce attr_set;
+        if (attr_set.need()) {
+            D4_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_pool_kernel<DD, PH, NW, LM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set.done();
+        }
+        D4_GLUE_LAUNCH_F(GL_FRAME_POOL_TAIL, bytes, flops, (frame_pool_kernel<DD, PH, NW, LM>), dim3(frames), dim3(NW * 64), lds, s, pm, wv_t, wo_t, fo);
+    }
     D4_LAUNCH_CHECK();
     return 0;
 }
