@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
     const int hh = lane >> 4;
     // every global load of the first round (4 hiddens per wave: all of them up to L = 16) is issued before anything is computed:
     // query, key rows, hidden rows, and for the gating wave the gate weights (and x when it is not the last hidden)
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
+    const f32x4 q4 = pool_query4<KB16>(p, m, lane);
     f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + lane * 4);
     auto load_keys = [&](int l0, f32x4 (&kv)[4]) {
 #pragma unroll

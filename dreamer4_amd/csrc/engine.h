@@ -133,6 +133,12 @@ struct d4_engine {
     std::vector<float*> proj_w, proj_b;
     std::vector<d4::FfPrep> ffp;           // depth layers + special ff at index depth
     std::vector<float*> pq_w, pkv_w;
+    // bf16 engine, wide key projection (round 6): pkq_w[l] = the folded key weights of pools l .. depth-2 followed by pool l's query weights,
+    // [(depth - l) * hp][D]; kall_b[slab][row][kall_ld] = the keys of every later pool for a hidden (columns p * hp) and, in the last hp columns,
+    // the queries of the pool whose input the slab is — a hidden is projected ONCE, when it is produced, for all the pools that will read it
+    std::vector<float*> pkq_w;
+    uint16_t* kall_b = nullptr;
+    int kall_ld = 0;
     // tiled images ([N / 16][K / 4][16][4]) of the small projections the per-frame fused kernels stream (frame_fused.hip); empty vectors:
     // the configuration does not take that path
     std::vector<float*> wo_t, pv_t, po_t;

@@ -53,6 +53,13 @@ int engine_layout(d4_engine* e, bool assign) {
         e->pq_w[p] = fl((size_t)(hp + e->php) * D);
         e->pkv_w[p] = fl((size_t)2 * hp * D);
     }
+    // wide key projection (bf16 activation images only; see engine.h): the weights of pool step l = keys of pools l .. depth-2, then queries of pool l
+    const bool wide_keys = e->bf16 && !e->fp32_planes() && !e->decoder && !e->encoder && c.pool_heads == 4 && hp == 256 && D <= 1024 && D % 64 == 0 && depth >= 2;
+    e->pkq_w.clear();
+    if (wide_keys) {
+        e->pkq_w.assign(depth - 1, nullptr);
+        for (int l = 0; l < depth - 1; ++l) e->pkq_w[l] = fl((size_t)(depth - l) * hp * D);
+    }
     // per-frame fused tails (frame_fused.hip): 8 heads x 64 and, for the pool tail, dim 512 with 4 pool heads — dynamics mode only
     e->wo_t.clear(); e->pv_t.clear(); e->po_t.clear();
     if (!e->encoder && !e->decoder && c.attn_dim_head == 64 && c.attn_heads == 8 && D % 32 == 0 && D >= 256) {
@@ -81,7 +88,9 @@ int engine_layout(d4_engine* e, bool assign) {
         const size_t per_layer = (size_t)(e->Nproj0 + hd) * D + (size_t)3 * e->inner_pad * D;
         const size_t per_pool = (size_t)(hp + e->php + 2 * hp) * D + (size_t)D * hp;
         const size_t extra = (size_t)(hd + c.attn_heads + 2 * hd + hd) * D + (size_t)2 * hd * dl + (size_t)2 * hd * D + (size_t)dl * (hd > D ? hd : D) + (size_t)D * hd + (size_t)D * dl;
-        e->bf16_cap = ((size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + 4096 + 7) / 8 * 8;
+        size_t wide = 0;
+        for (int l = 0; l < (int)e->pkq_w.size(); ++l) wide += (size_t)(depth - l) * hp * D + 8;
+        e->bf16_cap = ((size_t)(depth + 1) * per_layer + (size_t)depth * per_pool + extra + wide + 4096 + 7) / 8 * 8;
         e->bf16_arena = reinterpret_cast<uint16_t*>(alloc_bytes(e->bf16_cap * (e->split ? 3 : (e->h2 ? 2 : 1)) * sizeof(uint16_t)));     // split mode: three planes; fp16x2 mode: two
         if (e->h2) {
             e->wscale_cap = e->bf16_cap / 16 + 64;           // one float per weight row; the narrowest mirrored matrix has >= 16 columns
@@ -155,6 +164,11 @@ int engine_layout(d4_engine* e, bool assign) {
         // bytes (170 flop per byte with fp32 keys), and the pool mix reads every key row once: half the bytes on both sides.  The scores then see keys
         // rounded to bf16 like every other activation of this mode.
         if (c.pool_heads == 4 && D <= 1024) sh(e->pool_kv, (size_t)e->nslab * M * 2 * hp, true);
+    }
+    e->kall_b = nullptr; e->kall_ld = 0;
+    if (!e->pkq_w.empty()) {
+        e->kall_ld = depth * hp;                       // depth - 1 pools' keys + one query block
+        e->kall_b = reinterpret_cast<uint16_t*>(alloc_bytes((size_t)(2 * depth - 1) * M * e->kall_ld * sizeof(uint16_t)));
     }
     e->cq = fl(Fr * KQ * e->ldcq);
     e->ckv = fl(M * 2 * hd);
@@ -466,9 +480,10 @@ static int engine_gemm(GemmArgs& g, hipStream_t s) {
         if (!e->fp32_planes() && !e->shadows.empty()) {
             // bf16 activation images: read A's when it has one (and the bf16-activation kernel takes the call), refresh C's either in the
             // epilogue of that kernel or by a conversion pass after any other kernel
-            uint16_t* cb = e->shadow_of(g.C);
+            uint16_t* cb = (!g.C && g.Cb) ? g.Cb : e->shadow_of(g.C);     // (a caller may name a bf16-only output itself: the wide key projection)
             g.Ab = g.Wb ? e->shadow_of(g.A) : nullptr;
             if (g.Ab && !gemm_bf16a_applicable(g)) g.Ab = nullptr;
+            D4_REQUIRE(g.Ab || g.C, "bf16 engine: a GEMM (M=%d N=%d K=%d) with a bf16-only output cannot take the bf16-activation kernel", g.M, g.N, g.K);
             D4_REQUIRE(g.Ab || !e->shadow_only(g.A), "bf16 engine: a GEMM (M=%d N=%d K=%d) reads a bf16-only activation buffer but cannot take the bf16-activation kernel", g.M, g.N, g.K);
             if (g.Ab) {
                 g.Cb = cb;
@@ -589,6 +604,11 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
             if ((rc = tile16_weights(a.to_out, hp, e->po_t[p], D, hp, s))) return rc;
         }
     }
+    for (int l = 0; l < (int)e->pkq_w.size(); ++l) {
+        for (int p = l; p < c.depth - 1; ++p)
+            if ((rc = copy_rows(e->pkv_w[p], D, e->pkq_w[l] + (size_t)(p - l) * hp * D, D, hp, D, s))) return rc;
+        if ((rc = copy_rows(e->pq_w[l], D, e->pkq_w[l] + (size_t)(c.depth - 1 - l) * hp * D, D, hp, D, s))) return rc;
+    }
     for (int l = 0; l < (int)e->wo_t.size(); ++l)
         if ((rc = tile16_weights(e->layer_attn[l].to_out, hd, e->wo_t[l], D, hd, s))) return rc;
     if (e->decoder) {
@@ -676,6 +696,8 @@ int engine_prepare(d4_engine* e, hipStream_t s) {
             if ((rc = mir(e->pkv_w[p], (size_t)2 * hp, D))) return rc;
             if ((rc = mir(e->pools[p].to_out, (size_t)D, hp))) return rc;
         }
+        for (int l = 0; l < (int)e->pkq_w.size(); ++l)
+            if ((rc = mir(e->pkq_w[l], (size_t)(c.depth - l) * hp, D))) return rc;
         if ((rc = mir(e->cq_w, (size_t)(hd + h), D))) return rc;
         if ((rc = mir(e->ckv_w, (size_t)2 * hd, D))) return rc;
         if ((rc = mir(e->cross.to_out, (size_t)D, hd))) return rc;
@@ -713,6 +735,7 @@ static int ff_block(d4_engine* e, const FfPrep& fp, const float* out_b, const fl
     return engine_gemm(g2, s);
 }
 
+int g_pool_wide_keys = 1;             // test hook d4_debug_switch("pool_wide_keys")
 static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int M, hipStream_t s, const float* hiddens = nullptr,
                       float* y_compact = nullptr, int S = 0, int has_agent = 1) {
     if (!hiddens) hiddens = e->slabs;
@@ -725,13 +748,29 @@ static int pool_block(d4_engine* e, int p, const float* x, float* y, int L, int 
     const GemmArgs gq{x, D, e->pq_w[p], D, e->pool_q, e->ldpq, nullptr, nullptr, 0, M, mix_path ? hp : hp + e->php, D, GEMM_RMS_ROWSCALE, RMS_EPS};
     if (mix_path) {
         // keys only: [L*M][hp]; values come from ONE per-head projection of the softmax-weighted normalised hiddens
+        // bf16 engine, in-loop pools: the hiddens produced since the previous pool (slabs 2p+1, 2p+2; pool 0: slab 0 too) are projected ONCE, onto the
+        // key weights of this and every later pool plus this pool's query weights — one launch of N = (depth - p) * 256 per pool instead of a query
+        // launch and a key launch of L M rows x 256 (every hidden re-read by every pool: quadratic in depth).  Same products, same row scales
+        // (1 / rms of the hidden; both norms' gammas are folded into the weight rows); the queries become bf16 like the keys.
+        const bool wide = g_pool_wide_keys && t_bf16 && e->kall_b && hiddens == e->slabs && p < c.depth - 1 && L == 2 * p + 3 && x == e->slabs + (size_t)(L - 1) * M * D;
+        PoolMixArgs pm{};
+        pm.q = e->pool_q; pm.ldq = e->ldpq; pm.k = e->pool_kv; pm.ldk = hp;
+        if (wide) {
+            const int j0 = p == 0 ? 0 : 2 * p + 1, ld = e->kall_ld;
+            GemmArgs gw{hiddens + (size_t)j0 * M * D, D, e->pkq_w[p], D, nullptr, ld, nullptr, nullptr, 0, (L - j0) * M, (c.depth - p) * hp, D, GEMM_RMS_ROWSCALE, RMS_EPS};
+            gw.algo_flops = 2.0 * M * hp * (double)D * ((double)(L - j0) * (c.depth - 1 - p) + 1.0);       // (the query columns of the other slabs are not wanted)
+            gw.Cb = e->kall_b + (size_t)j0 * M * ld + (size_t)p * hp;
+            if ((rc = engine_gemm(gw, s))) return rc;
+            pm.k = nullptr; pm.k_b = e->kall_b + (size_t)p * hp; pm.ldk = ld;
+            pm.q = nullptr; pm.q_b = e->kall_b + (size_t)(L - 1) * M * ld + (size_t)(c.depth - 1) * hp; pm.ldq = ld;
+        } else {
         const GemmArgs gk{hiddens, D, e->pkv_w[p], D, e->pool_kv, hp, nullptr, nullptr, 0, L * M, hp, D, GEMM_RMS_ROWSCALE, RMS_EPS};
         if ((rc = gemm_two(gq, gk, s))) return rc;
-        PoolMixArgs pm{};
-        pm.q = e->pool_q; pm.ldq = e->ldpq; pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.k = e->pool_kv; pm.ldk = hp; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
+        if (t_bf16) pm.k_b = t_bf16->shadow_of(e->pool_kv);               // bf16 keys (the only copy of them in this mode)
+        }
+        pm.x = x; pm.ldx = D; pm.gate_w = e->pq_w[p] + (size_t)hp * D; pm.hid = hiddens; pm.D = D; pm.k_gamma = a.k_gamma;
         pm.u = e->pool_u; pm.M = M; pm.L = L; pm.heads = c.pool_heads; pm.eps = RMS_EPS;
         if (t_bf16 && D > 512) pm.hid_b = t_bf16->shadow_of(hiddens);     // (D <= 512 may take the block-per-row form, which reads fp32)
-        if (t_bf16) pm.k_b = t_bf16->shadow_of(e->pool_kv);               // bf16 keys (the only copy of them in this mode)
         if (t_bf16) if (uint16_t* ub = t_bf16->shadow_of(e->pool_u)) { pm.u_b = ub; if (t_bf16->shadow_only(e->pool_u)) pm.u = nullptr; }   // only the value GEMM reads the mixes
         // per-frame fused form (mix -> value projection -> output projection + residual in one kernel) where a frame per workgroup fills the chip;
         // frame_fused mode 2 (test hook): the mix stays its own kernel and only the tail is fused
@@ -1498,6 +1537,7 @@ int d4_debug_switch(const char* name, int value) {
     int* sw = nullptr;
     if (name && !strcmp(name, "time_attn_fused_append")) sw = &d4::g_time_attn_fused_append;
     else if (name && !strcmp(name, "attn_out_cols")) sw = &d4::g_attn_out_cols;
+    else if (name && !strcmp(name, "pool_wide_keys")) sw = &d4::g_pool_wide_keys;
     if (!sw) return -1;
     const int old = *sw;
     *sw = value;

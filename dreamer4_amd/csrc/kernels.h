@@ -114,6 +114,7 @@ bool gemm_profile_active();
 int gemm_profile_read(double* ms, double* flops, int64_t* count, int nclass);
 int gemm_profile_classes();
 extern int g_time_attn_fused_append;     // attn.hip: 1 (default) the cached decode's KV append rides in its time attention launch; 0 two launches (test hook)
+extern int g_pool_wide_keys;             // engine.hip: 1 (default) bf16 engine projects a hidden once for every later pool's keys; 0 one key projection per pool (test hook)
 extern int g_attn_out_cols;              // frame_fused.hip: 1 (default) attention inside the column-split output projection at <= 4 frames; 0 two launches (test hook)
 int gemm_force_config(int id);                             // test hook; returns the number of configurations
 const char* gemm_profile_class_name(int c);
@@ -157,6 +158,7 @@ struct PoolMixArgs {
     float eps;
     uint16_t* u_b = nullptr;           // optional bf16 image of u (bf16 engine: the per-head value GEMM reads this one)
     const uint16_t* k_b = nullptr;     // optional bf16 image of the projected keys (same [L*M][ldk] layout; bf16 engine): read INSTEAD of `k`
+    const uint16_t* q_b = nullptr;     // ... and of the projected queries ([M][ldq]; only with k_b): read instead of `q`
     const uint16_t* hid_b = nullptr;   // optional bf16 image of the hiddens (bf16 engine): read instead of `hid` by the one-wave-per-row form — the
                                        // values the pool's key GEMM consumed, at half the bytes of the kernel's dominant stream
 };

@@ -14,6 +14,19 @@ namespace d4 {
 // stand-alone kernel is bandwidth-bound and the deeper form measured 5 % slower there.
 // KB16: the projected keys are read from their bf16 image p.k_b (bf16 engine) instead of p.k — a template flag, not a run-time branch: a branch
 // inside the unrolled load batches keeps the compiler from issuing them together (measured: +26 % on the block-per-row kernel).
+// the lane's four query features of row m: fp32, or (bf16 engine, queries projected by the same launch as the keys) their bf16 image
+template <bool KB16>
+__device__ __forceinline__ f32x4 pool_query4(const PoolMixArgs& p, int m, int lane) {
+    if constexpr (KB16) {
+        if (p.q_b) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(p.q_b + (int64_t)m * p.ldq + lane * 4);
+            return f32x4{__builtin_bit_cast(float, raw.x << 16), __builtin_bit_cast(float, raw.x & 0xFFFF0000u),
+                         __builtin_bit_cast(float, raw.y << 16), __builtin_bit_cast(float, raw.y & 0xFFFF0000u)};
+        }
+    }
+    return *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
+}
+
 template <int ITER, bool DEEP = false, bool KB16 = false, class Store>
 __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int lane, float* ps, const f32x4* gws, Store store) {
     constexpr int PH = 4;
@@ -28,7 +41,7 @@ __device__ __forceinline__ void pool_mix_row(const PoolMixArgs& p, int m, int la
     // scores: the 4 heads x 64 features of a key row are exactly one float4 per lane (head = lane / 16), so the
     // per-head reductions are 16-lane DPP row reductions and all four heads are scored at once
     const int hh = lane >> 4;
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(p.q + (int64_t)m * p.ldq + lane * 4);
+    const f32x4 q4 = pool_query4<KB16>(p, m, lane);
     f32x4 g4 = *reinterpret_cast<const f32x4*>(p.k_gamma + lane * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) g4[e] = (g4[e] + 1.f) * 8.f;

@@ -247,6 +247,31 @@ def test_config5_bf16_engine_vs_oracle_at_the_bench_horizon():
     assert rep['values_max_abs'] < 0.3 and rep['cont_logp_max_abs'] < 0.3 and rep['actions_cont_max_abs'] <= 5e-2, rep
 
 
+@pytest.mark.parametrize('kw,B', [(dict(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), 24),
+                                  (dict(dim=64, dim_latent=8, num_latent_tokens=6, depth=4, time_block_every=2, attn_heads=2, num_discrete_actions=4), 3),
+                                  (dict(dim=1024, dim_latent=32, num_latent_tokens=64, depth=3, num_continuous_actions=6), 9)])
+def test_bf16_wide_key_projection_equals_one_key_projection_per_pool(kw, B):
+    """bf16 engine: a hidden is projected ONCE, when it is produced, onto the key weights of every later attention pool and the query weights of the
+    pool it feeds (engine.hip: pool_block, one launch of N = (depth - p) * 256 per pool) instead of a query launch + a key launch over all 2p + 3
+    hiddens per pool (D4:2143-2177 re-projects the whole stack in every pool).  Same products and row scales; only the QUERIES change arithmetic
+    (rounded to bf16 like the keys): against the per-pool form (test hook) the rollout differs, and by no more than bf16 rounding of one operand."""
+    lib = _lib.load()
+    a, b = _pair(kw, dtypes=('bf16', 'bf16'))            # two engines: a captured decode graph keeps the launch sequence it was recorded with
+    cfg = oracle_config(a)
+    nz = make_noise(cfg, 4, B, 5)
+    gk = dict(return_rewards_per_frame=True, return_agent_actions=True, return_log_probs_and_values=True, noise=nz)
+    try:
+        assert lib.d4_debug_switch(b'pool_wide_keys', 1) in (0, 1)
+        ea = a.generate(4, batch_size=B, **gk)
+        lib.d4_debug_switch(b'pool_wide_keys', 0)
+        eb = b.generate(4, batch_size=B, **gk)
+    finally:
+        lib.d4_debug_switch(b'pool_wide_keys', 1)
+    d = (ea.latents - eb.latents).abs().max().item()
+    assert 0. < d < 1e-2, d                      # it took the other path (bf16 queries), and stays inside the mode's own noise (3e-2 against fp32)
+    assert (ea.values - eb.values).abs().max().item() < 0.1
+
+
 def test_fp32_default_with_split_operand_projections_equals_the_f32_mfma_engine_to_fp32_accuracy():
     """matmul_dtype='fp32' (default) runs the SiLU-GLU input projections as split-operand fp32 GEMMs on the bf16 matrix cores
     (csrc/gemm_x3.hip); 'fp32_mfma' keeps every GEMM on the f32-input MFMA.  Both are fp32 arithmetic: at config 2's architecture
