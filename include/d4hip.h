@@ -270,6 +270,8 @@ int d4_frame_fused_set(int mode);
 /* Test hook for the two bit-identical launch fusions of the cached decode (each is asserted bitwise against its two-launch form): name =
  * "time_attn_fused_append" (KV append inside the time attention, csrc/attn.hip) or "attn_out_cols" (attention inside the column-split output
  * projection at <= 4 frames, csrc/frame_fused.hip); value 1 (default) fused, 0 two launches.  Returns the previous value, -1 for an unknown name.
+ * "pool_wide_keys" (bf16 engine only; NOT bit-identical: the queries become bf16): 1 (default) a hidden is projected once, when produced, onto the key
+ * weights of every later attention pool and the query weights of the pool it feeds; 0 a query launch + a key launch over the whole stack per pool.
  * Read when a frame is ENQUEUED: a captured hipGraph keeps the form it was captured with. */
 int d4_debug_switch(const char* name, int value);
 int d4_gemm_force_config(int id);
