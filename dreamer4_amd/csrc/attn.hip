@@ -623,6 +623,7 @@ __global__ __launch_bounds__(256) void pool_mix_rows_kernel(PoolMixArgs p) {
 int pool_mix(const PoolMixArgs& p, hipStream_t stream) {
     D4_REQUIRE(p.heads == 4, "pool_mix: 4 pool heads expected (AttentionPool default, D4:2147)");
     D4_REQUIRE(p.L >= 1 && p.L <= 64 && p.D % 4 == 0 && p.D <= 1024, "pool_mix: L=%d D=%d out of range", p.L, p.D);
+    D4_REQUIRE(p.k_b ? (p.q != nullptr || p.q_b != nullptr) : (p.k != nullptr && p.q != nullptr && p.q_b == nullptr), "pool_mix: keys / queries: fp32 (k, q) or the bf16 images (k_b with q or q_b)");
     if (p.M == 0) return 0;
     dim3 grid(cdiv(p.M, 4)), block(256);
     // one block per row (its four waves split the hiddens) while that leaves the CUs short of waves — by M alone: measured at B = 256, L = 13:

@@ -394,7 +394,7 @@ int frame_pool_tail(const float* u, const float* wv_t, const float* wo_t, int fr
 int frame_pool(const PoolMixArgs& pm, const float* wv_t, const float* wo_t, int frames, int S, const float* resid, int ldr, float* out, int ldo, float* c2,
                int ldc2, int c2_lo, int c2_hi, int c2_last, hipStream_t s) {
     D4_REQUIRE(frame_pool_tail_applicable(frames, S, pm.D, pm.heads) && pm.M == frames * S && pm.L >= 1 && pm.L <= 64 && ldr % 4 == 0 && ldo % 4 == 0 &&
-               (!c2 || ldc2 % 4 == 0), "frame_pool: call not supported");
+               (!c2 || ldc2 % 4 == 0) && pm.k && pm.q && !pm.k_b && !pm.q_b, "frame_pool: call not supported (fp32 keys / queries only)");
     FrameOut fo{resid, ldr, out, ldo, c2, ldc2, c2_lo, c2_hi, c2_last, S};
     constexpr int DD = 512, PH = 4;
     // algorithmic bytes: L hiddens + L projected keys per token row, queries + the row itself, the block output (+ the two weight matrices per XCD)
