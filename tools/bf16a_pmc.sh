@@ -9,6 +9,6 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACT
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $R/gpurun_out/pmcb_$i -o p -- python $R/tools/bf16a_pmc_target.py $SH $CFG > /dev/null 2>&1
 done
 cd $R
-python tools/pmc_summary.py gpurun_out/pmcb_1 gpurun_out/pmcb_2 gpurun_out/pmcb_3 gpurun_out/pmcb_4 gpurun_out/pmcb_5 2>&1 | grep -i "kernel\|bf16a" > gpurun_out/pmc_bf16a_${SH}_${CFG}.txt
+python tools/pmc_summary.py gpurun_out/pmcb_1 gpurun_out/pmcb_2 gpurun_out/pmcb_3 gpurun_out/pmcb_4 gpurun_out/pmcb_5 2>&1 | grep -i "kernel\|bf16" > gpurun_out/pmc_bf16a_${SH}_${CFG}.txt
 rm -rf gpurun_out/pmcb_*
 cat gpurun_out/pmc_bf16a_${SH}_${CFG}.txt
