@@ -459,16 +459,18 @@ def test_full_rollout_at_baseline_batch_vs_oracle():
         assert rep[k + '_max_abs'] <= tol, (k, rep[k + '_max_abs'], rep[k + '_scale'])
 
 
-def test_per_frame_fused_block_tails_equal_the_separate_kernels():
+@pytest.mark.parametrize('depth,T', [(6, 3), (17, 2)])
+def test_per_frame_fused_block_tails_equal_the_separate_kernels(depth, T):
     """frame_fused.hip (within-frame attention -> output projection, attention-pool mix -> value / output projections, one workgroup per frame) is
     taken by rule at >= 192 frames: the same rollout with the fused tails (mode 1), with the pool mix kept as its own kernel (2) and with the
-    separate kernels (0) agrees to fp32 summation order, and samples the same actions."""
+    separate kernels (0) agrees to fp32 summation order, and samples the same actions.  depth 17: pools over up to 33 hiddens, i.e. the fused pool
+    kernel's 8-wave instance (<= 32 hiddens run a wave per token row on 16 waves, round 6)."""
     from dreamer4_amd import DynamicsWorldModel, _lib
     lib = _lib.load()
     torch.manual_seed(0)
-    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=6, num_discrete_actions=4), terminal_bias=-10.).cuda()
+    m = randomize_weights(DynamicsWorldModel(dim=512, dim_latent=32, num_latent_tokens=32, depth=depth, num_discrete_actions=4), terminal_bias=-10.).cuda()
     cfg = oracle_config(m)
-    B, T = 192, 3
+    B = 192
     nz = make_noise(cfg, T, B, 5)
     outs = {}
     prev = lib.d4_frame_fused_set(0)
