@@ -552,30 +552,28 @@ def dynamics_agent_losses(W, agent_embed, latents, *, multi_token_pred_len, num_
         padded = F.pad(continuous_actions, (0, 0, 1, 0), value=0.)
         tgt, mask = _mtp_targets(padded, mtp)
         tgt, mask = tgt[:, 1:].clamp(1e-5, 1. - 1e-5), mask[:, 1:]
-        per = []
-        for i in range(mtp):
-            wc = W['action_embedder.continuous_action_unembed'][:, i]                                          # [nc][4 D][2]
-            params = torch.ops.d4hip.linear(pe, wc.permute(0, 2, 1).reshape(-1, wc.shape[1]), None, None, 0, 0.).unflatten(-1, (wc.shape[0], 2))
-            link = torch.exp if continuous_beta_param == 'exp_p1' else F.softplus
-            a, b_ = link(params[..., 0]) + 1., link(params[..., 1]) + 1.
-            x = tgt[:, :, i]
-            lp = (a - 1.) * torch.log(x) + (b_ - 1.) * torch.log1p(-x) + torch.lgamma(a + b_) - torch.lgamma(a) - torch.lgamma(b_)
-            nl = (-lp).masked_fill(~mask[:, :, i, None], 0.)
-            per.append(nl[lm].mean() if lm is not None else nl.mean())
-        out['continuous_actions'] = torch.stack(per)
+        wc = W['action_embedder.continuous_action_unembed']                                                    # [nc][mtp][4 D][2]
+        nc_ = wc.shape[0]
+        # every member's (alpha, beta) rows in one HIP GEMM: weight [mtp][nc][2][4 D], member-major
+        params = torch.ops.d4hip.linear(pe, wc.permute(1, 0, 3, 2).reshape(-1, wc.shape[2]), None, None, 0, 0.).unflatten(-1, (mtp, nc_, 2))       # (b, t, mtp, nc, 2)
+        link = torch.exp if continuous_beta_param == 'exp_p1' else F.softplus
+        a, b_ = link(params[..., 0]) + 1., link(params[..., 1]) + 1.
+        lp = (a - 1.) * torch.log(tgt) + (b_ - 1.) * torch.log1p(-tgt) + torch.lgamma(a + b_) - torch.lgamma(a) - torch.lgamma(b_)
+        nl = (-lp).masked_fill(~mask[..., None], 0.)                                                            # (b, t, mtp, nc)
+        out['continuous_actions'] = nl[lm].mean(dim=(0, 2)) if lm is not None else nl.mean(dim=(0, 1, 3))
     if discrete_actions is not None and t > 1:
         padded = F.pad(discrete_actions, (0, 0, 1, 0), value=-1)
         tgt, mask = _mtp_targets(padded, mtp)
         tgt, mask = tgt[:, 1:].clamp(min=0), mask[:, 1:]
-        per = []
-        for i in range(mtp):
-            logits = torch.ops.d4hip.linear(pe, W['action_embedder.discrete_action_unembed'][:, i].contiguous(), None, None, 0, 0.)
-            lps, o = [], 0
-            for a, n in enumerate(num_discrete_actions):
-                lp = logits[..., o:o + n].log_softmax(dim=-1)
-                lps.append(lp.gather(-1, tgt[:, :, i, a:a + 1]).squeeze(-1))
-                o += n
-            nl = (-torch.stack(lps, dim=-1)).masked_fill(~mask[:, :, i, None], 0.)
-            per.append(nl[lm].mean() if lm is not None else nl.mean())
-        out['discrete_actions'] = torch.stack(per)
+        # all mtp members in ONE HIP GEMM ([mtp * A][4 D] weight, member-major) and one pass of the loss algebra over (b, t, member): the per-member
+        # python loop was ~10 tiny launches per member and action type                                              dreamer4.py:7520-7560
+        un = W['action_embedder.discrete_action_unembed']                                                           # [A][mtp][4 D]
+        logits = torch.ops.d4hip.linear(pe, un.transpose(0, 1).reshape(-1, un.shape[-1]), None, None, 0, 0.).unflatten(-1, (mtp, un.shape[0]))   # (b, t, mtp, A)
+        lps, o = [], 0
+        for a, n in enumerate(num_discrete_actions):
+            lp = logits[..., o:o + n].log_softmax(dim=-1)
+            lps.append(lp.gather(-1, tgt[..., a:a + 1]).squeeze(-1))
+            o += n
+        nl = (-torch.stack(lps, dim=-1)).masked_fill(~mask[..., None], 0.)                                          # (b, t, mtp, na)
+        out['discrete_actions'] = nl[lm].mean(dim=(0, 2)) if lm is not None else nl.mean(dim=(0, 1, 3))
     return out
