@@ -483,6 +483,10 @@ int gemm_bf16a_rule(const GemmArgs& p) {
     // the pool key projection at 114688 rows 143 -> 91 us.  Below that it leaves CUs idle and loses (28 tiles: 65 vs 25 us).
     const int64_t t256 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) * nb;
     const int64_t t192 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 192) * nb;
+    // one nearly full round of 256 x 128 tiles where the 256 x 256 form would leave half the CUs idle (the wide key projection at 2 x 1792 rows,
+    // N = 1792 .. 2304: 27-28 us against 30-31 us on 256 x 192 tiles, tools/bf16a_widekeys_probe.py)
+    const int64_t t256x128 = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) * nb;
+    if (!swiglu && t256 < 140 && t256x128 >= 190 && t256x128 <= 256) return VA_256x128;
     if ((t256 >= 140 || t192 >= 140) && p.N >= 256) {
         // 256 x 192 (12 waves) when its rounds of the machine cost less tile area than the 256 x 256 form's: the SiLU-GLU input projection at 1792 rows
         // (203 tiles in one round against 154: 36.5 -> 31.8 us), the fused q/k/v projection at 14336 rows (N = 1552: 73.6 -> 62.4 us); at 14336 x 5504
